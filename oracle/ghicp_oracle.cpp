@@ -1,0 +1,867 @@
+// =====================================================================================
+//  ghicp_oracle.cpp  --  TEST INFRASTRUCTURE ONLY (CPU oracle for the GH-ICP hot path)
+//
+//  A dependency-free C++17 restatement of the reference's algorithm for the path
+//  SURVEY.md §8 names.  Only tests/, __graft_entry__.smoke() and bench.py's
+//  `cpu_baseline` leg may load this library; the product (gh-icp_amd/) never does.
+//
+//  PARITY STATUS: "parity unpinned" for every stage that goes through PCL/Eigen/FLANN
+//  (the reference ships no tests/goldens and its dependencies are not installable here,
+//  SURVEY.md §4/§8c).  Pinned pieces: Km::kmsolve/findpath/output are checked against the
+//  reference's own km.cpp compiled into oracle/_ref (see oracle/Makefile) and against the
+//  commented 3x3 known-answer vector in src/km.cpp:237-259; SBF::hammingDistance is checked
+//  against popcount.  All other stages restate upstream PCL semantics as documented below.
+//
+//  Numerics convention (DESIGN.md "numerics contract"): values the reference STORES in f32
+//  are f32 here; where the reference accumulates in f32 in an implementation-defined order
+//  (Eigen GEMM / SIMD reductions, FLANN-sorted sequential sums) the oracle accumulates in f64
+//  and rounds ONCE to f32 at the reference's storage point.  Compiled with -ffp-contract=off.
+//
+//  Every function cites the reference file:line it follows (paths under /root/reference).
+// =====================================================================================
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace orc {
+
+// ------------------------------------------------------------------ small linear algebra
+// Cyclic Jacobi for a symmetric 3x3 (f64).  Sweep order (0,1),(0,2),(1,2), 8 sweeps, a pivot
+// that is exactly zero is skipped.  V columns are the eigenvectors.  Stands in for
+// Eigen::SelfAdjointEigenSolver<Matrix3f> (pcl::PCA, pca.h:218-223) and Eigen::EigenSolver
+// (binary_feature_extraction.hpp:992-995), whose sources are not on disk.
+static void jacobi3(double a[3][3], double v[3][3]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) v[i][j] = (i == j) ? 1.0 : 0.0;
+  static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+  for (int sweep = 0; sweep < 8; sweep++) {
+    for (int k = 0; k < 3; k++) {
+      const int p = P[k], q = Q[k], r = 3 - p - q;
+      const double apq = a[p][q];
+      if (apq == 0.0) continue;
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+      const double at = std::fabs(theta);
+      double t = 1.0 / (at + std::sqrt(theta * theta + 1.0));
+      if (theta < 0.0) t = -t;
+      const double c = 1.0 / std::sqrt(t * t + 1.0);
+      const double s = t * c;
+      a[p][p] = a[p][p] - t * apq;
+      a[q][q] = a[q][q] + t * apq;
+      a[p][q] = a[q][p] = 0.0;
+      const double arp = a[r][p], arq = a[r][q];
+      a[r][p] = a[p][r] = c * arp - s * arq;
+      a[r][q] = a[q][r] = s * arp + c * arq;
+      for (int i = 0; i < 3; i++) {
+        const double vip = v[i][p], viq = v[i][q];
+        v[i][p] = c * vip - s * viq;
+        v[i][q] = s * vip + c * viq;
+      }
+    }
+  }
+}
+
+// Closest rotation to a 3x3 cross-covariance (Kabsch / Eigen::umeyama without scaling):
+// V, sigma^2 from Jacobi on A^T A (sorted descending), u1 = A v1/|.|, u2 = Gram-Schmidt(A v2),
+// u3 = u1 x u2, R = [u1 u2 u3] diag(1,1,det V) V^T.
+static void kabsch_rotation(const double A[3][3], double R[3][3]) {
+  double ata[3][3], V[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += A[k][i] * A[k][j];
+      ata[i][j] = s;
+    }
+  jacobi3(ata, V);
+  int ord[3] = {0, 1, 2};
+  // descending eigenvalue, ties -> lower index first (stable insertion sort)
+  for (int i = 1; i < 3; i++)
+    for (int j = i; j > 0 && ata[ord[j]][ord[j]] > ata[ord[j - 1]][ord[j - 1]]; j--) std::swap(ord[j], ord[j - 1]);
+  double v[3][3];  // v[c] = c-th right singular vector
+  for (int c = 0; c < 3; c++)
+    for (int i = 0; i < 3; i++) v[c][i] = V[i][ord[c]];
+  double detV = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
+                v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+  double u[3][3];
+  for (int c = 0; c < 2; c++)
+    for (int i = 0; i < 3; i++) u[c][i] = A[i][0] * v[c][0] + A[i][1] * v[c][1] + A[i][2] * v[c][2];
+  double n0 = std::sqrt(u[0][0] * u[0][0] + u[0][1] * u[0][1] + u[0][2] * u[0][2]);
+  if (n0 > 0) {
+    for (int i = 0; i < 3; i++) u[0][i] /= n0;
+  } else {
+    u[0][0] = 1; u[0][1] = 0; u[0][2] = 0;
+  }
+  double d01 = u[1][0] * u[0][0] + u[1][1] * u[0][1] + u[1][2] * u[0][2];
+  for (int i = 0; i < 3; i++) u[1][i] -= d01 * u[0][i];
+  double n1 = std::sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+  if (n1 > 1e-300) {
+    for (int i = 0; i < 3; i++) u[1][i] /= n1;
+  } else {  // rank <= 1: any unit vector orthogonal to u0 (deterministic choice)
+    int k = 0;
+    if (std::fabs(u[0][1]) < std::fabs(u[0][k])) k = 1;
+    if (std::fabs(u[0][2]) < std::fabs(u[0][k])) k = 2;
+    double e[3] = {0, 0, 0};
+    e[k] = 1;
+    double d = u[0][k];
+    for (int i = 0; i < 3; i++) u[1][i] = e[i] - d * u[0][i];
+    double nn = std::sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+    for (int i = 0; i < 3; i++) u[1][i] /= nn;
+  }
+  u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+  u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+  u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+  const double sgn = (detV < 0) ? -1.0 : 1.0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[i][j] = u[0][i] * v[0][j] + u[1][i] * v[1][j] + sgn * u[2][i] * v[2][j];
+}
+
+// ------------------------------------------------------------------ exact radius search
+// Restates pcl::KdTreeFLANN::radiusSearch semantics: exact, strict d^2 < r^2,
+// float L2 ((dx*dx + dy*dy) + dz*dz), query point included, results sorted by (d^2, index).
+// A uniform hash grid stands in for the KD-tree (same result set, same order).
+struct Grid {
+  float cell, inv;
+  float mn[3];
+  int dim[3];
+  std::vector<int> start, order;
+  const float* xyz = nullptr;
+  int n = 0;
+  int stride = 3;
+  void build(const float* p, int n_, int stride_, float cell_) {
+    xyz = p; n = n_; stride = stride_; cell = cell_; inv = 1.0f / cell_;
+    float mx[3] = {-3e38f, -3e38f, -3e38f};
+    mn[0] = mn[1] = mn[2] = 3e38f;
+    for (int i = 0; i < n; i++)
+      for (int d = 0; d < 3; d++) {
+        mn[d] = std::min(mn[d], p[(size_t)i * stride + d]);
+        mx[d] = std::max(mx[d], p[(size_t)i * stride + d]);
+      }
+    if (n == 0) mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0;
+    for (int d = 0; d < 3; d++) dim[d] = (int)std::floor((mx[d] - mn[d]) * inv) + 1;
+    size_t nc = (size_t)dim[0] * dim[1] * dim[2];
+    start.assign(nc + 1, 0);
+    std::vector<int> cellof(n);
+    for (int i = 0; i < n; i++) {
+      int c = cell_index(&p[(size_t)i * stride]);
+      cellof[i] = c;
+      start[c + 1]++;
+    }
+    for (size_t c = 0; c < nc; c++) start[c + 1] += start[c];
+    order.resize(n);
+    std::vector<int> cur(start.begin(), start.end() - 1);
+    for (int i = 0; i < n; i++) order[cur[cellof[i]]++] = i;
+  }
+  inline int coord(float v, int d) const {
+    int c = (int)std::floor((v - mn[d]) * inv);
+    return std::min(std::max(c, 0), dim[d] - 1);
+  }
+  inline int cell_index(const float* q) const { return (coord(q[0], 0) * dim[1] + coord(q[1], 1)) * dim[2] + coord(q[2], 2); }
+  // r must be <= k*cell for `reach` = k
+  void radius(const float* q, float r2, int reach, std::vector<std::pair<float, int>>& out) const {
+    out.clear();
+    int c[3] = {coord(q[0], 0), coord(q[1], 1), coord(q[2], 2)};
+    for (int x = std::max(c[0] - reach, 0); x <= std::min(c[0] + reach, dim[0] - 1); x++)
+      for (int y = std::max(c[1] - reach, 0); y <= std::min(c[1] + reach, dim[1] - 1); y++)
+        for (int z = std::max(c[2] - reach, 0); z <= std::min(c[2] + reach, dim[2] - 1); z++) {
+          int ci = (x * dim[1] + y) * dim[2] + z;
+          for (int k = start[ci]; k < start[ci + 1]; k++) {
+            int j = order[k];
+            const float* p = &xyz[(size_t)j * stride];
+            float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+            float d2 = dx * dx;
+            d2 += dy * dy;
+            d2 += dz * dz;
+            if (d2 < r2) out.emplace_back(d2, j);
+          }
+        }
+    std::sort(out.begin(), out.end());
+  }
+};
+
+// ------------------------------------------------------------------ a0: voxel filter
+// filter.hpp:28-88 incl. quirk Q1 (N phantom id_pairs with voxel 0 / idx 0 precede the real
+// ones, so the output starts with a copy of input point 0 standing for voxel 0).  The
+// representative of a voxel is its LOWEST input index (the reference's is whatever its
+// unstable std::sort leaves first: unpinned).
+static int voxel_filter(const float* xyz, int n, int stride, float voxel, int* keep) {
+  if (n <= 0) return 0;
+  const float inv = 1.0f / voxel;
+  float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+  for (int i = 0; i < n; i++)
+    for (int d = 0; d < 3; d++) {
+      mn[d] = std::min(mn[d], xyz[(size_t)i * stride + d]);
+      mx[d] = std::max(mx[d], xyz[(size_t)i * stride + d]);
+    }
+  unsigned long long max_v[3];
+  for (int d = 0; d < 3; d++) max_v[d] = (unsigned long long)(std::ceil((mx[d] - mn[d]) * inv) + 1);
+  const unsigned long long mul_x = max_v[1] * max_v[2], mul_y = max_v[2];
+  std::vector<std::pair<unsigned long long, unsigned>> pairs;
+  pairs.reserve(n);
+  for (int i = 0; i < n; i++) {
+    const float* p = &xyz[(size_t)i * stride];
+    unsigned long long vx = (unsigned long long)std::floor((p[0] - mn[0]) * inv);
+    unsigned long long vy = (unsigned long long)std::floor((p[1] - mn[1]) * inv);
+    unsigned long long vz = (unsigned long long)std::floor((p[2] - mn[2]) * inv);
+    pairs.emplace_back(vx * mul_x + vy * mul_y + vz, (unsigned)i);
+  }
+  std::sort(pairs.begin(), pairs.end());  // (voxel, idx): lowest idx first inside a voxel
+  int m = 0;
+  keep[m++] = 0;  // phantom group (voxel 0, idx 0), merged with any real voxel-0 points
+  size_t b = 0;
+  while (b < pairs.size() && pairs[b].first == 0) b++;
+  while (b < pairs.size()) {
+    keep[m++] = (int)pairs[b].second;
+    size_t e = b + 1;
+    while (e < pairs.size() && pairs[e].first == pairs[b].first) e++;
+    b = e;
+  }
+  return m;
+}
+
+// ------------------------------------------------------------------ a1: PCA / curvature
+// pca.h:133-165 + 202-250.  pcl::PCA semantics (float scatter D D^T of the de-meaned
+// neighbourhood, eigenvalues descending).  lambda[i*3..] as f32, curvature f64 exactly as
+// pca.h:240-247 computes it from the (f32-valued) doubles, count = ptNum.
+static void pca_features(const float* xyz, int m, int stride, float radius, float* lambda, double* curvature, int* count) {
+  Grid g;
+  g.build(xyz, m, stride, radius * 1.0001f);
+  const float r2 = (float)((double)radius * (double)radius);
+  std::vector<std::pair<float, int>> nb;
+  for (int i = 0; i < m; i++) {
+    g.radius(&xyz[(size_t)i * stride], r2, 1, nb);
+    const int k = (int)nb.size();
+    count[i] = k;
+    float* L = &lambda[(size_t)i * 3];
+    L[0] = L[1] = L[2] = 0.f;
+    curvature[i] = 0.0;  // std::vector<pcaFeature>(n) value-initialises (SURVEY.md A.1 probe 3)
+    if (k < 3) continue;  // pca.h:209
+    double c[3] = {0, 0, 0};
+    for (auto& e : nb)
+      for (int d = 0; d < 3; d++) c[d] += (double)xyz[(size_t)e.second * stride + d];
+    for (int d = 0; d < 3; d++) c[d] /= (double)k;
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (auto& e : nb) {
+      const float* p = &xyz[(size_t)e.second * stride];
+      double dx = (double)p[0] - c[0], dy = (double)p[1] - c[1], dz = (double)p[2] - c[2];
+      S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
+      S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
+    }
+    float Sf[6];
+    for (int q = 0; q < 6; q++) Sf[q] = (float)S[q];  // pcl::PCA holds a Matrix3f
+    double a[3][3] = {{Sf[0], Sf[1], Sf[2]}, {Sf[1], Sf[3], Sf[4]}, {Sf[2], Sf[4], Sf[5]}}, v[3][3];
+    jacobi3(a, v);
+    double ev[3] = {a[0][0], a[1][1], a[2][2]};
+    std::sort(ev, ev + 3);
+    L[0] = (float)ev[2]; L[1] = (float)ev[1]; L[2] = (float)ev[0];
+    const double l1 = L[0], l2 = L[1], l3 = L[2];
+    curvature[i] = ((l1 + l2 + l3) == 0) ? 0.0 : l3 / (l1 + l2 + l3);
+  }
+}
+
+// ------------------------------------------------------------------ a2: prune
+// keypoint_detect.hpp:132-147 (float ratios of double eigenvalues; NaN fails the compare).
+static int prune(const float* lambda, const int* count, int m, float ratio_max, int min_n, int* cand) {
+  int c = 0;
+  for (int i = 0; i < m; i++) {
+    const double l1 = lambda[(size_t)i * 3], l2 = lambda[(size_t)i * 3 + 1], l3 = lambda[(size_t)i * 3 + 2];
+    float r1 = (float)(l2 / l1), r2 = (float)(l3 / l2);
+    if (r1 < ratio_max && r2 < ratio_max && count[i] > min_n) cand[c++] = i;
+  }
+  return c;
+}
+
+// ------------------------------------------------------------------ a3: greedy NMS
+// keypoint_detect.hpp:149-191.  Order = curvature descending; ties (the reference's are
+// whatever unstable std::sort yields) broken by candidate order = lower point index first.
+static int nms(const float* xyz, int stride, const double* curvature, const int* cand, int c, float R, int* kp) {
+  if (c == 0) return 0;  // NB the reference's do-while would dereference an empty set (kd:177)
+  std::vector<int> ord(c);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return curvature[cand[a]] > curvature[cand[b]]; });
+  std::vector<float> pts((size_t)c * 3);
+  for (int r = 0; r < c; r++)
+    for (int d = 0; d < 3; d++) pts[(size_t)r * 3 + d] = xyz[(size_t)cand[ord[r]] * stride + d];
+  Grid g;
+  g.build(pts.data(), c, 3, R * 1.0001f);
+  const float r2 = (float)((double)R * (double)R);
+  std::vector<char> gone(c, 0);
+  std::vector<std::pair<float, int>> nb;
+  int k = 0;
+  for (int r = 0; r < c; r++) {
+    if (gone[r]) continue;
+    kp[k++] = cand[ord[r]];
+    g.radius(&pts[(size_t)r * 3], r2, 1, nb);
+    for (auto& e : nb) gone[e.second] = 1;
+  }
+  return k;
+}
+
+// ------------------------------------------------------------------ a4-a8: BSC
+// binary_feature_extraction.hpp (bfe).  feat: 4 variants x K x 56 bytes (unused variants stay 0),
+// lcs: K x 12 floats (x, y, z axes, origin).  pattern: 49 x 2 ints (bfe:63-117, quirk Q2).
+static void bsc_binarize(const float* weight /*>=147 (+zeros)*/, const float* depth, int ncell, const int* pattern, uint8_t* out) {
+  // bfe:464-565.  `ncell` is grid.size(): 147 for variant 0, 294 for the flip variants (Q3).
+  auto setbit = [&](int k) { if (k < 448) out[k / 8] |= (uint8_t)(1u << (k % 8)); };
+  int fd = 0;
+  for (int i = 0; i < ncell; i++) {
+    if (weight[i] > 0.1f) setbit(i);
+    fd++;
+  }
+  int offset = 0;
+  for (int nn = 0; nn < 3; nn++) {
+    double avg_d = 0, var_d = 0, avg_w = 0, var_w = 0;
+    for (int i = 0; i < 49; i++) {
+      double dd = (double)(depth[pattern[2 * i] + offset] - depth[pattern[2 * i + 1] + offset]);
+      double dw = (double)(weight[pattern[2 * i] + offset] - weight[pattern[2 * i + 1] + offset]);
+      avg_d += dd; avg_w += dw;
+    }
+    avg_d /= 49; avg_w /= 49;
+    for (int i = 0; i < 49; i++) {
+      double dd = (double)(depth[pattern[2 * i] + offset] - depth[pattern[2 * i + 1] + offset]);
+      double dw = (double)(weight[pattern[2 * i] + offset] - weight[pattern[2 * i + 1] + offset]);
+      var_d += (dd - avg_d) * (dd - avg_d);
+      var_w += (dw - avg_w) * (dw - avg_w);
+    }
+    var_d /= 49; var_w /= 49;
+    const double sd_d = std::sqrt(var_d), sd_w = std::sqrt(var_w);
+    for (int i = 0; i < 49; i++) {
+      double dd = (double)(depth[pattern[2 * i] + offset] - depth[pattern[2 * i + 1] + offset]);
+      if (std::fabs(dd - avg_d) > sd_d) setbit(fd);
+      fd++;
+      // Q4: the vacancy test ignores the plane offset (bfe:543)
+      if (!(weight[pattern[2 * i]] < 0.1f && weight[pattern[2 * i + 1]] < 0.1f)) {
+        double dw = (double)(weight[pattern[2 * i] + offset] - weight[pattern[2 * i + 1] + offset]);
+        if (std::fabs(dw - avg_w) > sd_w) setbit(fd);
+      }
+      fd++;
+    }
+    offset += 49;
+  }
+}
+
+static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K, float R, int dof, const int* pattern,
+                       uint8_t* feat, float* lcs, double* mean_nb) {
+  const double r_search = std::sqrt(3.0) * (double)R;  // bfe:641
+  const float r2s = (float)(r_search * r_search);
+  Grid g;
+  g.build(xyz, m, stride, (float)r_search * 1.0001f);
+  std::vector<std::pair<float, int>> nb;
+  std::memset(feat, 0, (size_t)4 * K * 56);
+  const float u = 2 * R / 7;            // bfe:71 unit_side_length_
+  const float delta = (float)(u * 0.5);  // bfe:204
+  const float den = 2 * delta * delta;   // bfe:239 (float)
+  const float r2c = (float)((1.5 * (double)u) * (1.5 * (double)u));
+  float centre[7];
+  for (int i = 0; i < 7; i++) centre[i] = (float)((i + 0.5) * (double)u - (double)R);  // bfe:226-227
+  const double radius_w = std::sqrt(2.0) * (double)R;  // bfe:951
+  double nb_sum = 0;
+  std::vector<float> loc;
+  for (int kk = 0; kk < K; kk++) {
+    const float* q = &xyz[(size_t)kp[kk] * stride];
+    g.radius(q, r2s, 1, nb);
+    const int mm = (int)nb.size();
+    nb_sum += mm;
+    // ---- a5: weighted PCA -> LCS (bfe:940-1035, 121-155)
+    float X[3] = {1, 0, 0}, Y[3] = {0, 1, 0}, Z[3] = {0, 0, 1};
+    if (mm >= 3) {
+      double c[3] = {0, 0, 0}, dis_all = 0;
+      for (auto& e : nb) {
+        const float* p = &xyz[(size_t)e.second * stride];
+        for (int d = 0; d < 3; d++) c[d] += (double)p[d];
+        dis_all += radius_w - (double)std::sqrt(e.first);  // Comput3DDistanceBetweenPoints: float sqrt of float d2
+      }
+      for (int d = 0; d < 3; d++) c[d] /= (double)mm;
+      double C[6] = {0, 0, 0, 0, 0, 0};
+      for (auto& e : nb) {
+        const float* p = &xyz[(size_t)e.second * stride];
+        const float w = (float)(radius_w - (double)std::sqrt(e.first));  // Q8: negative beyond sqrt2*R
+        double dx = (double)p[0] - c[0], dy = (double)p[1] - c[1], dz = (double)p[2] - c[2];
+        C[0] += (double)w * dx * dx; C[1] += (double)w * dx * dy; C[2] += (double)w * dx * dz;
+        C[3] += (double)w * dy * dy; C[4] += (double)w * dy * dz; C[5] += (double)w * dz * dz;
+      }
+      const float da = (float)dis_all;  // Matrix3f /= double scalar -> float divisor
+      float Cf[6];
+      for (int t = 0; t < 6; t++) Cf[t] = (float)C[t] / da;
+      double a[3][3] = {{Cf[0], Cf[1], Cf[2]}, {Cf[1], Cf[3], Cf[4]}, {Cf[2], Cf[4], Cf[5]}}, v[3][3];
+      jacobi3(a, v);
+      int imax = 0, imin = 0;  // bfe:999-1016 (strict compares, first index wins ties)
+      for (int i = 0; i < 3; i++) {
+        if ((float)a[i][i] > (float)a[imax][imax]) imax = i;
+        if ((float)a[i][i] < (float)a[imin][imin]) imin = i;
+      }
+      // Sign convention (EigenSolver's is implementation-defined, SURVEY.md hard part 3):
+      // the largest-magnitude component of each eigenvector is positive (lowest index on ties).
+      auto pick = [&](int col, float* o) {
+        double e[3] = {v[0][col], v[1][col], v[2][col]};
+        int b = 0;
+        if (std::fabs(e[1]) > std::fabs(e[b])) b = 1;
+        if (std::fabs(e[2]) > std::fabs(e[b])) b = 2;
+        double s = (e[b] < 0) ? -1.0 : 1.0;
+        for (int d = 0; d < 3; d++) o[d] = (float)(s * e[d]);
+      };
+      float P[3], N[3], Mid[3];
+      pick(imax, P);
+      pick(imin, N);
+      Mid[0] = P[1] * N[2] - P[2] * N[1];  // middle = principal x normal (bfe:1026)
+      Mid[1] = P[2] * N[0] - P[0] * N[2];
+      Mid[2] = P[0] * N[1] - P[1] * N[0];
+      for (int d = 0; d < 3; d++) { X[d] = P[d]; Y[d] = Mid[d]; }
+      Z[0] = X[1] * Y[2] - X[2] * Y[1];  // bfe:144 (before normalisation)
+      Z[1] = X[2] * Y[0] - X[0] * Y[2];
+      Z[2] = X[0] * Y[1] - X[1] * Y[0];
+      float nx = std::sqrt((X[0] * X[0] + X[1] * X[1]) + X[2] * X[2]);
+      float ny = std::sqrt((Y[0] * Y[0] + Y[1] * Y[1]) + Y[2] * Y[2]);
+      for (int d = 0; d < 3; d++) { X[d] = X[d] / nx; Y[d] = Y[d] / ny; }  // bfe:151-152
+    }
+    float* o = &lcs[(size_t)kk * 12];
+    for (int d = 0; d < 3; d++) { o[d] = X[d]; o[3 + d] = Y[d]; o[6 + d] = Z[d]; o[9 + d] = q[d]; }
+    // ---- a6: into the LCS (bfe:157-193; the 3-point SVD fit reduces to R=[x y z], t=0)
+    loc.resize((size_t)mm * 3);
+    for (int n = 0; n < mm; n++) {
+      const float* p = &xyz[(size_t)nb[n].second * stride];
+      float d0 = p[0] - q[0], d1 = p[1] - q[1], d2 = p[2] - q[2];
+      loc[(size_t)n * 3 + 0] = (X[0] * d0 + X[1] * d1) + X[2] * d2;
+      loc[(size_t)n * 3 + 1] = (Y[0] * d0 + Y[1] * d1) + Y[2] * d2;
+      loc[(size_t)n * 3 + 2] = (Z[0] * d0 + Z[1] * d1) + Z[2] * d2;
+    }
+    // ---- a7: 3 x (7x7) Gaussian-weighted projection grids (bfe:196-373)
+    double pnum[147], dsum[147];
+    for (int i = 0; i < 147; i++) pnum[i] = dsum[i] = 0;
+    static const int PA[3] = {0, 0, 1}, PB[3] = {1, 2, 2}, PD[3] = {2, 1, 0};
+    for (int pl = 0; pl < 3; pl++)
+      for (int n = 0; n < mm; n++) {
+        const float a = loc[(size_t)n * 3 + PA[pl]], b = loc[(size_t)n * 3 + PB[pl]];
+        const float depth = loc[(size_t)n * 3 + PD[pl]] + R;
+        for (int j = 0; j < 7; j++) {
+          const float dy = b - centre[j];
+          for (int i = 0; i < 7; i++) {
+            const float dx = a - centre[i];
+            float d2 = dx * dx;
+            d2 += dy * dy;
+            if (d2 < r2c) {
+              const float e = (float)std::exp((double)(-d2 / den));  // expf, correctly rounded
+              pnum[i + 7 * j + 49 * pl] += (double)e;
+              dsum[i + 7 * j + 49 * pl] += (double)depth * (double)e;
+            }
+          }
+        }
+      }
+    const float area = (float)(M_PI * (double)R * (double)R);  // bfe:337
+    const float ndens = (float)mm / area;                        // bfe:338
+    float weight[294], depth[294];
+    for (int i = 0; i < 147; i++) {
+      float avg = (float)dsum[i];
+      avg = (pnum[i] == 0.0) ? 0.0f : (float)((double)avg / pnum[i]);  // bfe:343-350
+      const float garea = u * u;
+      const float gdens = (float)(pnum[i] / (double)garea);
+      weight[i] = (ndens != 0.0f) ? gdens / ndens : 0.0f;
+      depth[i] = avg;
+    }
+    // ---- a8: binarise (+ flip variants with quirk Q3: [147 zero cells | re-arranged cells])
+    bsc_binarize(weight, depth, 147, pattern, &feat[((size_t)0 * K + kk) * 56]);
+    const int nvar = (dof > 4) ? 4 : (dof > 0 ? 2 : 1);
+    static const int TR[4][3] = {{0, 0, 0}, {1, 2, 2}, {3, 2, 1}, {2, 1, 3}};  // bfe:795,808,817
+    for (int vv = 1; vv < nvar; vv++) {
+      float w2[294], d2v[294];
+      for (int i = 0; i < 147; i++) w2[i] = d2v[i] = 0.f;
+      for (int pl = 0; pl < 3; pl++)
+        for (int k = 0; k < 49; k++) {
+          int src;
+          switch (TR[vv][pl]) {
+            case 1: src = 48 - k; break;                      // bfe:700-708
+            case 2: src = (6 - k / 7) * 7 + k % 7; break;     // bfe:711-723
+            default: src = (k / 7) * 7 + 6 - k % 7; break;    // bfe:726-738
+          }
+          w2[147 + 49 * pl + k] = weight[49 * pl + src];
+          d2v[147 + 49 * pl + k] = depth[49 * pl + src];
+        }
+      bsc_binarize(w2, d2v, 294, pattern, &feat[((size_t)vv * K + kk) * 56]);
+    }
+  }
+  if (mean_nb) *mean_nb = K ? nb_sum / K : 0;
+}
+
+// ------------------------------------------------------------------ a10/a11: feature distance
+static inline int popcount8(uint8_t b) { return __builtin_popcount((unsigned)b); }
+// stereo_binary_feature.cpp:87-104 (byte LUT popcount of XOR) + ghicp_reg.cpp:174-187
+static void fd_bsc(const uint8_t* fS, int ks, int V, const uint8_t* fT, int kt, double* FD) {
+  for (int i = 0; i < ks; i++)
+    for (int j = 0; j < kt; j++) {
+      int best = 1 << 30;
+      for (int v = 0; v < V; v++) {
+        const uint8_t* a = &fS[((size_t)v * ks + i) * 56];
+        const uint8_t* b = &fT[(size_t)j * 56];
+        int h = 0;
+        for (int t = 0; t < 56; t++) h += popcount8(a[t] ^ b[t]);
+        best = std::min(best, h);
+      }
+      FD[(size_t)i * kt + j] = best;
+    }
+}
+// fpfh.hpp:135-165: |Pearson correlation| in float, sequential
+static float fpfh_distance(const float* h1, const float* h2) {
+  float up = 0, d1 = 0, d2 = 0, m1 = 0, m2 = 0;
+  for (int i = 0; i < 33; i++) { m1 += h1[i]; m2 += h2[i]; }
+  m1 /= 33; m2 /= 33;
+  for (int i = 0; i < 33; i++) {
+    up += (h1[i] - m1) * (h2[i] - m2);
+    d1 += (h1[i] - m1) * (h1[i] - m1);
+    d2 += (h2[i] - m2) * (h2[i] - m2);
+  }
+  return std::fabs(up / std::sqrt(d1 * d2));
+}
+
+// ------------------------------------------------------------------ a15: Kuhn-Munkres
+// km.cpp:13-126 restated 1:1 (recursive DFS in ascending y, eps-tight test, slack array
+// re-initialised per root, INF2 = 1000).
+struct KM {
+  int n;
+  const double* w;  // n x n row-major
+  double eps;
+  std::vector<int> match;
+  std::vector<double> lx, ly, slack;
+  std::vector<char> visx, visy;
+  long long steps = 0;
+  bool findpath(int x) {  // km.cpp:13-37
+    visx[x] = 1;
+    steps++;
+    for (int y = 0; y < n; ++y) {
+      if (visy[y]) continue;
+      double t = lx[x] + ly[y] - w[(size_t)x * n + y];
+      if (t < eps) {
+        visy[y] = 1;
+        if (match[y] == -1 || findpath(match[y])) {
+          match[y] = x;
+          return true;
+        }
+      } else {
+        slack[y] = std::min(t, slack[y]);
+      }
+    }
+    return false;
+  }
+  void solve() {  // km.cpp:40-99
+    const int INF2 = 1000;
+    match.assign(n, -1); ly.assign(n, 0.0); lx.resize(n); slack.resize(n); visx.resize(n); visy.resize(n);
+    for (int i = 0; i < n; i++) {
+      lx[i] = w[(size_t)i * n];
+      for (int j = 0; j < n; j++) lx[i] = std::max(w[(size_t)i * n + j], lx[i]);
+    }
+    for (int x = 0; x < n; ++x) {
+      for (int j = 0; j < n; j++) slack[j] = INF2;
+      while (true) {
+        std::fill(visx.begin(), visx.end(), 0);
+        std::fill(visy.begin(), visy.end(), 0);
+        if (findpath(x)) break;
+        double delta = INF2;
+        for (int j = 0; j < n; j++)
+          if (!visy[j]) delta = std::min(delta, slack[j]);
+        for (int i = 0; i < n; i++)
+          if (visx[i]) lx[i] -= delta;
+        for (int i = 0; i < n; i++) {
+          if (visy[i]) ly[i] += delta;
+          else slack[i] -= delta;
+        }
+      }
+    }
+  }
+};
+
+}  // namespace orc
+
+// =====================================================================================
+//                                     C interface
+// =====================================================================================
+extern "C" {
+
+struct orc_params {  // mirrors GHRegistration ctor + Energyfunction::init (ghicp_reg.h:26-41, 77-117)
+  int feature;  // utility.h:51-57  BSC=0 RoPS=1 FPFH=2 None=3
+  int corr;     // utility.h:59-64  NN=0 NNR=1 KM=2
+  int dof;      // 4 or 6
+  int max_iter; // guard (the reference has none, ghicp_reg.cpp:49)
+  float radius_nonmax, adjust_ratio, adjust_step, est_iou;
+  float converge_t, converge_r;
+  float bbx_magnitude;
+  float pad_;
+  double penalty_initial, para1, para2, km_eps;
+  int min_cor, weight_changing_rate;
+};
+
+struct orc_iter {  // one iteration of ghicp_reg.cpp:49-103
+  int cor, converged;
+  double penalty, cdmean, cdstd, rmse, rmse_after, fdm, fdstd, iou, para1, para2, energy;
+  double Rt[16];  // this iteration's Rt_temp, row-major
+};
+
+int orc_voxel_filter(const float* xyz, int n, int stride, float voxel, int* keep) { return orc::voxel_filter(xyz, n, stride, voxel, keep); }
+void orc_pca(const float* xyz, int m, int stride, float radius, float* lambda, double* curvature, int* count) {
+  orc::pca_features(xyz, m, stride, radius, lambda, curvature, count);
+}
+int orc_prune(const float* lambda, const int* count, int m, float ratio_max, int min_n, int* cand) {
+  return orc::prune(lambda, count, m, ratio_max, min_n, cand);
+}
+int orc_nms(const float* xyz, int stride, const double* curvature, const int* cand, int c, float R, int* kp) {
+  return orc::nms(xyz, stride, curvature, cand, c, R, kp);
+}
+// keypoint_detect.hpp:27-51
+int orc_keypoints(const float* xyz, int m, int stride, float radius, float ratio_max, int min_n, float R_nms, int* kp, double* mean_nb) {
+  std::vector<float> lambda((size_t)m * 3);
+  std::vector<double> curv(m);
+  std::vector<int> count(m), cand(m);
+  orc::pca_features(xyz, m, stride, radius, lambda.data(), curv.data(), count.data());
+  if (mean_nb) { double s = 0; for (int i = 0; i < m; i++) s += count[i]; *mean_nb = m ? s / m : 0; }
+  int c = orc::prune(lambda.data(), count.data(), m, ratio_max, min_n, cand.data());
+  return orc::nms(xyz, stride, curv.data(), cand.data(), c, R_nms, kp);
+}
+void orc_bsc(const float* xyz, int m, int stride, const int* kp, int K, float R, int dof, const int* pattern, uint8_t* feat, float* lcs,
+             double* mean_nb) {
+  orc::bsc_encode(xyz, m, stride, kp, K, R, dof, pattern, feat, lcs, mean_nb);
+}
+void orc_bsc_binarize(const float* weight, const float* depth, int ncell, const int* pattern, uint8_t* out56) {
+  std::memset(out56, 0, 56);
+  orc::bsc_binarize(weight, depth, ncell, pattern, out56);
+}
+void orc_fd_bsc(const uint8_t* fS, int ks, int V, const uint8_t* fT, int kt, double* FD) { orc::fd_bsc(fS, ks, V, fT, kt, FD); }
+void orc_fd_fpfh(const float* hS, int ks, const float* hT, int kt, double* FD) {
+  for (int i = 0; i < ks; i++)
+    for (int j = 0; j < kt; j++) FD[(size_t)i * kt + j] = orc::fpfh_distance(&hS[(size_t)i * 33], &hT[(size_t)j * 33]);
+}
+long long orc_km(const double* w, int n, double eps, int* match) {
+  orc::KM km;
+  km.n = n; km.w = w; km.eps = eps;
+  km.solve();
+  for (int i = 0; i < n; i++) match[i] = km.match[i];
+  return km.steps;
+}
+void orc_jacobi3(const double* a_in, double* eval, double* evec) {
+  double a[3][3], v[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = a_in[i * 3 + j];
+  orc::jacobi3(a, v);
+  for (int i = 0; i < 3; i++) { eval[i] = a[i][i]; for (int j = 0; j < 3; j++) evec[i * 3 + j] = v[i][j]; }
+}
+// pcl::registration::TransformationEstimationSVD<PointXYZ,PointXYZ> (float umeyama, no scale):
+// ghicp_reg.cpp:839-866.  src/tgt are c x 3 f64 (cast to f32 as the reference does), Rt 4x4 f32 values.
+void orc_rigid_svd(const double* src, const double* tgt, int c, double* Rt16) {
+  double ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0};
+  for (int i = 0; i < c; i++)
+    for (int d = 0; d < 3; d++) { ms[d] += (double)(float)src[(size_t)i * 3 + d]; mt[d] += (double)(float)tgt[(size_t)i * 3 + d]; }
+  float msf[3], mtf[3];
+  for (int d = 0; d < 3; d++) { msf[d] = (float)(ms[d] / c); mtf[d] = (float)(mt[d] / c); }
+  double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int i = 0; i < c; i++) {
+    double a[3], b[3];
+    for (int d = 0; d < 3; d++) { a[d] = (double)(float)tgt[(size_t)i * 3 + d] - (double)mtf[d]; b[d] = (double)(float)src[(size_t)i * 3 + d] - (double)msf[d]; }
+    for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) H[r][q] += a[r] * b[q];
+  }
+  double A[3][3], R[3][3];
+  for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) A[r][q] = (double)(float)(H[r][q] / c);
+  orc::kabsch_rotation(A, R);
+  float Rf[3][3], tf[3];
+  for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) Rf[r][q] = (float)R[r][q];
+  for (int r = 0; r < 3; r++)
+    tf[r] = (float)((double)mtf[r] - (((double)Rf[r][0] * (double)msf[0] + (double)Rf[r][1] * (double)msf[1]) + (double)Rf[r][2] * (double)msf[2]));
+  for (int i = 0; i < 16; i++) Rt16[i] = 0;
+  for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) Rt16[r * 4 + q] = Rf[r][q]; Rt16[r * 4 + 3] = tf[r]; }
+  Rt16[15] = 1;
+}
+
+// GHRegistration::ghicp_reg (src/ghicp_reg.cpp:24-112) and everything it calls.
+//   kpS/kpT : K x 3 f64 (Keypoints::setCoordinate, ghicp_reg.h:53-59).  kpS is NOT modified.
+//   FD      : ks x kt f64 row-major (calFD_* output) or NULL for feature None.
+//   trace   : max_iter records; matchlist: max_iter x ks ints (T index or -1) or NULL.
+// Returns the number of iterations executed.
+int orc_register(const orc_params* P, const double* kpS_in, int ks, const double* kpT, int kt, const double* FD, double* Rt_final,
+                 orc_iter* trace, int* matchlist, double* km_seconds) {
+  const int BSC = 0, NONE = 3, NN = 0, NNR = 1, KMc = 2;
+  std::vector<double> kpS(kpS_in, kpS_in + (size_t)ks * 3);
+  std::vector<double> ED((size_t)ks * kt), CD((size_t)ks * kt);
+  const float scale = (float)(0.005 * P->bbx_magnitude);  // ghicp_reg.h:40
+  double para1 = P->para1, para2 = P->para2, penalty = 0;
+  double RMS = 99999, FDM = 0, FDstd = 0, IoU = 0;
+  double Rt_till[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  bool converge = false;
+  int it = 0;
+  double km_time = 0;
+  std::vector<int> SP, TP;
+  while (!converge && it < P->max_iter) {
+    orc_iter rec;
+    std::memset(&rec, 0, sizeof(rec));
+    // calED (ghicp_reg.cpp:114-139)
+    for (int i = 0; i < ks; i++)
+      for (int j = 0; j < kt; j++) {
+        double dx = kpS[(size_t)i * 3] - kpT[(size_t)j * 3], dy = kpS[(size_t)i * 3 + 1] - kpT[(size_t)j * 3 + 1],
+               dz = kpS[(size_t)i * 3 + 2] - kpT[(size_t)j * 3 + 2];
+        ED[(size_t)i * kt + j] = scale * std::sqrt(dx * dx + dy * dy + dz * dz);
+      }
+    double CDmean = 0, CDstd = 0;
+    const double nn = (double)ks * kt;
+    if (P->feature == NONE) {  // calCD_NF :216-243 (Q6)
+      double s = 0;
+      for (size_t e = 0; e < ED.size(); e++) { CD[e] = ED[e]; s += CD[e]; }
+      CDmean = s / kt / ks;
+      penalty = std::max(CDmean, 1.0);
+    } else if (P->feature == BSC) {  // calCD_BSC :245-293
+      const double WFD = std::exp(-1.0 * it / P->weight_changing_rate), WED = 1.0 - WFD;
+      double s = 0, s2 = 0;
+      for (size_t e = 0; e < ED.size(); e++) { CD[e] = WED * ED[e] + WFD * FD[e]; s += CD[e]; }
+      CDmean = s / kt / ks;
+      for (size_t e = 0; e < ED.size(); e++) s2 += (CD[e] - CDmean) * (CD[e] - CDmean);
+      CDstd = std::sqrt(s2 / kt / ks);
+      if (it > 1) penalty = RMS * para1 * scale * WED + (FDM + para2 * FDstd) * WFD;
+      else penalty = CDmean - P->penalty_initial * CDstd;
+      penalty = std::max(penalty, 5.0);
+    } else {  // calCD_FPFH :295-341
+      double s = 0;
+      for (size_t e = 0; e < ED.size(); e++) { CD[e] = 1.0 * ED[e] / std::pow(FD[e], 1.0 / (it + 1)); s += CD[e]; }
+      CDmean = s / ks / kt;
+      if (it > 1) penalty = RMS * para1 * scale * para2;
+      else penalty = CDmean / P->penalty_initial;
+    }
+    (void)nn;
+    rec.cdmean = CDmean; rec.cdstd = CDstd; rec.penalty = penalty;
+    SP.clear(); TP.clear();
+    if (P->corr == NN) {  // findcorrespondenceNN :700-769
+      for (int i = 0; i < ks; i++) {
+        double mincd = 9e20; int mi = 0;
+        for (int j = 0; j < kt; j++) if (CD[(size_t)i * kt + j] < mincd) { mincd = CD[(size_t)i * kt + j]; mi = j; }
+        if (mincd < penalty) { SP.push_back(i); TP.push_back(mi); }
+      }
+    } else if (P->corr == NNR) {  // findcorrespondenceNNR :605-698 (Q7: no penalty test)
+      std::vector<int> SV(ks), TV(kt);
+      for (int i = 0; i < ks; i++) {
+        double mincd = 9e20; int mi = 0;
+        for (int j = 0; j < kt; j++) if (CD[(size_t)i * kt + j] < mincd) { mincd = CD[(size_t)i * kt + j]; mi = j; }
+        SV[i] = mi;
+      }
+      for (int j = 0; j < kt; j++) {
+        double mincd = 9e20; int mi = 0;
+        for (int i = 0; i < ks; i++) if (CD[(size_t)i * kt + j] < mincd) { mincd = CD[(size_t)i * kt + j]; mi = i; }
+        TV[j] = mi;
+      }
+      for (int i = 0; i < ks; i++) if (kt > 0 && TV[SV[i]] == i) { SP.push_back(i); TP.push_back(SV[i]); }
+    } else if (P->corr == KMc) {  // findcorrespondenceKM :343-460
+      auto t0 = std::chrono::steady_clock::now();
+      const int n = std::max(ks, kt);
+      std::vector<double> gw((size_t)n * n, -penalty);
+      for (int i = 0; i < ks; i++)
+        for (int j = 0; j < kt; j++) if (CD[(size_t)i * kt + j] < penalty) gw[(size_t)i * n + j] = -CD[(size_t)i * kt + j];
+      orc::KM km;
+      km.n = n; km.w = gw.data(); km.eps = P->km_eps;
+      km.solve();
+      // Km::output km.cpp:144-233 (ascending y; exact compare with -penalty)
+      double energy = 0;
+      for (int y = 0; y < n; y++) {
+        const double g = gw[(size_t)km.match[y] * n + y];
+        if (g != -penalty) { SP.push_back(km.match[y]); TP.push_back(y); }
+        if (g != -10000) energy -= g;  // Calenergy km.cpp:128-141 (INF = 10000)
+      }
+      rec.energy = energy;
+      km_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    const int cor = (int)SP.size();
+    rec.cor = cor;
+    if (matchlist) {
+      int* ml = &matchlist[(size_t)it * ks];
+      for (int i = 0; i < ks; i++) ml[i] = -1;
+      for (int c = 0; c < cor; c++) ml[SP[c]] = TP[c];
+    }
+    // RMSE / FDM / FDstd (:548-578, :675-695, :746-766).  For feature None the reference reads an
+    // FD matrix that Energyfunction::init zero-filled, so FDM = FDstd = 0 (unused there).
+    double RMSE = 0, FDcul = 0;
+    FDM = 0; FDstd = 0;
+    for (int c = 0; c < cor; c++) {
+      const double* s = &kpS[(size_t)SP[c] * 3]; const double* t = &kpT[(size_t)TP[c] * 3];
+      RMSE += (s[0] - t[0]) * (s[0] - t[0]) + (s[1] - t[1]) * (s[1] - t[1]) + (s[2] - t[2]) * (s[2] - t[2]);
+      FDM += FD ? FD[(size_t)SP[c] * kt + TP[c]] : 0.0;
+    }
+    FDM /= cor;
+    for (int c = 0; c < cor; c++) { double f = (FD ? FD[(size_t)SP[c] * kt + TP[c]] : 0.0) - FDM; FDcul += f * f; }
+    FDstd = std::sqrt(FDcul / cor);
+    RMSE = std::sqrt(RMSE / cor);
+    RMS = RMSE;
+    rec.rmse = RMSE; rec.fdm = FDM; rec.fdstd = FDstd;
+    // transformestimation :791-927
+    if (cor < P->min_cor) converge = true;
+    IoU = 1.0 * cor / (ks + kt - cor);
+    rec.iou = IoU;
+    std::vector<double> Sp((size_t)cor * 3), Tp((size_t)cor * 3);
+    for (int c = 0; c < cor; c++)
+      for (int d = 0; d < 3; d++) { Sp[(size_t)c * 3 + d] = kpS[(size_t)SP[c] * 3 + d]; Tp[(size_t)c * 3 + d] = kpT[(size_t)TP[c] * 3 + d]; }
+    double Rt[16];
+    orc_rigid_svd(Sp.data(), Tp.data(), cor, Rt);
+    std::memcpy(rec.Rt, Rt, sizeof(Rt));
+    const double* R = Rt;
+    const double dx = Rt[3], dy = Rt[7], dz = Rt[11];
+    double ax = std::atan2(R[9], R[10]);
+    double ay = std::atan2(-R[8], std::sqrt(R[9] * R[9] + R[10] * R[10]));
+    double az = std::atan2(R[1], R[0]);
+    const double pi = 3.1415926;
+    ax = ax / pi * 180; ay = ay / pi * 180; az = az / pi * 180;
+    auto apply = [&](double* p) {
+      double x = p[0], y = p[1], z = p[2];
+      p[0] = ((R[0] * x + R[1] * y) + R[2] * z) + Rt[3];
+      p[1] = ((R[4] * x + R[5] * y) + R[6] * z) + Rt[7];
+      p[2] = ((R[8] * x + R[9] * y) + R[10] * z) + Rt[11];
+    };
+    for (int i = 0; i < ks; i++) apply(&kpS[(size_t)i * 3]);
+    double after = 0;
+    for (int c = 0; c < cor; c++) {
+      apply(&Sp[(size_t)c * 3]);
+      for (int d = 0; d < 3; d++) after += (Sp[(size_t)c * 3 + d] - Tp[(size_t)c * 3 + d]) * (Sp[(size_t)c * 3 + d] - Tp[(size_t)c * 3 + d]);
+    }
+    after = std::sqrt(after / cor);
+    rec.rmse_after = after;
+    if (std::fabs(dx) < P->converge_t && std::fabs(dy) < P->converge_t && std::fabs(dz) < P->converge_t && std::fabs(ax) < P->converge_r &&
+        std::fabs(ay) < P->converge_r && std::fabs(az) < P->converge_r)
+      converge = true;
+    // adjustweight :771-789
+    if (P->est_iou / IoU > P->adjust_ratio) { para1 += P->adjust_step; para2 += P->adjust_step; }
+    else if (IoU / P->est_iou > P->adjust_ratio) { para1 -= P->adjust_step; para2 -= P->adjust_step; }
+    rec.para1 = para1; rec.para2 = para2;
+    // Rt_tillnow = Rt_temp * Rt_tillnow  (:93)
+    double nt[16];
+    for (int r = 0; r < 4; r++)
+      for (int c = 0; c < 4; c++) {
+        double s = 0;
+        for (int k = 0; k < 4; k++) s += Rt[r * 4 + k] * Rt_till[k * 4 + c];
+        nt[r * 4 + c] = s;
+      }
+    std::memcpy(Rt_till, nt, sizeof(nt));
+    rec.converged = converge ? 1 : 0;
+    if (trace) trace[it] = rec;
+    it++;
+  }
+  std::memcpy(Rt_final, Rt_till, sizeof(Rt_till));
+  if (km_seconds) *km_seconds = km_time;
+  return it;
+}
+
+// pcl::transformPointCloud with Rt_final.cast<float>() (test/ghicp_main.cpp:153): float 4x4 * (x,y,z,1)
+void orc_transform_cloud(const float* xyz, int n, int stride, const double* Rt, float* out) {
+  float M[12];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) M[r * 4 + c] = (float)Rt[r * 4 + c];
+  for (int i = 0; i < n; i++) {
+    const float* p = &xyz[(size_t)i * stride];
+    for (int r = 0; r < 3; r++) out[(size_t)i * 3 + r] = ((M[r * 4] * p[0] + M[r * 4 + 1] * p[1]) + M[r * 4 + 2] * p[2]) + M[r * 4 + 3];
+  }
+}
+
+// bounding-box magnitude of the down-sampled source (test/ghicp_main.cpp:91-93)
+float orc_bbx_magnitude(const float* xyz, int n, int stride) {
+  if (n <= 0) return 0.f;
+  double mn[3], mx[3];
+  for (int d = 0; d < 3; d++) mn[d] = mx[d] = xyz[d];
+  for (int i = 0; i < n; i++)
+    for (int d = 0; d < 3; d++) {
+      double v = xyz[(size_t)i * stride + d];
+      if (mn[d] > v) mn[d] = v;
+      if (mx[d] < v) mx[d] = v;
+    }
+  return (float)(mx[0] - mn[0] + mx[1] - mn[1] + mx[2] - mn[2]);
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
+the product package.  See oracle/ghicp_oracle.cpp for what each entry restates (file:line).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BSC, ROPS, FPFH, NONE = 0, 1, 2, 3  # utility.h:51-57
+NN, NNR, KM = 0, 1, 2  # utility.h:59-64
+
+
+class Params(C.Structure):
+    _fields_ = [("feature", C.c_int), ("corr", C.c_int), ("dof", C.c_int), ("max_iter", C.c_int),
+                ("radius_nonmax", C.c_float), ("adjust_ratio", C.c_float), ("adjust_step", C.c_float),
+                ("est_iou", C.c_float), ("converge_t", C.c_float), ("converge_r", C.c_float),
+                ("bbx_magnitude", C.c_float), ("pad_", C.c_float),
+                ("penalty_initial", C.c_double), ("para1", C.c_double), ("para2", C.c_double),
+                ("km_eps", C.c_double), ("min_cor", C.c_int), ("weight_changing_rate", C.c_int)]
+
+
+class Iter(C.Structure):
+    _fields_ = [("cor", C.c_int), ("converged", C.c_int)] + [
+        (k, C.c_double) for k in ("penalty", "cdmean", "cdstd", "rmse", "rmse_after", "fdm", "fdstd",
+                                  "iou", "para1", "para2", "energy")] + [("Rt", C.c_double * 16)]
+
+
+def default_params(feature=NONE, corr=NN, dof=6, est_iou=0.6, radius_nonmax=1.5, bbx_magnitude=100.0,
+                   adjust_ratio=1.1, adjust_step=0.1, max_iter=200) -> Params:
+    """Reference defaults: README.md:79-85, ghicp_reg.h:32-40,80."""
+    return Params(feature, corr, dof, max_iter, radius_nonmax, adjust_ratio, adjust_step, est_iou,
+                  0.02, 0.02, bbx_magnitude, 0.0, 2.0, 1.0, 1.0, 0.01, 10, 6)
+
+
+def build(force: bool = False) -> None:
+    so = os.path.join(_HERE, "libghicp_oracle.so")
+    src = os.path.join(_HERE, "ghicp_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libghicp_oracle.so"], stdout=subprocess.DEVNULL)
+    ref = os.path.join(_HERE, "_ref", "libkm_ref.so")
+    if os.path.exists("/root/reference/src/km.cpp") and (force or not os.path.exists(ref)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(os.path.join(_HERE, "libghicp_oracle.so"))
+        _lib.orc_km.restype = C.c_longlong
+        _lib.orc_bbx_magnitude.restype = C.c_float
+    return _lib
+
+
+def ref_lib():
+    """The reference's own km.cpp (oracle/_ref/libkm_ref.so) or None when it was not built."""
+    global _ref
+    if _ref is None:
+        p = os.path.join(_HERE, "_ref", "libkm_ref.so")
+        if not os.path.exists(p):
+            try:
+                build()
+            except Exception:
+                pass
+        if os.path.exists(p):
+            _ref = C.CDLL(p)
+    return _ref
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def voxel_filter(xyz, voxel):
+    xyz = _f32(xyz)
+    keep = np.empty(xyz.shape[0] + 1, dtype=np.int32)
+    m = lib().orc_voxel_filter(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], C.c_float(voxel), _p(keep, C.c_int))
+    return keep[:m].copy()
+
+
+def pca(xyz, radius):
+    xyz = _f32(xyz)
+    m = xyz.shape[0]
+    lam = np.zeros((m, 3), np.float32)
+    curv = np.zeros(m, np.float64)
+    cnt = np.zeros(m, np.int32)
+    lib().orc_pca(_p(xyz, C.c_float), m, xyz.shape[1], C.c_float(radius), _p(lam, C.c_float), _p(curv, C.c_double), _p(cnt, C.c_int))
+    return lam, curv, cnt
+
+
+def prune(lam, cnt, ratio_max=0.65, min_n=20):
+    lam = _f32(lam)
+    cnt = np.ascontiguousarray(cnt, np.int32)
+    cand = np.empty(lam.shape[0], np.int32)
+    c = lib().orc_prune(_p(lam, C.c_float), _p(cnt, C.c_int), lam.shape[0], C.c_float(ratio_max), min_n, _p(cand, C.c_int))
+    return cand[:c].copy()
+
+
+def nms(xyz, curv, cand, R):
+    xyz = _f32(xyz)
+    curv = np.ascontiguousarray(curv, np.float64)
+    cand = np.ascontiguousarray(cand, np.int32)
+    kp = np.empty(max(1, cand.size), np.int32)
+    k = lib().orc_nms(_p(xyz, C.c_float), xyz.shape[1], _p(curv, C.c_double), _p(cand, C.c_int), cand.size, C.c_float(R), _p(kp, C.c_int))
+    return kp[:k].copy()
+
+
+def keypoints(xyz, radius, R_nms, ratio_max=0.65, min_n=20):
+    xyz = _f32(xyz)
+    kp = np.empty(max(1, xyz.shape[0]), np.int32)
+    mean_nb = C.c_double(0)
+    k = lib().orc_keypoints(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], C.c_float(radius), C.c_float(ratio_max), min_n,
+                            C.c_float(R_nms), _p(kp, C.c_int), C.byref(mean_nb))
+    return kp[:k].copy(), mean_nb.value
+
+
+def bsc(xyz, kp, R, dof, pattern):
+    xyz = _f32(xyz)
+    kp = np.ascontiguousarray(kp, np.int32)
+    pattern = np.ascontiguousarray(pattern, np.int32)
+    K = kp.size
+    feat = np.zeros((4, K, 56), np.uint8)
+    lcs = np.zeros((K, 12), np.float32)
+    mean_nb = C.c_double(0)
+    lib().orc_bsc(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], _p(kp, C.c_int), K, C.c_float(R), dof, _p(pattern, C.c_int),
+                  _p(feat, C.c_ubyte), _p(lcs, C.c_float), C.byref(mean_nb))
+    return feat, lcs, mean_nb.value
+
+
+def bsc_binarize(weight, depth, pattern):
+    weight, depth = _f32(weight), _f32(depth)
+    pattern = np.ascontiguousarray(pattern, np.int32)
+    out = np.zeros(56, np.uint8)
+    lib().orc_bsc_binarize(_p(weight, C.c_float), _p(depth, C.c_float), weight.size, _p(pattern, C.c_int), _p(out, C.c_ubyte))
+    return out
+
+
+def fd_bsc(fS, fT):
+    """fS: (V,ks,56) u8, fT: (kt,56) u8 -> (ks,kt) f64"""
+    fS = np.ascontiguousarray(fS, np.uint8)
+    fT = np.ascontiguousarray(fT, np.uint8)
+    V, ks, _ = fS.shape
+    kt = fT.shape[0]
+    FD = np.zeros((ks, kt), np.float64)
+    lib().orc_fd_bsc(_p(fS, C.c_ubyte), ks, V, _p(fT, C.c_ubyte), kt, _p(FD, C.c_double))
+    return FD
+
+
+def fd_fpfh(hS, hT):
+    hS, hT = _f32(hS), _f32(hT)
+    FD = np.zeros((hS.shape[0], hT.shape[0]), np.float64)
+    lib().orc_fd_fpfh(_p(hS, C.c_float), hS.shape[0], _p(hT, C.c_float), hT.shape[0], _p(FD, C.c_double))
+    return FD
+
+
+def km(w, eps=0.01):
+    w = np.ascontiguousarray(w, np.float64)
+    n = w.shape[0]
+    match = np.empty(n, np.int32)
+    steps = lib().orc_km(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int))
+    return match, steps
+
+
+def km_reference(w, eps=0.01, penalty=0.0):
+    """The reference's own Km::kmsolve (compiled from /root/reference/src/km.cpp)."""
+    r = ref_lib()
+    if r is None:
+        return None
+    w = np.ascontiguousarray(w, np.float64)
+    n = w.shape[0]
+    match = np.empty(n, np.int32)
+    r.ref_km_solve(_p(w, C.c_double), n, C.c_double(eps), C.c_double(penalty), _p(match, C.c_int))
+    return match
+
+
+def jacobi3(a):
+    a = np.ascontiguousarray(a, np.float64)
+    ev = np.zeros(3)
+    evec = np.zeros((3, 3))
+    lib().orc_jacobi3(_p(a, C.c_double), _p(ev, C.c_double), _p(evec, C.c_double))
+    return ev, evec
+
+
+def rigid_svd(src, tgt):
+    src = np.ascontiguousarray(src, np.float64)
+    tgt = np.ascontiguousarray(tgt, np.float64)
+    Rt = np.zeros(16)
+    lib().orc_rigid_svd(_p(src, C.c_double), _p(tgt, C.c_double), src.shape[0], _p(Rt, C.c_double))
+    return Rt.reshape(4, 4)
+
+
+def register(params: Params, kpS, kpT, FD=None, want_matchlist=False):
+    """Returns dict(Rt, iters, trace[list of dict], matchlist, km_seconds)."""
+    kpS = np.ascontiguousarray(kpS, np.float64)
+    kpT = np.ascontiguousarray(kpT, np.float64)
+    ks, kt = kpS.shape[0], kpT.shape[0]
+    Rt = np.zeros(16)
+    trace = (Iter * params.max_iter)()
+    ml = np.full((params.max_iter, ks), -2, np.int32) if want_matchlist else None
+    fdp = None
+    if FD is not None:
+        FD = np.ascontiguousarray(FD, np.float64)
+        assert FD.shape == (ks, kt)
+        fdp = _p(FD, C.c_double)
+    kms = C.c_double(0)
+    it = lib().orc_register(C.byref(params), _p(kpS, C.c_double), ks, _p(kpT, C.c_double), kt, fdp, _p(Rt, C.c_double), trace,
+                            _p(ml, C.c_int) if ml is not None else None, C.byref(kms))
+    tr = []
+    for i in range(it):
+        r = trace[i]
+        d = {k: getattr(r, k) for k, _ in Iter._fields_ if k != "Rt"}
+        d["Rt"] = np.array(r.Rt[:]).reshape(4, 4)
+        tr.append(d)
+    return dict(Rt=Rt.reshape(4, 4), iters=it, trace=tr, matchlist=None if ml is None else ml[:it], km_seconds=kms.value)
+
+
+def transform_cloud(xyz, Rt):
+    xyz = _f32(xyz)
+    Rt = np.ascontiguousarray(Rt, np.float64)
+    out = np.empty((xyz.shape[0], 3), np.float32)
+    lib().orc_transform_cloud(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], _p(Rt, C.c_double), _p(out, C.c_float))
+    return out
+
+
+def bbx_magnitude(xyz):
+    xyz = _f32(xyz)
+    return float(lib().orc_bbx_magnitude(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1]))
