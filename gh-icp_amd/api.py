@@ -1,0 +1,299 @@
+"""ctypes binding of libghicp_hip.so (include/ghicp_c.h) for tests and bench.py.
+
+PyTorch is used only as the owner of device memory and streams; every compute call goes through
+the C ABI into the HIP kernels.  There is NO CPU fallback: a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libghicp_hip.so")
+
+FEATURE_BSC, FEATURE_ROPS, FEATURE_FPFH, FEATURE_NONE = 0, 1, 2, 3
+CORR_NN, CORR_NNR, CORR_KM = 0, 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [("feature", C.c_int32), ("corr", C.c_int32), ("dof", C.c_int32), ("max_iter", C.c_int32),
+                ("radius_nonmax", C.c_float), ("adjust_ratio", C.c_float), ("adjust_step", C.c_float),
+                ("est_iou", C.c_float), ("converge_t", C.c_float), ("converge_r", C.c_float),
+                ("bbx_magnitude", C.c_float), ("pad_", C.c_float),
+                ("penalty_initial", C.c_double), ("para1", C.c_double), ("para2", C.c_double),
+                ("km_eps", C.c_double), ("min_cor", C.c_int32), ("weight_changing_rate", C.c_int32)]
+
+
+class Iter(C.Structure):
+    _fields_ = [("cor", C.c_int32), ("converged", C.c_int32)] + [
+        (k, C.c_double) for k in ("penalty", "cdmean", "cdstd", "rmse", "rmse_after", "fdm", "fdstd",
+                                  "iou", "para1", "para2", "energy")] + [("Rt", C.c_double * 16)]
+
+
+class PairConfig(C.Structure):
+    _fields_ = [("reg", Params), ("voxel", C.c_float), ("neighborhood_radius", C.c_float),
+                ("ratio_max", C.c_float), ("min_neighbors", C.c_int32), ("pattern", C.c_int32 * 98)]
+
+
+class PairStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_s", "n_t", "m_s", "m_t", "k_s", "k_t")] + [
+        ("iterations", C.c_int32), ("converged", C.c_int32), ("Rt", C.c_double * 16), ("bbx_magnitude", C.c_float)] + [
+        (k, C.c_float) for k in ("ms_voxel", "ms_keypoints", "ms_feature", "ms_fd", "ms_loop", "ms_total")]
+
+
+EXPORTS = [
+    "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers",
+    "ghicp_ctx_synchronize", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
+    "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
+    "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
+    "ghicp_rigid_svd", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
+]
+
+_lib = None
+
+
+class GhicpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GhicpError("libghicp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(or make -C gh-icp_amd/csrc). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ghicp_last_error.restype = C.c_char_p
+        _lib.ghicp_version.restype = C.c_char_p
+    return _lib
+
+
+def default_params(feature=FEATURE_BSC, corr=CORR_KM, dof=6, est_iou=0.6, radius_nonmax=1.5, bbx_magnitude=0.0,
+                   max_iter=200) -> Params:
+    p = Params()
+    load().ghicp_params_default(C.byref(p))
+    p.feature, p.corr, p.dof, p.est_iou, p.radius_nonmax = feature, corr, dof, est_iou, radius_nonmax
+    p.bbx_magnitude, p.max_iter = bbx_magnitude, max_iter
+    return p
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One ghicp_ctx bound to a device (and optionally a torch stream)."""
+
+    def __init__(self, device: int = 0, stream=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise GhicpError("no GPU visible: the GH-ICP hot path has no CPU fallback")
+        self.torch = torch
+        self.lib = load()
+        self.device = device
+        h = C.c_void_p()
+        rc = self.lib.ghicp_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise GhicpError("ghicp_ctx_create failed with code %d" % rc)
+        self.h = h
+        if stream is not None:
+            self.set_stream(stream)
+        self.dev = torch.device("cuda", device)
+
+    def set_stream(self, stream):
+        self._check(self.lib.ghicp_ctx_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ghicp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise GhicpError("ghicp error %d: %s" % (rc, self.lib.ghicp_last_error(self.h).decode()))
+
+    def sync(self):
+        self._check(self.lib.ghicp_ctx_synchronize(self.h))
+
+    def _dev(self, a, dtype):
+        t = self.torch
+        if isinstance(a, np.ndarray):
+            a = t.from_numpy(np.ascontiguousarray(a))
+        return a.to(device=self.dev, dtype=dtype).contiguous()
+
+    # ---------------------------------------------------------------- per pair
+    def fd_bsc(self, featS, featT):
+        """featS (V,ks,56) u8, featT (kt,56) u8 -> FD (ks,kt) int16 tensor (values are u16 <= 441)."""
+        t = self.torch
+        fS, fT = self._dev(featS, t.uint8), self._dev(featT, t.uint8)
+        V, ks, _ = fS.shape
+        kt = fT.shape[0]
+        FD = t.empty((ks, kt), dtype=t.int16, device=self.dev)
+        self._check(self.lib.ghicp_fd_bsc(self.h, _ptr(fS), C.c_int64(ks), V, _ptr(fT), C.c_int64(kt), _ptr(FD)))
+        return FD
+
+    def fd_fpfh(self, hS, hT):
+        t = self.torch
+        hS, hT = self._dev(hS, t.float32), self._dev(hT, t.float32)
+        FD = t.empty((hS.shape[0], hT.shape[0]), dtype=t.float32, device=self.dev)
+        self._check(self.lib.ghicp_fd_fpfh(self.h, _ptr(hS), C.c_int64(hS.shape[0]), _ptr(hT), C.c_int64(hT.shape[0]), _ptr(FD)))
+        return FD
+
+    def km_solve(self, w, eps=0.01):
+        t = self.torch
+        w = self._dev(w, t.float64)
+        n = w.shape[0]
+        match = t.empty(n, dtype=t.int32, device=self.dev)
+        self._check(self.lib.ghicp_km_solve(self.h, _ptr(w), C.c_int64(n), C.c_double(eps), _ptr(match)))
+        return match
+
+    def rigid_svd(self, src, tgt):
+        t = self.torch
+        src, tgt = self._dev(src, t.float64), self._dev(tgt, t.float64)
+        Rt = (C.c_double * 16)()
+        self._check(self.lib.ghicp_rigid_svd(self.h, _ptr(src), _ptr(tgt), C.c_int64(src.shape[0]), Rt))
+        return np.array(Rt[:]).reshape(4, 4)
+
+    def register(self, params: Params, kpS, kpT, FD=None, want_matchlist=False):
+        """GHRegistration::ghicp_reg. kpS/kpT (k,3) f64; FD int16(u16)/f32 (ks,kt) or None."""
+        t = self.torch
+        kpS, kpT = self._dev(kpS, t.float64), self._dev(kpT, t.float64)
+        ks, kt = kpS.shape[0], kpT.shape[0]
+        if FD is not None:
+            assert tuple(FD.shape) == (ks, kt) and FD.is_contiguous()
+        Rt = (C.c_double * 16)()
+        trace = (Iter * params.max_iter)()
+        n_iter = C.c_int32(0)
+        ml = t.full((params.max_iter, ks), -2, dtype=t.int32, device=self.dev) if want_matchlist else None
+        self._check(self.lib.ghicp_register(self.h, C.byref(params), _ptr(kpS), C.c_int64(ks), _ptr(kpT), C.c_int64(kt), _ptr(FD), Rt,
+                                            trace, C.byref(n_iter), _ptr(ml)))
+        it = n_iter.value
+        tr = []
+        for i in range(it):
+            r = trace[i]
+            d = {k: getattr(r, k) for k, _ in Iter._fields_ if k != "Rt"}
+            d["Rt"] = np.array(r.Rt[:]).reshape(4, 4)
+            tr.append(d)
+        return dict(Rt=np.array(Rt[:]).reshape(4, 4), iters=it, trace=tr,
+                    matchlist=None if ml is None else ml[:it].cpu().numpy())
+
+    # ---------------------------------------------------------------- front end
+    def _xyz(self, xyz):
+        t = self.torch
+        x = self._dev(xyz, t.float32)
+        assert x.dim() == 2 and x.shape[1] >= 3
+        return x
+
+    def voxel_filter(self, xyz, voxel):
+        t = self.torch
+        x = self._xyz(xyz)
+        n = x.shape[0]
+        keep = t.empty(n + 1, dtype=t.int32, device=self.dev)
+        m = C.c_int64(0)
+        self._check(self.lib.ghicp_voxel_filter(self.h, _ptr(x), C.c_int64(n), x.shape[1], C.c_float(voxel), _ptr(keep), C.byref(m)))
+        return keep[: m.value]
+
+    def bbx_magnitude(self, xyz):
+        x = self._xyz(xyz)
+        out = C.c_float(0)
+        self._check(self.lib.ghicp_bbx_magnitude(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], C.byref(out)))
+        return out.value
+
+    def pca_curvature(self, xyz, radius):
+        t = self.torch
+        x = self._xyz(xyz)
+        m = x.shape[0]
+        lam = t.empty((m, 3), dtype=t.float32, device=self.dev)
+        curv = t.empty(m, dtype=t.float64, device=self.dev)
+        cnt = t.empty(m, dtype=t.int32, device=self.dev)
+        self._check(self.lib.ghicp_pca_curvature(self.h, _ptr(x), C.c_int64(m), x.shape[1], C.c_float(radius), _ptr(lam), _ptr(curv), _ptr(cnt)))
+        return lam, curv, cnt
+
+    def prune(self, lam, cnt, ratio_max=0.65, min_n=20):
+        t = self.torch
+        lam, cnt = self._dev(lam, t.float32), self._dev(cnt, t.int32)
+        m = lam.shape[0]
+        cand = t.empty(max(m, 1), dtype=t.int32, device=self.dev)
+        c = C.c_int64(0)
+        self._check(self.lib.ghicp_prune(self.h, _ptr(lam), _ptr(cnt), C.c_int64(m), C.c_float(ratio_max), min_n, _ptr(cand), C.byref(c)))
+        return cand[: c.value]
+
+    def nms(self, xyz, curv, cand, radius):
+        t = self.torch
+        x = self._xyz(xyz)
+        curv, cand = self._dev(curv, t.float64), self._dev(cand, t.int32)
+        c = cand.shape[0]
+        kp = t.empty(max(c, 1), dtype=t.int32, device=self.dev)
+        k = C.c_int64(0)
+        self._check(self.lib.ghicp_nms(self.h, _ptr(x), x.shape[1], _ptr(curv), _ptr(cand), C.c_int64(c), C.c_float(radius), _ptr(kp), C.byref(k)))
+        return kp[: k.value]
+
+    def keypoints(self, xyz, radius, nms_radius, ratio_max=0.65, min_n=20):
+        t = self.torch
+        x = self._xyz(xyz)
+        m = x.shape[0]
+        kp = t.empty(max(m, 1), dtype=t.int32, device=self.dev)
+        k = C.c_int64(0)
+        self._check(self.lib.ghicp_keypoints(self.h, _ptr(x), C.c_int64(m), x.shape[1], C.c_float(radius), C.c_float(ratio_max), min_n,
+                                             C.c_float(nms_radius), _ptr(kp), C.byref(k)))
+        return kp[: k.value]
+
+    def bsc_encode(self, xyz, kp, radius, dof, pattern):
+        t = self.torch
+        x = self._xyz(xyz)
+        kp = self._dev(kp, t.int32)
+        K = kp.shape[0]
+        pat = np.ascontiguousarray(pattern, dtype=np.int32).reshape(-1)
+        assert pat.size == 98
+        feat = t.zeros((4, K, 56), dtype=t.uint8, device=self.dev)
+        lcs = t.zeros((K, 12), dtype=t.float32, device=self.dev)
+        self._check(self.lib.ghicp_bsc_encode(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], _ptr(kp), C.c_int64(K), C.c_float(radius), dof,
+                                              pat.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(feat), _ptr(lcs)))
+        return feat, lcs
+
+    def transform_cloud(self, xyz, Rt):
+        t = self.torch
+        x = self._xyz(xyz)
+        Rt = np.ascontiguousarray(Rt, dtype=np.float64)
+        out = t.empty((x.shape[0], 3), dtype=t.float32, device=self.dev)
+        self._check(self.lib.ghicp_transform_cloud(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], Rt.ctypes.data_as(C.POINTER(C.c_double)), _ptr(out)))
+        return out
+
+    def register_pair(self, cfg: PairConfig, xyzS, xyzT, want_trace=True):
+        xS, xT = self._xyz(xyzS), self._xyz(xyzT)
+        assert xS.shape[1] == xT.shape[1]
+        stats = PairStats()
+        trace = (Iter * cfg.reg.max_iter)() if want_trace else None
+        self._check(self.lib.ghicp_register_pair(self.h, C.byref(cfg), _ptr(xS), C.c_int64(xS.shape[0]), _ptr(xT), C.c_int64(xT.shape[0]),
+                                                 xS.shape[1], C.byref(stats), trace))
+        tr = []
+        if want_trace:
+            for i in range(stats.iterations):
+                r = trace[i]
+                d = {k: getattr(r, k) for k, _ in Iter._fields_ if k != "Rt"}
+                d["Rt"] = np.array(r.Rt[:]).reshape(4, 4)
+                tr.append(d)
+        return stats, tr
+
+
+def pair_config(feature=FEATURE_BSC, corr=CORR_KM, dof=6, est_iou=0.6, voxel=0.1, neighborhood_radius=0.5, radius_nonmax=1.5,
+                pattern=None, max_iter=200) -> PairConfig:
+    cfg = PairConfig()
+    cfg.reg = default_params(feature, corr, dof, est_iou, radius_nonmax, 0.0, max_iter)
+    cfg.voxel, cfg.neighborhood_radius, cfg.ratio_max, cfg.min_neighbors = voxel, neighborhood_radius, 0.65, 20
+    pat = np.zeros(98, np.int32) if pattern is None else np.ascontiguousarray(pattern, np.int32).reshape(-1)
+    for i in range(98):
+        cfg.pattern[i] = int(pat[i])
+    return cfg

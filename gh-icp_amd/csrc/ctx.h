@@ -1,0 +1,139 @@
+// Internal: context, device buffers, host/device staging.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ghicp_c.h"
+
+#define GH_HIP(call)                                                                                          \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) return ctx->fail(GHICP_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+#define GH_TRY(call)               \
+  do {                             \
+    int r_ = (call);               \
+    if (r_ != GHICP_OK) return r_; \
+  } while (0)
+#define GH_ARG(cond)                                                                \
+  do {                                                                              \
+    if (!(cond)) return ctx->fail(GHICP_ERR_ARG, "%s: bad argument (%s)", __func__, #cond); \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      if (e != hipSuccess) return e;
+      p = nullptr; cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+enum BufSlot {
+  // staging (host-pointer mode)
+  B_STAGE0 = 0, B_STAGE1, B_STAGE2, B_STAGE3, B_STAGE4, B_STAGE5, B_STAGE6, B_STAGE7,
+  // loop
+  B_LOOP_STATE, B_LOOP_KPS, B_LOOP_PARTMIN, B_LOOP_PARTIDX, B_LOOP_PARTSUM, B_LOOP_PARTMIN2, B_LOOP_PARTIDX2, B_LOOP_FDT,
+  B_LOOP_SP, B_LOOP_TP, B_LOOP_TRACE, B_LOOP_WFD, B_LOOP_KMW, B_LOOP_KMMATCH, B_LOOP_KMSCR, B_LOOP_ACC,
+  // spatial grid / sort
+  B_GRID_KEYS, B_GRID_KEYS2, B_GRID_VALS, B_GRID_VALS2, B_GRID_TMP, B_GRID_START, B_GRID_PTS, B_GRID_MISC,
+  B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS,
+  // front end
+  B_FE_LAMBDA, B_FE_CURV, B_FE_COUNT, B_FE_CAND, B_FE_STATE, B_FE_KP, B_FE_SORTK, B_FE_SORTK2, B_FE_SORTV, B_FE_SORTV2, B_FE_CPTS,
+  B_FE_FLAGS, B_FE_SCAN,
+  // pair pipeline
+  B_P_KEEP_S, B_P_KEEP_T, B_P_DS_S, B_P_DS_T, B_P_KP_S, B_P_KP_T, B_P_KPXYZ_S, B_P_KPXYZ_T, B_P_FEAT_S, B_P_FEAT_T, B_P_LCS,
+  B_P_FD, B_P_MISC, B_P_PATTERN,
+  B_KM_LX, B_KM_MISC,
+  B_NUM
+};
+
+struct ghicp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool host_ptrs = false;
+  std::string err;
+  DevBuf buf[B_NUM];
+  void* pinned = nullptr;  // small pinned host scratch
+  size_t pinned_cap = 0;
+  int num_cu = 256;
+
+  int fail(int code, const char* fmt, ...) {
+    char tmp[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof(tmp), fmt, ap);
+    va_end(ap);
+    err = tmp;
+    return code;
+  }
+  template <typename T> int reserve(BufSlot s, size_t count, T** out) {
+    hipError_t e = buf[s].reserve(count * sizeof(T) + 16);
+    if (e != hipSuccess) return fail(GHICP_ERR_HIP, "hipMalloc(%zu bytes, slot %d): %s", count * sizeof(T), (int)s, hipGetErrorString(e));
+    *out = buf[s].as<T>();
+    return GHICP_OK;
+  }
+};
+
+// Stages ABI arrays when the context is in host-pointer mode; a no-op in device-pointer mode.
+struct Stager {
+  ghicp_ctx* ctx;
+  struct Out { void* host; void* dev; size_t bytes; };
+  std::vector<Out> outs;
+  std::vector<void*> temps;
+  explicit Stager(ghicp_ctx* c) : ctx(c) {}
+  ~Stager() { for (void* p : temps) (void)hipFree(p); }
+  template <typename T> int in(const T* p, size_t count, const T** out) {
+    if (!ctx->host_ptrs || p == nullptr) { *out = p; return GHICP_OK; }
+    void* d = nullptr;
+    if (hipMalloc(&d, count * sizeof(T) + 16) != hipSuccess) return ctx->fail(GHICP_ERR_HIP, "stage-in hipMalloc failed");
+    temps.push_back(d);
+    if (hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return ctx->fail(GHICP_ERR_HIP, "stage-in copy failed");
+    *out = reinterpret_cast<const T*>(d);
+    return GHICP_OK;
+  }
+  template <typename T> int out(T* p, size_t count, T** outp) {
+    if (!ctx->host_ptrs || p == nullptr) { *outp = p; return GHICP_OK; }
+    void* d = nullptr;
+    if (hipMalloc(&d, count * sizeof(T) + 16) != hipSuccess) return ctx->fail(GHICP_ERR_HIP, "stage-out hipMalloc failed");
+    temps.push_back(d);
+    outs.push_back({p, d, count * sizeof(T)});
+    *outp = reinterpret_cast<T*>(d);
+    return GHICP_OK;
+  }
+  // copy outputs back (all, or only the first `bytes` of the one registered for host pointer `p`)
+  int finish() {
+    for (auto& o : outs)
+      if (hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        return ctx->fail(GHICP_ERR_HIP, "stage-out copy failed");
+    if (!outs.empty() && hipStreamSynchronize(ctx->stream) != hipSuccess) return ctx->fail(GHICP_ERR_HIP, "stage-out sync failed");
+    outs.clear();
+    return GHICP_OK;
+  }
+};
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- internal (device-pointer) entry points shared between translation units
+int gh_fd_bsc_dev(ghicp_ctx* ctx, const uint8_t* featS, int ks, int V, const uint8_t* featT, int kt, uint16_t* FD);
+int gh_register_dev(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int ks, const double* kpT, int kt, const void* FD,
+                    double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist);
+int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, const int* done_flag);

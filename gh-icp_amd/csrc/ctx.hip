@@ -1,0 +1,229 @@
+// Context management + small stand-alone entry points (rigid solve, cloud transform, gather, bbox).
+#include "ctx.h"
+#include "devmath.h"
+
+extern "C" const char* ghicp_version(void) { return "ghicp-hip 0.1 (gfx950)"; }
+
+extern "C" void ghicp_params_default(ghicp_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->feature = GHICP_FEATURE_BSC;
+  p->corr = GHICP_CORR_KM;
+  p->dof = 6;
+  p->max_iter = 200;  // = the column count of the reference's matchlist (ghicp_reg.h:100)
+  p->radius_nonmax = 1.5f;
+  p->adjust_ratio = 1.1f;  // README.md:79-85
+  p->adjust_step = 0.1f;
+  p->est_iou = 0.6f;
+  p->converge_t = 0.02f;  // ghicp_reg.h:80
+  p->converge_r = 0.02f;
+  p->bbx_magnitude = 0.f;
+  p->penalty_initial = 2.0;  // ghicp_reg.h:32-38
+  p->para1 = 1.0;
+  p->para2 = 1.0;
+  p->km_eps = 0.01;
+  p->min_cor = 10;
+  p->weight_changing_rate = 6;
+}
+
+extern "C" int ghicp_ctx_create(int device, ghicp_ctx** out) {
+  if (!out) return GHICP_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return GHICP_ERR_NO_GPU;
+  if (hipSetDevice(device) != hipSuccess) return GHICP_ERR_NO_GPU;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GHICP_ERR_NO_GPU;
+  ghicp_ctx* c = new ghicp_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) { delete c; return GHICP_ERR_HIP; }
+  c->pinned_cap = 4096;
+  *out = c;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
+  if (!ctx) return GHICP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  delete ctx;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* s) {
+  if (!ctx) return GHICP_ERR_ARG;
+  ctx->stream = reinterpret_cast<hipStream_t>(s);
+  return GHICP_OK;
+}
+extern "C" int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on) {
+  if (!ctx) return GHICP_ERR_ARG;
+  ctx->host_ptrs = on != 0;
+  return GHICP_OK;
+}
+extern "C" int ghicp_ctx_synchronize(ghicp_ctx* ctx) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_HIP(hipStreamSynchronize(ctx->stream));
+  return GHICP_OK;
+}
+extern "C" const char* ghicp_last_error(const ghicp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+namespace {
+
+// single-workgroup float-Umeyama (same arithmetic as the k_solve stage of loop.hip)
+__global__ __launch_bounds__(1024) void k_rigid_svd(const double* __restrict__ src, const double* __restrict__ tgt, int c,
+                                                    double* __restrict__ out16) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < c; i += nt)
+    for (int d = 0; d < 3; d++) { m[d] += (double)(float)src[(size_t)i * 3 + d]; m[3 + d] += (double)(float)tgt[(size_t)i * 3 + d]; }
+  for (int d = 0; d < 6; d++) m[d] = gh_block_sum(m[d], red);
+  float msf[3], mtf[3];
+  for (int d = 0; d < 3; d++) { msf[d] = (float)(m[d] / (double)c); mtf[d] = (float)(m[3 + d] / (double)c); }
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < c; i += nt) {
+    double a[3], b[3];
+    for (int d = 0; d < 3; d++) {
+      a[d] = (double)(float)tgt[(size_t)i * 3 + d] - (double)mtf[d];
+      b[d] = (double)(float)src[(size_t)i * 3 + d] - (double)msf[d];
+    }
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++) H[r * 3 + q] += a[r] * b[q];
+  }
+  for (int d = 0; d < 9; d++) H[d] = gh_block_sum(H[d], red);
+  if (tid == 0) {
+    double A[9], R[9];
+    for (int d = 0; d < 9; d++) A[d] = (double)(float)(H[d] / (double)c);
+    gh_kabsch(A, R);
+    float Rf[9];
+    for (int d = 0; d < 9; d++) Rf[d] = (float)R[d];
+    for (int d = 0; d < 16; d++) out16[d] = 0;
+    for (int r = 0; r < 3; r++) {
+      const float t = (float)((double)mtf[r] - (((double)Rf[r * 3] * (double)msf[0] + (double)Rf[r * 3 + 1] * (double)msf[1]) +
+                                                 (double)Rf[r * 3 + 2] * (double)msf[2]));
+      for (int q = 0; q < 3; q++) out16[r * 4 + q] = (double)Rf[r * 3 + q];
+      out16[r * 4 + 3] = (double)t;
+    }
+    out16[15] = 1;
+  }
+}
+
+// pcl::transformPointCloud with a float 4x4 (test/ghicp_main.cpp:153): ((m0 x + m1 y) + m2 z) + m3
+struct M34 { float m[12]; };
+__global__ __launch_bounds__(256) void k_transform(const float* __restrict__ xyz, long long n, int stride, M34 M, float* __restrict__ out) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float x = xyz[i * stride], y = xyz[i * stride + 1], z = xyz[i * stride + 2];
+    out[i * 3 + 0] = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
+    out[i * 3 + 1] = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
+    out[i * 3 + 2] = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather4(const float* __restrict__ xyz, int stride, const int* __restrict__ idx, long long m,
+                                                 float4* __restrict__ out) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= m) return;
+  const long long s = idx[i];
+  out[i] = make_float4(xyz[s * stride], xyz[s * stride + 1], xyz[s * stride + 2], 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, long long n, int stride, float* __restrict__ mm /*6: min xyz, max xyz as ordered ints*/) {
+  __shared__ float smin[3][4], smax[3][4];
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    for (int d = 0; d < 3; d++) { const float v = xyz[i * stride + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+  for (int d = 0; d < 3; d++) {
+    for (int o = 32; o > 0; o >>= 1) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[d][threadIdx.x >> 6] = mn[d]; smax[d][threadIdx.x >> 6] = mx[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    float a = smin[d][0], b = smax[d][0];
+    for (int w = 1; w < 4; w++) { a = fminf(a, smin[d][w]); b = fmaxf(b, smax[d][w]); }
+    // float atomic min/max through the order-preserving int mapping
+    auto enc = [](float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; };
+    atomicMin(reinterpret_cast<int*>(mm) + d, enc(a));
+    atomicMax(reinterpret_cast<int*>(mm) + 3 + d, enc(b));
+  }
+}
+
+}  // namespace
+
+int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float* mm_host6) {
+  int* d;
+  GH_TRY(ctx->reserve(B_GRID_MISC, 64, &d));
+  const int init[6] = {0x7f7fffff, 0x7f7fffff, 0x7f7fffff, (int)0x80800000, (int)0x80800000, (int)0x80800000};  // enc(+FLT_MAX), enc(-FLT_MAX)
+  GH_HIP(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) hipLaunchKernelGGL(k_bbox, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, ctx->stream, xyz, n, stride, reinterpret_cast<float*>(d));
+  int h[6];
+  GH_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 6; k++) {
+    int i = h[k] >= 0 ? h[k] : h[k] ^ 0x7fffffff;
+    memcpy(&mm_host6[k], &i, 4);
+  }
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_bbx_magnitude(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float* bbx) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(bbx != nullptr && n >= 0 && stride >= 3);
+  Stager sg(ctx);
+  const float* d;
+  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  if (n == 0) { *bbx = 0.f; return GHICP_OK; }
+  float mm[6];
+  GH_TRY(gh_bbox_dev(ctx, d, n, stride, mm));
+  // Bounds are doubles holding float values; the sum is formed in double and stored to float (main:91-93)
+  *bbx = (float)((double)mm[3] - (double)mm[0] + (double)mm[4] - (double)mm[1] + (double)mm[5] - (double)mm[2]);
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_rigid_svd(ghicp_ctx* ctx, const double* src, const double* tgt, int64_t c, double* Rt16) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(c > 0 && src && tgt && Rt16);
+  Stager sg(ctx);
+  const double *ds, *dt;
+  GH_TRY(sg.in(src, (size_t)c * 3, &ds));
+  GH_TRY(sg.in(tgt, (size_t)c * 3, &dt));
+  double* out;
+  GH_TRY(ctx->reserve(B_P_MISC, 16, &out));
+  hipLaunchKernelGGL(k_rigid_svd, dim3(1), dim3(1024), 0, ctx->stream, ds, dt, (int)c, out);
+  GH_HIP(hipGetLastError());
+  GH_HIP(hipMemcpyAsync(Rt16, out, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(hipStreamSynchronize(ctx->stream));
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const double* Rt, float* out) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(n >= 0 && stride >= 3 && Rt != nullptr);
+  Stager sg(ctx);
+  const float* d;
+  float* o;
+  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.out(out, (size_t)n * 3, &o));
+  M34 M;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) M.m[r * 4 + c] = (float)Rt[r * 4 + c];
+  if (n > 0) {
+    hipLaunchKernelGGL(k_transform, dim3(min(cdiv(n, 256), 4096)), dim3(256), 0, ctx->stream, d, (long long)n, stride, M, o);
+    GH_HIP(hipGetLastError());
+  }
+  return sg.finish();
+}
+
+extern "C" int ghicp_gather_points(ghicp_ctx* ctx, const float* xyz, int stride, const int32_t* idx, int64_t m, float* out) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(m >= 0 && stride >= 3);
+  if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_gather_points: device-pointer mode only");
+  if (m > 0) {
+    hipLaunchKernelGGL(k_gather4, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, xyz, stride, idx, (long long)m, reinterpret_cast<float4*>(out));
+    GH_HIP(hipGetLastError());
+  }
+  return GHICP_OK;
+}

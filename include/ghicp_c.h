@@ -1,0 +1,163 @@
+/* =====================================================================================
+ *  ghicp_c.h -- C ABI of libghicp_hip.so: the MI355X (gfx950) GH-ICP registration hot path.
+ *
+ *  This is the drop-in boundary.  The reference has no FFI; its boundary is the
+ *  public C++ class API.  Each entry point below names the reference method(s) it replaces
+ *  (paths under the reference checkout).  The C++ headers next to this file (ghicp_reg.h, km.h,
+ *  keypoint_detect.hpp, binary_feature_extraction.hpp, common_reg.h ...) keep the reference's
+ *  class / method names and forward here.
+ *
+ *  Conventions
+ *    - every function returns GHICP_OK (0) or an error code; ghicp_last_error() has the text.
+ *    - bulk array arguments are DEVICE pointers by default.  After
+ *      ghicp_ctx_set_host_pointers(ctx, 1) they are HOST pointers and the library stages them
+ *      (this is what the C++ drop-in classes use).  Scalars / small outputs marked [host] are
+ *      always host memory.
+ *    - all work is enqueued on the context's stream (ghicp_ctx_set_stream); functions that
+ *      return counts synchronise that stream.
+ *    - point clouds are `float` with a stride in floats (3 = packed xyz, 4 = float4,
+ *      8 = pcl::PointXYZI's 32-byte layout).
+ *    - no cwd side effects, no stdout, re-entrant per context (unlike km.cpp:147 / bfe:96).
+ * ===================================================================================== */
+#ifndef GHICP_C_H_
+#define GHICP_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ghicp_ctx ghicp_ctx;
+
+enum {
+  GHICP_OK = 0,
+  GHICP_ERR_ARG = 1,      /* bad argument */
+  GHICP_ERR_HIP = 2,      /* a HIP runtime call failed */
+  GHICP_ERR_NO_GPU = 3,   /* no usable gfx950 device: the library has NO CPU fallback */
+  GHICP_ERR_CAPACITY = 4, /* an output buffer / internal limit is too small */
+  GHICP_ERR_INTERNAL = 5
+};
+
+/* include/utility.h:51-57 and :59-64 (same numeric values as the reference enums) */
+enum { GHICP_FEATURE_BSC = 0, GHICP_FEATURE_ROPS = 1, GHICP_FEATURE_FPFH = 2, GHICP_FEATURE_NONE = 3 };
+enum { GHICP_CORR_NN = 0, GHICP_CORR_NNR = 1, GHICP_CORR_KM = 2 };
+
+/* GHRegistration ctor arguments (include/ghicp_reg.h:77-117) + Energyfunction::init constants
+ * (include/ghicp_reg.h:26-41).  ghicp_params_default() fills the reference defaults. */
+typedef struct ghicp_params {
+  int32_t feature;  /* GHICP_FEATURE_* */
+  int32_t corr;     /* GHICP_CORR_*    */
+  int32_t dof;      /* 4 or 6 (only selects the number of source BSC variants, ghicp_reg.cpp:178-182) */
+  int32_t max_iter; /* guard; the reference loops `while(!converge)` with none (ghicp_reg.cpp:49) */
+  float radius_nonmax, adjust_ratio, adjust_step, est_iou;
+  float converge_t, converge_r; /* 0.02 m / 0.02 deg (ghicp_reg.h:80) */
+  float bbx_magnitude;          /* test/ghicp_main.cpp:91-93 */
+  float pad_;
+  double penalty_initial, para1, para2, km_eps;
+  int32_t min_cor, weight_changing_rate;
+} ghicp_params;
+
+/* One iteration of GHRegistration::ghicp_reg (src/ghicp_reg.cpp:49-103): what the reference
+ * prints / keeps in `energy, rmse, rmseafter, cor` (include/ghicp_reg.h:147-148). */
+typedef struct ghicp_iter {
+  int32_t cor, converged;
+  double penalty, cdmean, cdstd, rmse, rmse_after, fdm, fdstd, iou, para1, para2, energy;
+  double Rt[16]; /* Rt_temp of this iteration, row-major */
+} ghicp_iter;
+
+/* ------------------------------------------------------------------ context */
+int ghicp_ctx_create(int device, ghicp_ctx** ctx);
+int ghicp_ctx_destroy(ghicp_ctx* ctx);
+int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* hip_stream);
+int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on);
+int ghicp_ctx_synchronize(ghicp_ctx* ctx);
+const char* ghicp_last_error(const ghicp_ctx* ctx);
+const char* ghicp_version(void);
+void ghicp_params_default(ghicp_params* p);
+
+/* ------------------------------------------------------------------ front end (per cloud) */
+/* CFilter::voxelfilter (include/filter.hpp:28-88, incl. its phantom-entry quirk: output row 0 is
+ * a copy of input point 0).  keep_idx: capacity n+1 int32; *m [host]. */
+int ghicp_voxel_filter(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float voxel, int32_t* keep_idx, int64_t* m);
+/* gather rows: out[i] = xyz[idx[i]] as packed float4 (x,y,z,0). */
+int ghicp_gather_points(ghicp_ctx* ctx, const float* xyz, int stride, const int32_t* idx, int64_t m, float* out_xyz4);
+/* bbx_magnitude of test/ghicp_main.cpp:91-93 (CloudUtility::getCloudBound, utility.h:153-183). [host] out */
+int ghicp_bbx_magnitude(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float* bbx);
+
+/* PrincipleComponentAnalysis::CalculatePcaFeaturesOfPointCloud(cloud, features, float radius)
+ * (include/pca.h:133-165, 202-250).  lambda: m x 3 f32 (descending), curvature: m f64, count: m i32. */
+int ghicp_pca_curvature(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float* lambda, double* curvature,
+                        int32_t* count);
+/* CKeypointDetect::pruneUnstablePoints (include/keypoint_detect.hpp:132-147). cand: capacity m; *c [host]. */
+int ghicp_prune(ghicp_ctx* ctx, const float* lambda, const int32_t* count, int64_t m, float ratio_max, int min_n, int32_t* cand,
+                int64_t* c);
+/* CKeypointDetect::nonMaximaSuppression (include/keypoint_detect.hpp:149-191).  kp: capacity c,
+ * output in descending-curvature order; *k [host]. */
+int ghicp_nms(ghicp_ctx* ctx, const float* xyz, int stride, const double* curvature, const int32_t* cand, int64_t c, float radius,
+              int32_t* kp, int64_t* k);
+/* CKeypointDetect::keypointDetectionBasedOnCurvature (include/keypoint_detect.hpp:27-51):
+ * PCA -> prune -> NMS.  kp_idx: capacity m; *k [host]. */
+int ghicp_keypoints(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float ratio_max, int min_n, float nms_radius,
+                    int32_t* kp_idx, int64_t* k);
+
+/* BSCEncoder::extractBinaryFeatures (include/binary_feature_extraction.hpp:603-676).
+ * pattern: 49 x 2 int32 [host] (the sample_pattern.txt content, bfe:63-117).
+ * feat: 4 x k x 56 bytes (variants beyond the dof's count are zero), lcs: k x 12 f32 (x,y,z axes, origin). */
+int ghicp_bsc_encode(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, const int32_t* kp_idx, int64_t k, float radius, int dof,
+                     const int32_t* pattern, uint8_t* feat, float* lcs);
+
+/* ------------------------------------------------------------------ per pair */
+/* GHRegistration::calFD_BSC (src/ghicp_reg.cpp:143-200) + StereoBinaryFeature::hammingDistance
+ * (src/stereo_binary_feature.cpp:87-104).  featS: V x ks x 56, featT: kt x 56, FD: ks x kt u16 row-major. */
+int ghicp_fd_bsc(ghicp_ctx* ctx, const uint8_t* featS, int64_t ks, int V, const uint8_t* featT, int64_t kt, uint16_t* FD);
+/* GHRegistration::calFD_FPFH (src/ghicp_reg.cpp:202-214) + FPFHfeature::compute_fpfh_distance
+ * (include/fpfh.hpp:135-165).  hist: k x 33 f32, FD: ks x kt f32 row-major. */
+int ghicp_fd_fpfh(ghicp_ctx* ctx, const float* histS, int64_t ks, const float* histT, int64_t kt, float* FD);
+
+/* Km::kmsolve (src/km.cpp:40-126): w is n x n f64 row-major, match[y] = x (int32, n). */
+int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double eps, int32_t* match);
+
+/* pcl::registration::TransformationEstimationSVD as used by GHRegistration::transformestimation
+ * (src/ghicp_reg.cpp:839-866): c x 3 f64 correspondences (cast to f32 like the reference), Rt 4x4 [host]. */
+int ghicp_rigid_svd(ghicp_ctx* ctx, const double* src, const double* tgt, int64_t c, double* Rt16);
+
+/* GHRegistration::ghicp_reg (src/ghicp_reg.cpp:24-112): the whole iteration loop
+ * (calED, calCD_*, findcorrespondence{NN,NNR,KM}, transformestimation, adjustweight).
+ *   kpS: ks x 3 f64, kpT: kt x 3 f64 (Keypoints::setCoordinate, ghicp_reg.h:53-59); kpS is not modified.
+ *   FD : ks x kt row-major; u16 for BSC, f32 for FPFH, NULL for None.
+ *   Rt16 [host] final 4x4 (Source -> Target); trace [host] capacity max_iter or NULL;
+ *   n_iter [host]; matchlist: max_iter x ks int32 (T index or -1) or NULL. */
+int ghicp_register(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int64_t ks, const double* kpT, int64_t kt, const void* FD,
+                   double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist);
+
+/* pcl::transformPointCloud(cloud, out, Rt.cast<float>()) (test/ghicp_main.cpp:153). out: n x 3 packed f32. */
+int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const double* Rt16_host, float* out_xyz);
+
+/* ------------------------------------------------------------------ whole pair (test/ghicp_main.cpp:86-153) */
+typedef struct ghicp_pair_config {
+  ghicp_params reg;         /* bbx_magnitude is computed from the down-sampled source and overwritten */
+  float voxel;              /* argv[6]; <= 0 skips the voxel filter */
+  float neighborhood_radius;/* argv[7] */
+  float ratio_max;          /* 0.65 (main:96) */
+  int32_t min_neighbors;    /* 20   (main:97) */
+  int32_t pattern[98];      /* BSC sample pattern */
+} ghicp_pair_config;
+
+typedef struct ghicp_pair_stats {
+  int64_t n_s, n_t, m_s, m_t, k_s, k_t; /* raw, down-sampled, keypoints */
+  int32_t iterations, converged;
+  double Rt[16];
+  float bbx_magnitude;
+  float ms_voxel, ms_keypoints, ms_feature, ms_fd, ms_loop, ms_total; /* hipEvent timings */
+} ghicp_pair_stats;
+
+/* voxel -> keypoints -> feature -> FD -> loop for one (S,T); raw clouds are device (or host) xyz. */
+int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* xyzS, int64_t nS, const float* xyzT, int64_t nT,
+                        int stride, ghicp_pair_stats* stats /*[host]*/, ghicp_iter* trace /*[host] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GHICP_C_H_ */

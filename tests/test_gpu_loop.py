@@ -1,0 +1,154 @@
+"""GPU parity of the iteration loop, FD kernels and KM against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+
+from conftest import rot_err, trans_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg1(synth, oracle, n_kp=2000):
+    p = synth.gauss_pair(n_kp=n_kp)
+    kpS = p.source[p.kp_source].astype(np.float64)
+    kpT = p.target[p.kp_target].astype(np.float64)
+    return p, kpS, kpT, oracle.bbx_magnitude(p.source)
+
+
+def _compare_traces(tg, to, rel=1e-9):
+    assert len(tg) == len(to)
+    for a, b in zip(tg, to):
+        assert a["cor"] == b["cor"] and a["converged"] == b["converged"]
+        for k in ("penalty", "cdmean", "cdstd", "rmse", "rmse_after", "iou", "para1", "para2", "fdm", "fdstd"):
+            if np.isnan(b[k]):
+                assert np.isnan(a[k]), k
+            else:
+                assert a[k] == pytest.approx(b[k], rel=rel, abs=1e-12), k
+        np.testing.assert_allclose(a["Rt"], b["Rt"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("corr", [0, 1])
+def test_loop_none_nn_nnr_cfg1(ctx, api, synth, oracle, corr):
+    """cfg1 (BASELINE configs[0]): N/N 6-DoF; GPU loop vs oracle, iteration by iteration."""
+    p, kpS, kpT, bbx = _cfg1(synth, oracle)
+    po = oracle.default_params(oracle.NONE, corr, 6, 0.9, 1.5, bbx)
+    ro = oracle.register(po, kpS, kpT, want_matchlist=True)
+    pg = api.default_params(api.FEATURE_NONE, corr, 6, 0.9, 1.5, bbx)
+    rg = ctx.register(pg, kpS, kpT, want_matchlist=True)
+    assert rg["iters"] == ro["iters"]
+    np.testing.assert_array_equal(rg["matchlist"], ro["matchlist"])  # index work: bit-exact
+    _compare_traces(rg["trace"], ro["trace"])
+    # north_star tolerance: 1e-4 rotation, 1e-3 m translation
+    assert rot_err(rg["Rt"], ro["Rt"]) < 1e-4 and trans_err(rg["Rt"], ro["Rt"]) < 1e-3
+    assert rot_err(rg["Rt"], p.gt) < 1e-3 and trans_err(rg["Rt"], p.gt) < 5e-3
+
+
+def _fake_bsc_fd(rng, ks, kt):
+    FD = rng.integers(60, 200, size=(ks, kt)).astype(np.float64)
+    idx = np.arange(min(ks, kt))
+    FD[idx, idx] = rng.integers(5, 40, size=idx.size)
+    return FD
+
+
+@pytest.mark.parametrize("corr", [0, 1, 2])
+def test_loop_bsc_energy(ctx, api, synth, oracle, corr):
+    """BSC-style hybrid energy (u16 FD) with NN / NNR / KM matching on unequal keypoint counts."""
+    import torch
+
+    p, kpS, kpT, bbx = _cfg1(synth, oracle, n_kp=700)
+    kpS, kpT = kpS[:600], kpT[:700]
+    rng = np.random.default_rng(3 + corr)
+    FD = _fake_bsc_fd(rng, 600, 700)
+    po = oracle.default_params(oracle.BSC, corr, 6, 0.6, 1.5, bbx, max_iter=40)
+    ro = oracle.register(po, kpS, kpT, FD, want_matchlist=True)
+    pg = api.default_params(api.FEATURE_BSC, corr, 6, 0.6, 1.5, bbx, max_iter=40)
+    FDg = torch.from_numpy(FD.astype(np.int16)).cuda()
+    rg = ctx.register(pg, kpS, kpT, FDg, want_matchlist=True)
+    assert rg["iters"] == ro["iters"]
+    np.testing.assert_array_equal(rg["matchlist"], ro["matchlist"])
+    _compare_traces(rg["trace"], ro["trace"])
+    np.testing.assert_allclose(rg["Rt"], ro["Rt"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("corr", [0, 1])
+def test_loop_fpfh_energy(ctx, api, synth, oracle, corr):
+    import torch
+
+    p, kpS, kpT, bbx = _cfg1(synth, oracle, n_kp=500)
+    rng = np.random.default_rng(11)
+    FD = (0.2 + 0.6 * rng.random((500, 500))).astype(np.float32)
+    FD[np.arange(500), np.arange(500)] = 0.97
+    po = oracle.default_params(oracle.FPFH, corr, 6, 0.6, 1.5, bbx, max_iter=40)
+    ro = oracle.register(po, kpS, kpT, FD.astype(np.float64), want_matchlist=True)
+    pg = api.default_params(api.FEATURE_FPFH, corr, 6, 0.6, 1.5, bbx, max_iter=40)
+    rg = ctx.register(pg, kpS, kpT, torch.from_numpy(FD).cuda(), want_matchlist=True)
+    assert rg["iters"] == ro["iters"]
+    np.testing.assert_array_equal(rg["matchlist"], ro["matchlist"])
+    _compare_traces(rg["trace"], ro["trace"], rel=1e-7)  # device pow() vs glibc pow(): <= 1 ulp apart
+    np.testing.assert_allclose(rg["Rt"], ro["Rt"], rtol=0, atol=1e-6)
+
+
+def test_km_kat_and_random(ctx, oracle):
+    """km.cpp:237-259 known-answer vector + random matrices vs the oracle (and the reference's own km.cpp)."""
+    W = np.array([[-5, -2, -100], [-4, -2, -6], [-100, -1, -7]], float)
+    assert ctx.km_solve(W).cpu().numpy().tolist() == [0, 2, 1]
+    rng = np.random.default_rng(5)
+    for n, frac in ((1, 0), (2, 0), (7, 0.3), (64, 0.1), (257, 0.02), (1000, 0.004), (1500, 0.01)):
+        cd = 5 + 60 * rng.random((n, n))
+        cd[np.arange(n), (np.arange(n) * 7) % n] = 3 * rng.random(n)
+        cd = np.where(rng.random((n, n)) < frac, 8 * rng.random((n, n)), cd)
+        w = np.where(cd < 8.0, -cd, -8.0)
+        m_o, _ = oracle.km(w)
+        m_g = ctx.km_solve(w).cpu().numpy()
+        np.testing.assert_array_equal(m_g, m_o)
+        if n <= 300:
+            m_r = oracle.km_reference(w)
+            if m_r is not None:
+                np.testing.assert_array_equal(m_g, m_r)
+
+
+def test_km_all_equal_and_loop_km_none(ctx, api, synth, oracle):
+    w = np.full((33, 33), -2.5)
+    np.testing.assert_array_equal(ctx.km_solve(w).cpu().numpy(), oracle.km(w)[0])
+    p, kpS, kpT, bbx = _cfg1(synth, oracle, n_kp=400)
+    po = oracle.default_params(oracle.NONE, oracle.KM, 6, 0.9, 1.5, bbx, max_iter=30)
+    ro = oracle.register(po, kpS, kpT, want_matchlist=True)
+    pg = api.default_params(api.FEATURE_NONE, api.CORR_KM, 6, 0.9, 1.5, bbx, max_iter=30)
+    rg = ctx.register(pg, kpS, kpT, want_matchlist=True)
+    assert rg["iters"] == ro["iters"]
+    np.testing.assert_array_equal(rg["matchlist"], ro["matchlist"])
+    _compare_traces(rg["trace"], ro["trace"])
+
+
+def test_fd_bsc_hamming(ctx, oracle):
+    rng = np.random.default_rng(2)
+    for V, ks, kt in ((1, 1, 1), (4, 130, 77), (2, 64, 200), (4, 257, 65)):
+        fS = rng.integers(0, 256, size=(V, ks, 56), dtype=np.uint8)
+        fT = rng.integers(0, 256, size=(kt, 56), dtype=np.uint8)
+        FDg = ctx.fd_bsc(fS, fT).cpu().numpy().astype(np.int64) & 0xFFFF
+        FDo = oracle.fd_bsc(fS, fT).astype(np.int64)
+        np.testing.assert_array_equal(FDg, FDo)
+        # independent check: popcount via numpy
+        ref = np.unpackbits(fS[:, :, None, :] ^ fT[None, None, :, :], axis=-1).sum(-1).min(0)
+        np.testing.assert_array_equal(FDg, ref)
+
+
+def test_fd_fpfh_correlation(ctx, oracle):
+    rng = np.random.default_rng(4)
+    hS = (rng.random((150, 33)) * 100).astype(np.float32)
+    hT = (rng.random((90, 33)) * 100).astype(np.float32)
+    hT[3] = 7.0  # constant histogram -> NaN similarity, as in the reference
+    FDg = ctx.fd_fpfh(hS, hT).cpu().numpy()
+    FDo = oracle.fd_fpfh(hS, hT).astype(np.float32)
+    np.testing.assert_array_equal(FDg, FDo)  # same sequential f32 order: bit-exact (NaN == NaN)
+
+
+def test_rigid_svd(ctx, oracle):
+    rng = np.random.default_rng(8)
+    src = rng.normal(size=(500, 3)) * [10, 5, 2]
+    R, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(R) < 0:
+        R[:, 0] *= -1
+    tgt = src @ R.T + [1.0, -2.0, 0.5] + 0.01 * rng.normal(size=(500, 3))
+    Rg, Ro = ctx.rigid_svd(src, tgt), oracle.rigid_svd(src, tgt)
+    np.testing.assert_array_equal(Rg, Ro)
+    assert np.abs(Rg[:3, :3] - R).max() < 1e-3
