@@ -37,6 +37,18 @@ __device__ inline void gh_jacobi3(double& a00, double& a01, double& a02, double&
 #undef GH_ROT
 }
 
+// N2: round n f64 sums onto the f32 grid of the matrix scale: nearest multiple of 2^(e-23), e = exponent of
+// the largest |entry| (ties to even).  See DESIGN.md "numerics contract".
+__device__ inline void gh_quant_grid(double* v, int n) {
+  double mx = 0;
+  for (int i = 0; i < n; i++) mx = fmax(mx, fabs(v[i]));
+  if (!(mx > 0) || !isfinite(mx)) return;
+  int e;
+  frexp(mx, &e);
+  const double q = ldexp(1.0, e - 1 - 23);
+  for (int i = 0; i < n; i++) v[i] = rint(v[i] / q) * q;
+}
+
 // Closest rotation to the 3x3 cross-covariance A (row-major), Kabsch via Jacobi on A^T A:
 // right singular vectors sorted by descending eigenvalue (stable), u1 = A v1/|.|, u2 = GS(A v2),
 // u3 = u1 x u2, R = [u1 u2 u3] diag(1,1,sign det V) V^T.   (N5)

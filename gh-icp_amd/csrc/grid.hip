@@ -1,0 +1,187 @@
+// Uniform-grid build (cell keys -> stable radix sort -> cell table -> points in cell order) and the
+// voxel down-sampling filter.  rocPRIM/hipCUB is used for the radix sort / select primitives only.
+#include "grid.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_cell_keys(const float* __restrict__ xyz, long long n, int stride, GridDesc g, unsigned* __restrict__ keys,
+                                                   unsigned* __restrict__ vals) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= n) return;
+  const int cx = gh_cell_coord(xyz[i * stride], g.mn[0], g.inv, g.dim[0]);
+  const int cy = gh_cell_coord(xyz[i * stride + 1], g.mn[1], g.inv, g.dim[1]);
+  const int cz = gh_cell_coord(xyz[i * stride + 2], g.mn[2], g.inv, g.dim[2]);
+  keys[i] = ((unsigned)cx * g.dim[1] + cy) * g.dim[2] + cz;
+  vals[i] = (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void k_cell_start(const unsigned* __restrict__ keys, unsigned n, unsigned ncell, unsigned* __restrict__ start) {
+  const unsigned c = blockIdx.x * 256u + threadIdx.x;
+  if (c > ncell) return;
+  unsigned lo = 0, hi = n;  // lower_bound(keys, c)
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (keys[mid] < c) lo = mid + 1;
+    else hi = mid;
+  }
+  start[c] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_gather_sorted(const float* __restrict__ xyz, int stride, const unsigned* __restrict__ vals, long long n,
+                                                       float4* __restrict__ pts) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= n) return;
+  const long long s = vals[i];
+  pts[i] = make_float4(xyz[s * stride], xyz[s * stride + 1], xyz[s * stride + 2], __uint_as_float((unsigned)s));
+}
+
+static int bits_for(unsigned long long maxv) {
+  int b = 1;
+  while (b < 64 && (maxv >> b) != 0ull) b++;
+  return b;
+}
+
+}  // namespace
+
+int gh_grid_build(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float cell, const GridSlots& sl, DeviceGrid* out) {
+  hipStream_t s = ctx->stream;
+  GridDesc g;
+  memset(&g, 0, sizeof(g));
+  g.n = (int)n;
+  float mm[6] = {0, 0, 0, 0, 0, 0};
+  if (n > 0) GH_TRY(gh_bbox_dev(ctx, xyz, n, stride, mm));
+  for (;;) {  // coarsen until the dense cell table is affordable (a larger cell is still exact: superset search)
+    g.inv = 1.0f / cell;
+    unsigned long long nc = 1;
+    for (int d = 0; d < 3; d++) {
+      g.mn[d] = mm[d];
+      g.dim[d] = (int)std::floor((mm[3 + d] - mm[d]) * g.inv) + 1;
+      if (g.dim[d] < 1) g.dim[d] = 1;
+      nc *= (unsigned long long)g.dim[d];
+    }
+    if (nc <= (1ull << 26)) { g.ncell = (unsigned)nc; break; }
+    cell *= 1.5f;
+  }
+  unsigned *keys, *keys2, *vals, *vals2, *start;
+  float4* pts;
+  GH_TRY(ctx->reserve(sl.keys, (size_t)n + 1, &keys));
+  GH_TRY(ctx->reserve(sl.keys2, (size_t)n + 1, &keys2));
+  GH_TRY(ctx->reserve(sl.vals, (size_t)n + 1, &vals));
+  GH_TRY(ctx->reserve(sl.vals2, (size_t)n + 1, &vals2));
+  GH_TRY(ctx->reserve(sl.start, (size_t)g.ncell + 2, &start));
+  GH_TRY(ctx->reserve(sl.pts, (size_t)n + 1, &pts));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, n, stride, g, keys, vals);
+    size_t tb = 0;
+    const int eb = bits_for(g.ncell);
+    GH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));
+    char* tmp;
+    GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+    GH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));
+    hipLaunchKernelGGL(k_gather_sorted, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, stride, vals2, n, pts);
+  }
+  hipLaunchKernelGGL(k_cell_start, dim3(cdiv((long long)g.ncell + 1, 256)), dim3(256), 0, s, keys2, (unsigned)n, g.ncell, start);
+  GH_HIP(hipGetLastError());
+  out->d = g;
+  out->pts = pts;
+  out->start = start;
+  out->keys = keys2;
+  return GHICP_OK;
+}
+
+// =============================================================================== voxel filter
+namespace {
+
+struct VoxDesc {
+  float mn[3];
+  float inv;
+  unsigned long long mul_x, mul_y;
+};
+
+// filter.hpp:57-70: float (p - min) * inv, floor, cast to u64; key = vx*mul_vx + vy*mul_vy + vz
+__global__ __launch_bounds__(256) void k_voxel_keys(const float* __restrict__ xyz, long long n, int stride, VoxDesc v,
+                                                    unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long vx = (unsigned long long)floorf((xyz[i * stride] - v.mn[0]) * v.inv);
+  const unsigned long long vy = (unsigned long long)floorf((xyz[i * stride + 1] - v.mn[1]) * v.inv);
+  const unsigned long long vz = (unsigned long long)floorf((xyz[i * stride + 2] - v.mn[2]) * v.inv);
+  keys[i] = vx * v.mul_x + vy * v.mul_y + vz;
+  vals[i] = (unsigned)i;
+}
+
+// head of every voxel run whose key > 0; slot 0 of the output is the phantom group (filter.hpp:52,66,75-83)
+__global__ __launch_bounds__(256) void k_voxel_flags(const unsigned long long* __restrict__ keys, long long n, unsigned char* __restrict__ flags) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  flags[i] = (k != 0ull && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+__global__ void k_set_first(int* keep) { keep[0] = 0; }
+
+}  // namespace
+
+int gh_voxel_filter_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float voxel, int32_t* keep, long long* m_out) {
+  hipStream_t s = ctx->stream;
+  if (n <= 0) { *m_out = 0; return GHICP_OK; }
+  float mm[6];
+  GH_TRY(gh_bbox_dev(ctx, xyz, n, stride, mm));
+  VoxDesc v;
+  v.inv = 1.0f / voxel;  // filter.hpp:30
+  unsigned long long maxv[3];
+  for (int d = 0; d < 3; d++) {
+    v.mn[d] = mm[d];
+    const float gap = mm[3 + d] - mm[d];                              // Eigen::Vector4f gap_p = max_p - min_p
+    maxv[d] = (unsigned long long)(std::ceil(gap * v.inv) + 1);       // filter.hpp:38-40
+  }
+  v.mul_x = maxv[1] * maxv[2];
+  v.mul_y = maxv[2];
+  const long double total = (long double)maxv[0] * (long double)maxv[1] * (long double)maxv[2];
+  if (total >= 18446744073709551615.0L) return ctx->fail(GHICP_ERR_CAPACITY, "voxel filter: the number of boxes exceeds the limit");  // filter.hpp:42-46
+  unsigned long long *keys, *keys2;
+  unsigned *vals, *vals2;
+  unsigned char* flags;
+  int* dcount;
+  GH_TRY(ctx->reserve(B_GRID_KEYS, (size_t)n * 2 + 2, (unsigned**)&keys));
+  GH_TRY(ctx->reserve(B_GRID_KEYS2, (size_t)n * 2 + 2, (unsigned**)&keys2));
+  GH_TRY(ctx->reserve(B_GRID_VALS, (size_t)n + 1, &vals));
+  GH_TRY(ctx->reserve(B_GRID_VALS2, (size_t)n + 1, &vals2));
+  GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)n + 16, &flags));
+  GH_TRY(ctx->reserve(B_FE_SCAN, 16, &dcount));
+  hipLaunchKernelGGL(k_voxel_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, n, stride, v, keys, vals);
+  const unsigned long long maxkey = (maxv[0] - 1) * v.mul_x + (maxv[1] - 1) * v.mul_y + (maxv[2] - 1);
+  const int eb = bits_for(maxkey);
+  size_t tb = 0, tb2 = 0;
+  GH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));
+  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));
+  char* tmp;
+  GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
+  GH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));  // stable: lowest input index leads its voxel
+  hipLaunchKernelGGL(k_voxel_flags, dim3(cdiv(n, 256)), dim3(256), 0, s, keys2, n, flags);
+  hipLaunchKernelGGL(k_set_first, dim3(1), dim3(1), 0, s, keep);
+  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));
+  int hc = 0;
+  GH_HIP(hipMemcpyAsync(&hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+  GH_HIP(hipStreamSynchronize(s));
+  *m_out = (long long)hc + 1;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_voxel_filter(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float voxel, int32_t* keep_idx, int64_t* m) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(n >= 0 && n < (1ll << 31) - 2 && stride >= 3 && voxel > 0.f && m != nullptr);
+  Stager sg(ctx);
+  const float* d;
+  int32_t* k;
+  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.out(keep_idx, (size_t)n + 1, &k));
+  long long mm = 0;
+  GH_TRY(gh_voxel_filter_dev(ctx, d, n, stride, voxel, k, &mm));
+  *m = mm;
+  return sg.finish();
+}

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, doub
   for (int d = 0; d < 9; d++) H[d] = gh_block_sum(H[d], red);
   if (tid == 0) {
     double A[9], R[9];
-    for (int d = 0; d < 9; d++) A[d] = (double)(float)(H[d] / (double)cor);
+    for (int d = 0; d < 9; d++) A[d] = H[d] / (double)cor;
+    gh_quant_grid(A, 9);  // N2: umeyama's sigma is a Matrix3f
     gh_kabsch(A, R);
     float Rf[9], tf[3];
     for (int d = 0; d < 9; d++) Rf[d] = (float)R[d];

@@ -1,0 +1,195 @@
+// Keypoint front end, part 2 (gfx950): CKeypointDetect::nonMaximaSuppression
+// (reference include/keypoint_detect.hpp:149-191) and the PCA -> prune -> NMS driver
+// keypointDetectionBasedOnCurvature (keypoint_detect.hpp:27-51).
+//
+// The reference is a sequential greedy sweep: sort candidates by curvature (descending), repeatedly
+// emit the best unsuppressed one and erase everything within R of it.  Greedy NMS over a strict total
+// order is the unique fixed point of
+//     selected(i)  <=>  no selected j with rank(j) < rank(i) and d2(i,j) < R^2          
+// which is computed here in parallel rounds: a candidate whose better-ranked neighbours are all
+// decided-suppressed becomes selected; one with a selected better-ranked neighbour becomes suppressed.
+// Rank = (curvature desc, candidate order asc): stable radix sort, so ties resolve to the lower point index.
+#include "grid.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+struct GridArgs {
+  GridDesc d;
+  const float4* pts;
+  const unsigned* start;
+};
+
+// order-preserving map f64 -> u64 (ascending); NaN never reaches here (prune rejects it)
+__device__ inline unsigned long long f64_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(256) void k_nms_keys(const double* __restrict__ curvature, const int* __restrict__ cand, int c,
+                                                  unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c) return;
+  keys[i] = f64_key(curvature[cand[i]]);
+  vals[i] = i;
+}
+
+// cpts[r] = xyz of the rank-r candidate (packed float3 rows for gh_grid_build)
+__global__ __launch_bounds__(256) void k_nms_points(const float* __restrict__ xyz, int stride, const int* __restrict__ cand,
+                                                    const int* __restrict__ ord, int c, float* __restrict__ cpts) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= c) return;
+  const long long s = cand[ord[r]];
+  cpts[r * 3] = xyz[s * stride];
+  cpts[r * 3 + 1] = xyz[s * stride + 1];
+  cpts[r * 3 + 2] = xyz[s * stride + 2];
+}
+
+enum { UNDECIDED = 0, SELECTED = 1, SUPPRESSED = 2 };
+
+__global__ __launch_bounds__(256) void k_nms_round(GridArgs G, float r2, int* __restrict__ state, int* __restrict__ undecided) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= G.d.n) return;
+  const float4 P = G.pts[p];
+  const int rp = (int)__float_as_uint(P.w);
+  if (__hip_atomic_load(&state[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != UNDECIDED) return;
+  const int cx = gh_cell_coord(P.x, G.d.mn[0], G.d.inv, G.d.dim[0]);
+  const int cy = gh_cell_coord(P.y, G.d.mn[1], G.d.inv, G.d.dim[1]);
+  const int cz = gh_cell_coord(P.z, G.d.mn[2], G.d.inv, G.d.dim[2]);
+  for (int pass = 0; pass < 4; pass++) {  // a few in-kernel sweeps let decisions propagate several hops per launch
+    bool pending = false, killed = false;
+    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+      for (unsigned q = b; q < e && !killed; q++) {
+        const float4 Q = G.pts[q];
+        const int rq = (int)__float_as_uint(Q.w);
+        if (rq >= rp) continue;
+        const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        if (d2 < r2) {
+          const int sq = __hip_atomic_load(&state[rq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (sq == SELECTED) killed = true;
+          else if (sq == UNDECIDED) pending = true;
+        }
+      }
+    });
+    if (killed) { __hip_atomic_store(&state[rp], SUPPRESSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (!pending) { __hip_atomic_store(&state[rp], SELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+  }
+  atomicAdd(undecided, 1);
+}
+
+__global__ __launch_bounds__(256) void k_nms_flags(const int* __restrict__ state, int c, unsigned char* __restrict__ flags) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < c) flags[r] = state[r] == SELECTED ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_nms_emit(const int* __restrict__ sel_rank, const int* __restrict__ nsel, const int* __restrict__ cand,
+                                                  const int* __restrict__ ord, int* __restrict__ kp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < *nsel) kp[i] = cand[ord[sel_rank[i]]];
+}
+
+}  // namespace
+
+int gh_pca_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float radius, float* lambda, double* curvature, int32_t* count);
+int gh_prune_dev(ghicp_ctx* ctx, const float* lambda, const int32_t* count, long long m, float ratio_max, int min_n, int32_t* cand, long long* c_out);
+
+int gh_nms_dev(ghicp_ctx* ctx, const float* xyz, int stride, const double* curvature, const int32_t* cand, long long c, float radius, int32_t* kp,
+               long long* k_out) {
+  *k_out = 0;
+  if (c <= 0) return GHICP_OK;  // NB the reference's do-while dereferences an empty set here (keypoint_detect.hpp:177)
+  hipStream_t s = ctx->stream;
+  unsigned long long *keys, *keys2;
+  int *vals, *ord, *state, *misc, *selrank;
+  float* cpts;
+  unsigned char* flags;
+  GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)c + 1, &keys));
+  GH_TRY(ctx->reserve(B_FE_SORTK2, (size_t)c + 1, &keys2));
+  GH_TRY(ctx->reserve(B_FE_SORTV, (size_t)c + 1, &vals));
+  GH_TRY(ctx->reserve(B_FE_SORTV2, (size_t)c + 1, &ord));
+  GH_TRY(ctx->reserve(B_FE_STATE, (size_t)c + 1, &state));
+  GH_TRY(ctx->reserve(B_FE_CPTS, (size_t)c * 3 + 3, &cpts));
+  GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)c + 16, &flags));
+  GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
+  GH_TRY(ctx->reserve(B_FE_KP, (size_t)c + 1, &selrank));
+  hipLaunchKernelGGL(k_nms_keys, dim3(cdiv(c, 256)), dim3(256), 0, s, curvature, cand, (int)c, keys, vals);
+  size_t tb = 0, tb2 = 0;
+  GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys, keys2, vals, ord, (int)c, 0, 64, s));
+  hipcub::CountingInputIterator<int> iota(0);
+  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, iota, flags, selrank, misc, (int)c, s));
+  char* tmp;
+  GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
+  GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, keys, keys2, vals, ord, (int)c, 0, 64, s));  // stable
+  hipLaunchKernelGGL(k_nms_points, dim3(cdiv(c, 256)), dim3(256), 0, s, xyz, stride, cand, ord, (int)c, cpts);
+  DeviceGrid G;
+  const GridSlots sl = {B_GRID_KEYS, B_GRID_KEYS2, B_GRID_VALS, B_GRID_VALS2, B_GRID_START, B_GRID_PTS};
+  GH_TRY(gh_grid_build(ctx, cpts, c, 3, radius * 1.0001f, sl, &G));  // float4.w of the grid points = rank
+  GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
+  GH_HIP(hipMemsetAsync(state, 0, (size_t)c * sizeof(int), s));
+  GridArgs A = {G.d, G.pts, G.start};
+  const float r2 = (float)((double)radius * (double)radius);
+  int* hflag = reinterpret_cast<int*>(ctx->pinned);
+  for (int round = 0;; round++) {
+    for (int r = 0; r < 4; r++) {
+      GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
+      hipLaunchKernelGGL(k_nms_round, dim3(cdiv(c, 256)), dim3(256), 0, s, A, r2, state, misc + 1);
+    }
+    GH_HIP(hipMemcpyAsync(hflag, misc + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    GH_HIP(hipStreamSynchronize(s));
+    if (hflag[0] == 0) break;
+    if (round > (int)c + 8) return ctx->fail(GHICP_ERR_INTERNAL, "nms: no progress");
+  }
+  hipLaunchKernelGGL(k_nms_flags, dim3(cdiv(c, 256)), dim3(256), 0, s, state, (int)c, flags);
+  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, iota, flags, selrank, misc, (int)c, s));  // ascending rank = descending curvature
+  hipLaunchKernelGGL(k_nms_emit, dim3(cdiv(c, 256)), dim3(256), 0, s, selrank, misc, cand, ord, kp);
+  GH_HIP(hipMemcpyAsync(hflag, misc, sizeof(int), hipMemcpyDeviceToHost, s));
+  GH_HIP(hipStreamSynchronize(s));
+  *k_out = hflag[0];
+  return GHICP_OK;
+}
+
+int gh_keypoints_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float radius, float ratio_max, int min_n, float nms_radius,
+                     int32_t* kp, long long* k_out) {
+  *k_out = 0;
+  if (m <= 0) return GHICP_OK;
+  float* lambda;
+  double* curv;
+  int *count, *cand;
+  GH_TRY(ctx->reserve(B_FE_LAMBDA, (size_t)m * 3 + 3, &lambda));
+  GH_TRY(ctx->reserve(B_FE_CURV, (size_t)m + 1, &curv));
+  GH_TRY(ctx->reserve(B_FE_COUNT, (size_t)m + 1, &count));
+  GH_TRY(ctx->reserve(B_FE_CAND, (size_t)m + 1, &cand));
+  GH_TRY(gh_pca_dev(ctx, xyz, m, stride, radius, lambda, curv, count));
+  long long c = 0;
+  GH_TRY(gh_prune_dev(ctx, lambda, count, m, ratio_max, min_n, cand, &c));
+  return gh_nms_dev(ctx, xyz, stride, curv, cand, c, nms_radius, kp, k_out);
+}
+
+extern "C" int ghicp_nms(ghicp_ctx* ctx, const float* xyz, int stride, const double* curvature, const int32_t* cand, int64_t c, float radius,
+                         int32_t* kp, int64_t* k) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(c >= 0 && c < (1ll << 31) - 2 && stride >= 3 && radius > 0.f && k != nullptr);
+  if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_nms: device-pointer mode only (use ghicp_keypoints from host memory)");
+  long long kk = 0;
+  GH_TRY(gh_nms_dev(ctx, xyz, stride, curvature, cand, c, radius, kp, &kk));
+  *k = kk;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_keypoints(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float ratio_max, int min_n,
+                               float nms_radius, int32_t* kp_idx, int64_t* k) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(m >= 0 && m < (1ll << 31) - 2 && stride >= 3 && radius > 0.f && nms_radius > 0.f && k != nullptr);
+  Stager sg(ctx);
+  const float* d;
+  int32_t* dk;
+  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.out(kp_idx, (size_t)m, &dk));
+  long long kk = 0;
+  GH_TRY(gh_keypoints_dev(ctx, d, m, stride, radius, ratio_max, min_n, nms_radius, dk, &kk));
+  *k = kk;
+  return sg.finish();
+}

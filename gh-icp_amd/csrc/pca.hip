@@ -1,0 +1,214 @@
+// Keypoint front end, part 1 (gfx950):
+//   k_pca_cells : PrincipleComponentAnalysis::CalculatePcaFeaturesOfPointCloud + CalculatePcaFeature
+//                 (reference include/pca.h:133-165, 202-250).  One wave per occupied grid cell: the
+//                 lanes are the cell's query points, the 27-cell neighbourhood (9 contiguous runs of
+//                 the cell-sorted float4 array) is staged through LDS in coalesced 16-byte loads and
+//                 every lane sweeps the tile with broadcast ds_read_b128.  Two sweeps (centroid, then
+//                 de-meaned scatter) in f64, scatter rounded once to f32 (pcl::PCA is a Matrix3f),
+//                 eigenvalues by cyclic Jacobi (numerics contract N1-N3).
+//   prune       : CKeypointDetect::pruneUnstablePoints (include/keypoint_detect.hpp:132-147).
+// Roofline: HBM-bound by contract (16 B in + 24 B out per point); the 27-cell gather re-reads are
+// served by LDS/L2 (streamed traffic 16*M*27-cell amplification).
+#include "grid.h"
+#include "devmath.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+constexpr int PCA_CHUNK = 512;
+
+struct GridArgs {
+  GridDesc d;
+  const float4* pts;
+  const unsigned* start;
+};
+
+__global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __restrict__ cells, const int* __restrict__ ncells,
+                                                   int* __restrict__ counter, float r2, float* __restrict__ lambda,
+                                                   double* __restrict__ curvature, int* __restrict__ count) {
+  __shared__ float4 sC[PCA_CHUNK];
+  __shared__ int s_cell;
+  const int lane = threadIdx.x;
+  const int nc = *ncells;
+  for (;;) {
+    if (lane == 0) s_cell = atomicAdd(counter, 1);
+    __syncthreads();
+    const int c = __builtin_amdgcn_readfirstlane(s_cell);
+    __syncthreads();
+    if (c >= nc) break;
+    const unsigned key = cells[c];
+    const int cz = key % G.d.dim[2];
+    const int cy = (key / G.d.dim[2]) % G.d.dim[1];
+    const int cx = key / (G.d.dim[2] * G.d.dim[1]);
+    const unsigned qb = G.start[key], qe = G.start[key + 1];
+    for (unsigned q0 = qb; q0 < qe; q0 += 64) {
+      const unsigned q = q0 + lane;
+      const bool live = q < qe;
+      float4 P = make_float4(0, 0, 0, 0);
+      if (live) P = G.pts[q];
+      // ---- sweep 1: neighbour count and centroid (pca.h:151, pcl::PCA mean)
+      int k = 0;
+      double sx = 0, sy = 0, sz = 0;
+      gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
+        for (unsigned base = rb; base < re; base += PCA_CHUNK) {
+          const int cnt = min((unsigned)PCA_CHUNK, re - base);
+          for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
+          __syncthreads();
+          if (live)
+            for (int t = 0; t < cnt; t++) {
+              const float4 Cc = sC[t];
+              const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
+              float d2 = dx * dx;
+              d2 += dy * dy;
+              d2 += dz * dz;
+              if (d2 < r2) { k++; sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z; }
+            }
+          __syncthreads();
+        }
+      });
+      const double mx = sx / (double)k, my = sy / (double)k, mz = sz / (double)k;
+      // ---- sweep 2: de-meaned scatter
+      double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+      gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
+        for (unsigned base = rb; base < re; base += PCA_CHUNK) {
+          const int cnt = min((unsigned)PCA_CHUNK, re - base);
+          for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
+          __syncthreads();
+          if (live && k >= 3)
+            for (int t = 0; t < cnt; t++) {
+              const float4 Cc = sC[t];
+              const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
+              float d2 = dx * dx;
+              d2 += dy * dy;
+              d2 += dz * dz;
+              if (d2 < r2) {
+                const double ex = (double)Cc.x - mx, ey = (double)Cc.y - my, ez = (double)Cc.z - mz;
+                s00 += ex * ex; s01 += ex * ey; s02 += ex * ez;
+                s11 += ey * ey; s12 += ey * ez; s22 += ez * ez;
+              }
+            }
+          __syncthreads();
+        }
+      });
+      if (live) {
+        const unsigned orig = __float_as_uint(P.w);
+        float l1 = 0.f, l2 = 0.f, l3 = 0.f;
+        double cv = 0.0;
+        if (k >= 3) {  // pca.h:209
+          double S[6] = {s00, s01, s02, s11, s12, s22};
+          gh_quant_grid(S, 6);  // N2: pcl::PCA's Matrix3f
+          double a00 = (double)(float)S[0], a01 = (double)(float)S[1], a02 = (double)(float)S[2], a11 = (double)(float)S[3],
+                 a12 = (double)(float)S[4], a22 = (double)(float)S[5];
+          double V[9];
+          gh_jacobi3(a00, a01, a02, a11, a12, a22, V);
+          double e0 = a00, e1 = a11, e2 = a22, t;  // ascending sort
+          if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
+          if (e1 > e2) { t = e1; e1 = e2; e2 = t; }
+          if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
+          l1 = (float)e2; l2 = (float)e1; l3 = (float)e0;
+          const double d1 = (double)l1, d2_ = (double)l2, d3 = (double)l3;
+          cv = ((d1 + d2_ + d3) == 0.0) ? 0.0 : d3 / (d1 + d2_ + d3);  // pca.h:240-247
+        }
+        lambda[(size_t)orig * 3] = l1;
+        lambda[(size_t)orig * 3 + 1] = l2;
+        lambda[(size_t)orig * 3 + 2] = l3;
+        curvature[orig] = cv;
+        count[orig] = k;
+      }
+    }
+  }
+}
+
+// keypoint_detect.hpp:132-147: float ratios of the (f32-valued) double eigenvalues; NaN fails
+__global__ __launch_bounds__(256) void k_prune_flags(const float* __restrict__ lambda, const int* __restrict__ count, long long m, float ratio_max,
+                                                     int min_n, unsigned char* __restrict__ flags) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= m) return;
+  const double l1 = (double)lambda[i * 3], l2 = (double)lambda[i * 3 + 1], l3 = (double)lambda[i * 3 + 2];
+  const float r1 = (float)(l2 / l1), r2 = (float)(l3 / l2);
+  flags[i] = (r1 < ratio_max && r2 < ratio_max && count[i] > min_n) ? 1 : 0;
+}
+
+}  // namespace
+
+int gh_pca_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float radius, float* lambda, double* curvature, int32_t* count) {
+  if (m <= 0) return GHICP_OK;
+  hipStream_t s = ctx->stream;
+  DeviceGrid G;
+  const GridSlots sl = {B_GRID_KEYS, B_GRID_KEYS2, B_GRID_VALS, B_GRID_VALS2, B_GRID_START, B_GRID_PTS};
+  GH_TRY(gh_grid_build(ctx, xyz, m, stride, radius * 1.0001f, sl, &G));
+  // occupied cells = unique sorted keys
+  unsigned* cells;
+  int* misc;
+  GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)m + 1, &cells));
+  GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
+  size_t tb = 0;
+  GH_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, G.keys, cells, misc, (int)m, s));
+  char* tmp;
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+  GH_HIP(hipcub::DeviceSelect::Unique(tmp, tb, G.keys, cells, misc, (int)m, s));
+  GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
+  GridArgs A = {G.d, G.pts, G.start};
+  const float r2 = (float)((double)radius * (double)radius);  // pcl radiusSearch: static_cast<float>(radius*radius)
+  const int blocks = ctx->num_cu * 20;
+  hipLaunchKernelGGL(k_pca_cells, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, lambda, curvature, count);
+  GH_HIP(hipGetLastError());
+  return GHICP_OK;
+}
+
+int gh_prune_dev(ghicp_ctx* ctx, const float* lambda, const int32_t* count, long long m, float ratio_max, int min_n, int32_t* cand, long long* c_out) {
+  *c_out = 0;
+  if (m <= 0) return GHICP_OK;
+  hipStream_t s = ctx->stream;
+  unsigned char* flags;
+  int* dcount;
+  GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)m + 16, &flags));
+  GH_TRY(ctx->reserve(B_FE_SCAN, 16, &dcount));
+  hipLaunchKernelGGL(k_prune_flags, dim3(cdiv(m, 256)), dim3(256), 0, s, lambda, count, m, ratio_max, min_n, flags);
+  hipcub::CountingInputIterator<int> iota(0);
+  size_t tb = 0;
+  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, iota, flags, cand, dcount, (int)m, s));
+  char* tmp;
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb, iota, flags, cand, dcount, (int)m, s));
+  int hc = 0;
+  GH_HIP(hipMemcpyAsync(&hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+  GH_HIP(hipStreamSynchronize(s));
+  *c_out = hc;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_pca_curvature(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float* lambda, double* curvature,
+                                   int32_t* count) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(m >= 0 && m < (1ll << 31) - 2 && stride >= 3 && radius > 0.f);
+  Stager sg(ctx);
+  const float* d;
+  float* dl;
+  double* dc;
+  int32_t* dn;
+  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.out(lambda, (size_t)m * 3, &dl));
+  GH_TRY(sg.out(curvature, (size_t)m, &dc));
+  GH_TRY(sg.out(count, (size_t)m, &dn));
+  GH_TRY(gh_pca_dev(ctx, d, m, stride, radius, dl, dc, dn));
+  return sg.finish();
+}
+
+extern "C" int ghicp_prune(ghicp_ctx* ctx, const float* lambda, const int32_t* count, int64_t m, float ratio_max, int min_n, int32_t* cand,
+                           int64_t* c) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(m >= 0 && m < (1ll << 31) - 2 && c != nullptr);
+  Stager sg(ctx);
+  const float* dl;
+  const int32_t* dn;
+  int32_t* dc;
+  GH_TRY(sg.in(lambda, (size_t)m * 3, &dl));
+  GH_TRY(sg.in(count, (size_t)m, &dn));
+  GH_TRY(sg.out(cand, (size_t)m, &dc));
+  long long cc = 0;
+  GH_TRY(gh_prune_dev(ctx, dl, dn, m, ratio_max, min_n, dc, &cc));
+  *c = cc;
+  return sg.finish();
+}

@@ -65,6 +65,20 @@ static void jacobi3(double a[3][3], double v[3][3]) {
   }
 }
 
+// Numerics contract N2: a matrix the reference holds as Matrix3f is rounded ONCE from its f64 sums onto the
+// f32 grid of the MATRIX scale: every entry becomes the nearest multiple of 2^(e-23), e = exponent of the
+// largest |entry| (ties to even).  Per-entry f32 rounding would keep ~24 significant bits of entries that are
+// tiny only through cancellation, i.e. summation-order noise no f32-accumulating reference can resolve.
+static void quant_grid(double* v, int n) {
+  double mx = 0;
+  for (int i = 0; i < n; i++) mx = std::max(mx, std::fabs(v[i]));
+  if (!(mx > 0) || !std::isfinite(mx)) return;
+  int e;
+  std::frexp(mx, &e);  // mx = f * 2^e, f in [0.5,1)
+  const double q = std::ldexp(1.0, e - 1 - 23);
+  for (int i = 0; i < n; i++) v[i] = std::nearbyint(v[i] / q) * q;
+}
+
 // Closest rotation to a 3x3 cross-covariance (Kabsch / Eigen::umeyama without scaling):
 // V, sigma^2 from Jacobi on A^T A (sorted descending), u1 = A v1/|.|, u2 = Gram-Schmidt(A v2),
 // u3 = u1 x u2, R = [u1 u2 u3] diag(1,1,det V) V^T.
@@ -250,8 +264,9 @@ static void pca_features(const float* xyz, int m, int stride, float radius, floa
       S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
       S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
     }
+    quant_grid(S, 6);  // pcl::PCA holds a Matrix3f (N2)
     float Sf[6];
-    for (int q = 0; q < 6; q++) Sf[q] = (float)S[q];  // pcl::PCA holds a Matrix3f
+    for (int q = 0; q < 6; q++) Sf[q] = (float)S[q];
     double a[3][3] = {{Sf[0], Sf[1], Sf[2]}, {Sf[1], Sf[3], Sf[4]}, {Sf[2], Sf[4], Sf[5]}}, v[3][3];
     jacobi3(a, v);
     double ev[3] = {a[0][0], a[1][1], a[2][2]};
@@ -383,6 +398,7 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
         C[0] += (double)w * dx * dx; C[1] += (double)w * dx * dy; C[2] += (double)w * dx * dz;
         C[3] += (double)w * dy * dy; C[4] += (double)w * dy * dz; C[5] += (double)w * dz * dz;
       }
+      quant_grid(C, 6);                 // Matrix3f covariance (N2)
       const float da = (float)dis_all;  // Matrix3f /= double scalar -> float divisor
       float Cf[6];
       for (int t = 0; t < 6; t++) Cf[t] = (float)C[t] / da;
@@ -658,7 +674,8 @@ void orc_rigid_svd(const double* src, const double* tgt, int c, double* Rt16) {
     for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) H[r][q] += a[r] * b[q];
   }
   double A[3][3], R[3][3];
-  for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) A[r][q] = (double)(float)(H[r][q] / c);
+  for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) A[r][q] = H[r][q] / c;
+  orc::quant_grid(&A[0][0], 9);  // Eigen::umeyama's sigma is a Matrix3f (N2)
   orc::kabsch_rotation(A, R);
   float Rf[3][3], tf[3];
   for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) Rf[r][q] = (float)R[r][q];

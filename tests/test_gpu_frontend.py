@@ -1,0 +1,146 @@
+"""GPU parity of the per-cloud front end (voxel filter, PCA/curvature, prune, NMS, BSC) and of the
+whole-pair pipeline against the CPU oracle, stage by stage on identical inputs (through the C ABI)."""
+import numpy as np
+import pytest
+
+from conftest import rot_err, trans_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tls(synth):
+    return synth.tls_pair(120_000)
+
+
+@pytest.fixture(scope="module")
+def ds_target(tls, oracle):
+    keep = oracle.voxel_filter(tls.target, 0.1)
+    return tls.target[keep]
+
+
+def test_voxel_filter(ctx, oracle, tls, synth):
+    for cloud, voxel in ((tls.target, 0.1), (tls.source, 0.25), (synth.gauss_pair(5000).source, 0.5)):
+        ko = oracle.voxel_filter(cloud, voxel)
+        kg = ctx.voxel_filter(cloud, voxel).cpu().numpy()
+        np.testing.assert_array_equal(kg, ko)  # index work: bit-exact, incl. the phantom row 0 (Q1)
+        assert kg[0] == 0 and len(set(kg[1:].tolist())) == len(kg) - 1
+    # edge cases: single point, all points in one voxel
+    one = np.array([[1.0, 2.0, 3.0]], np.float32)
+    np.testing.assert_array_equal(ctx.voxel_filter(one, 0.1).cpu().numpy(), oracle.voxel_filter(one, 0.1))
+    same = np.tile(one, (100, 1))
+    np.testing.assert_array_equal(ctx.voxel_filter(same, 0.1).cpu().numpy(), oracle.voxel_filter(same, 0.1))
+
+
+def test_bbx_magnitude(ctx, oracle, tls):
+    assert ctx.bbx_magnitude(tls.source) == oracle.bbx_magnitude(tls.source)
+
+
+def test_pca_curvature(ctx, oracle, ds_target):
+    lo, co, no = oracle.pca(ds_target, 0.5)
+    lg, cg, ng = ctx.pca_curvature(ds_target, 0.5)
+    lg, cg, ng = lg.cpu().numpy(), cg.cpu().numpy(), ng.cpu().numpy()
+    np.testing.assert_array_equal(ng, no)  # neighbour counts: exact radius search, bit-exact
+    # f64-accumulate / round-once contract: the f32 eigenvalues agree to the bit (tolerate a handful of
+    # 1-ulp straddles of the f32 rounding boundary)
+    bad = np.flatnonzero((lg != lo).any(axis=1))
+    assert bad.size <= max(3, lo.shape[0] // 20000), bad.size
+    np.testing.assert_allclose(lg, lo, rtol=3e-7, atol=0)
+    np.testing.assert_allclose(cg, co, rtol=1e-6, atol=1e-12)
+    # independent check of the oracle on a few points: numpy eigh of the same scatter
+    from scipy.spatial import cKDTree
+
+    tree = cKDTree(ds_target.astype(np.float64))
+    for i in (0, 17, 4000, ds_target.shape[0] - 1):
+        nb = tree.query_ball_point(ds_target[i].astype(np.float64), 0.5 - 1e-9)
+        if abs(len(nb) - no[i]) > 1 or len(nb) < 3:
+            continue
+        q = ds_target[nb].astype(np.float64)
+        ev = np.sort(np.linalg.eigvalsh((q - q.mean(0)).T @ (q - q.mean(0))))[::-1]
+        if len(nb) == no[i]:
+            np.testing.assert_allclose(lo[i], ev, rtol=1e-4, atol=1e-6)
+
+
+def test_prune_and_nms(ctx, oracle, ds_target):
+    lo, co, no = oracle.pca(ds_target, 0.5)
+    cand_o = oracle.prune(lo, no)
+    cand_g = ctx.prune(lo, no).cpu().numpy()
+    np.testing.assert_array_equal(cand_g, cand_o)
+    for R in (1.5, 0.7):
+        kp_o = oracle.nms(ds_target, co, cand_o, R)
+        kp_g = ctx.nms(ds_target, co, cand_o, R).cpu().numpy()
+        np.testing.assert_array_equal(kp_g, kp_o)  # same set AND same (descending-curvature) order
+        # NMS invariants: minimum separation >= R, curvature non-increasing
+        P = ds_target[kp_g].astype(np.float64)
+        if len(kp_g) > 1:
+            from scipy.spatial import cKDTree
+
+            d, _ = cKDTree(P).query(P, k=2)
+            assert d[:, 1].min() >= R * (1 - 1e-6)
+        assert np.all(np.diff(co[kp_g]) <= 0)
+    # ties: all-equal curvature must resolve to the lower index first
+    flat = np.zeros_like(co)
+    np.testing.assert_array_equal(ctx.nms(ds_target, flat, cand_o, 1.5).cpu().numpy(), oracle.nms(ds_target, flat, cand_o, 1.5))
+    # empty candidate list
+    assert ctx.nms(ds_target, co, np.zeros(0, np.int32), 1.5).numel() == 0
+
+
+def test_keypoints_end_to_end(ctx, oracle, ds_target):
+    kp_o, _ = oracle.keypoints(ds_target, 0.5, 1.5)
+    kp_g = ctx.keypoints(ds_target, 0.5, 1.5).cpu().numpy()
+    np.testing.assert_array_equal(kp_g, kp_o)
+    assert len(kp_g) > 50
+
+
+@pytest.mark.parametrize("dof,pattern", [(6, "glibc"), (4, "zero"), (0, "glibc")])
+def test_bsc_encode(ctx, oracle, synth, ds_target, dof, pattern):
+    pat = synth.bsc_pattern_glibc() if pattern == "glibc" else synth.bsc_pattern_zero()
+    kp, _ = oracle.keypoints(ds_target, 0.5, 1.5)
+    fo, lo, _ = oracle.bsc(ds_target, kp, 1.5, dof, pat)
+    fg, lg = ctx.bsc_encode(ds_target, kp, 1.5, dof, pat)
+    fg, lg = fg.cpu().numpy(), lg.cpu().numpy()
+    np.testing.assert_array_equal(lg, lo)  # LCS axes: f32 bit-exact
+    ham = np.unpackbits(fg ^ fo, axis=-1).sum(-1)  # (4, K)
+    # 441-bit strings: bit-exact (tolerate <= 1 flipped bit on <= 0.5% of keypoints: thresholds on f32 values
+    # whose f64 sums were formed in a different order)
+    assert ham.max() <= 1 and (ham > 0).sum() <= max(1, kp.size // 200), (ham.max(), (ham > 0).sum())
+    nvar = 4 if dof > 4 else (2 if dof > 0 else 1)
+    assert not fg[nvar:].any()
+    if pattern == "zero":  # Q2: with the shipped (0,0) pattern every compare bit is 0
+        bits = np.unpackbits(fg[0], axis=-1, bitorder="little")
+        assert not bits[:, 147:441].any()
+    for v in range(1, nvar):  # Q3: flip variants carry bits only in [147, 294)
+        bits = np.unpackbits(fg[v], axis=-1, bitorder="little")
+        assert not bits[:, :147].any() and not bits[:, 294:].any()
+
+
+@pytest.mark.parametrize("corr", ["NN", "KM"])
+def test_pair_pipeline_vs_oracle(ctx, api, oracle, synth, tls, corr):
+    """test/ghicp_main.cpp order on device vs the oracle's pipeline; final 4x4 within the north_star tolerance."""
+    pat = synth.bsc_pattern_glibc()
+    c = api.CORR_NN if corr == "NN" else api.CORR_KM
+    cfg = api.pair_config(api.FEATURE_BSC, c, 6, 0.6, 0.1, 0.5, 1.5, pat, max_iter=80)
+    stats, tr = ctx.register_pair(cfg, tls.source, tls.target)
+    # oracle pipeline
+    ds, kp, feat = {}, {}, {}
+    for name, cloud, dof in (("T", tls.target, 0), ("S", tls.source, 6)):
+        keep = oracle.voxel_filter(cloud, 0.1)
+        ds[name] = cloud[keep]
+        kp[name], _ = oracle.keypoints(ds[name], 0.5, 1.5)
+        feat[name], _, _ = oracle.bsc(ds[name], kp[name], 1.5, dof, pat)
+    assert (stats.m_s, stats.m_t, stats.k_s, stats.k_t) == (ds["S"].shape[0], ds["T"].shape[0], kp["S"].size, kp["T"].size)
+    FD = oracle.fd_bsc(feat["S"], feat["T"][0])
+    bbx = oracle.bbx_magnitude(ds["S"])
+    assert stats.bbx_magnitude == bbx
+    P = oracle.default_params(oracle.BSC, oracle.NN if corr == "NN" else oracle.KM, 6, 0.6, 1.5, bbx, max_iter=80)
+    ro = oracle.register(P, ds["S"][kp["S"]].astype(np.float64), ds["T"][kp["T"]].astype(np.float64), FD)
+    Rg = np.array(stats.Rt[:]).reshape(4, 4)
+    assert stats.iterations == ro["iters"]
+    assert [t["cor"] for t in tr] == [t["cor"] for t in ro["trace"]]
+    assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
+
+
+def test_transform_cloud(ctx, oracle, tls):
+    Rt = tls.gt
+    og = ctx.transform_cloud(tls.source[:5000], Rt).cpu().numpy()
+    np.testing.assert_array_equal(og, oracle.transform_cloud(tls.source[:5000], Rt))
