@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- GH-ICP registration hot path on MI355X: registered pairs/sec (+ ms/iteration).
+
+Workload = BASELINE.json configs[1]: synthetic ETH-like TLS pair, 1 M points per scan, 0.1 m voxel,
+BSC feature + KM (Kuhn-Munkres) matching, 6-DoF.  A "step" = one complete pass of the hot path
+(voxel filter -> curvature keypoints -> BSC -> feature distance -> GH-ICP loop -> 4x4) over one pair
+whose raw clouds are already resident in HBM.  With N GPUs every rank registers its own pair
+(independent units, no data-path collective): weak scaling, value = pairs of all ranks / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the kernel's own stream)
+and `cpu_baseline` (the oracle = PCL-free restatement of the reference path, 1 thread, rank 0, N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(st, kernel):
+    """SURVEY.md §8(d) compulsory traffic of ONE launch of `kernel` for this pair (bytes)."""
+    ms, mt, ks, kt = st.m_s, st.m_t, st.k_s, st.k_t
+    n = max(ks, kt)
+    if kernel == "pca_cells":  # S1: 16 B in + 20 B out (lambda 12, curvature... f64 here: 8, count 4 = 24) per point, one launch per cloud
+        return 0.5 * (16 + 24) * (ms + mt)
+    if kernel == "bsc":  # S3: 16*M in + 56*V*K + 48*K out, per cloud (average of S: V=4, T: V=1)
+        return 0.5 * (16 * (ms + mt) + 56 * (4 * ks + kt) + 48 * (ks + kt))
+    if kernel == "km_solve":  # S5 KM: the n x n f64 weight matrix must be read at least once
+        return 8.0 * n * n
+    if kernel == "cd_rowmin":  # S5 sweep: keypoints + u16 FD in, row minima out
+        return 24.0 * (ks + kt) + 2.0 * ks * kt + 12.0 * ks
+    if kernel == "km_weights":
+        return 24.0 * (ks + kt) + 2.0 * ks * kt + 8.0 * n * n
+    if kernel == "fd_bsc":
+        return 56.0 * (4 * ks + kt) + 2.0 * ks * kt
+    return float("nan")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--hits", type=int, default=1_000_000, help="points per scan (cfg2 = 1M)")
+    ap.add_argument("--corr", default="KM", choices=["KM", "NN", "NNR"])
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU (oracle) baseline leg")
+    ap.add_argument("--check", type=int, default=1, help="compare the GPU 4x4 with the oracle's on rank 0 (N=1)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the GH-ICP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    api = importlib.import_module("gh-icp_amd.api")
+    synth = importlib.import_module("gh-icp_amd.synth")
+
+    # ---- synthetic cfg2 pair for this rank (pair_id = rank: independent scenes, weak scaling)
+    t0 = time.time()
+    pair = synth.tls_pair(args.hits, config_id=2, pair_id=rank)
+    gen_s = time.time() - t0
+    stream = torch.cuda.Stream()
+    ctx = api.Context(local_rank, stream=stream)
+    with torch.cuda.stream(stream):
+        xS = torch.from_numpy(pair.source).cuda()
+        xT = torch.from_numpy(pair.target).cuda()
+    corr = {"KM": api.CORR_KM, "NN": api.CORR_NN, "NNR": api.CORR_NNR}[args.corr]
+    cfg = api.pair_config(api.FEATURE_BSC, corr, 6, 0.6, 0.1, 0.5, 1.5, synth.bsc_pattern_glibc(), max_iter=200)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stats, _ = ctx.register_pair(cfg, xS, xT, want_trace=False)
+    ctx.kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats, _ = ctx.register_pair(cfg, xS, xT, want_trace=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ktimes = {k: ctx.kernel_time(k) for k in ("pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort")}
+    ctx.kernel_timing(False)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    pairs_total = args.steps * world
+    value = pairs_total / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    Rg = np.array(stats.Rt[:]).reshape(4, 4)
+    iters = max(1, stats.iterations)
+
+    # ---- roofline of the dominant kernel (largest share of HIP-event kernel time over the timed region)
+    dom = max(ktimes, key=lambda k: ktimes[k][0])
+    dom_ms, dom_n = ktimes[dom]
+    avg_ms = dom_ms / max(1, dom_n)
+    b_alg = algorithmic_bytes(stats, dom)
+    achieved = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 5), "launches": dom_n, "alg_bytes_per_launch": int(b_alg),
+                "per_kernel": {k: {"ms_total": round(v[0], 3), "launches": v[1],
+                                   "GBps": round(algorithmic_bytes(stats, k) / (v[0] / max(1, v[1]) * 1e-3) / 1e9, 2) if v[0] > 0 and algorithmic_bytes(stats, k) == algorithmic_bytes(stats, k) else None}
+                               for k, v in ktimes.items()}}
+
+    # ---- CPU baseline: the oracle (faithful PCL-free restatement of the reference path), 1 thread
+    cpu = None
+    check = None
+    if world == 1 and args.cpu_baseline:
+        from oracle import oracle as O  # checker / baseline only
+
+        tc = time.perf_counter()
+        ds, kp, feat = {}, {}, {}
+        for name, cloud, dof in (("T", pair.target, 0), ("S", pair.source, 6)):
+            keep = O.voxel_filter(cloud, 0.1)
+            ds[name] = cloud[keep]
+            kp[name], _ = O.keypoints(ds[name], 0.5, 1.5)
+            feat[name], _, _ = O.bsc(ds[name], kp[name], 1.5, dof, synth.bsc_pattern_glibc())
+        FD = O.fd_bsc(feat["S"], feat["T"][0])
+        t_front = time.perf_counter() - tc
+        P = O.default_params(O.BSC, {"KM": O.KM, "NN": O.NN, "NNR": O.NNR}[args.corr], 6, 0.6, 1.5, O.bbx_magnitude(ds["S"]))
+        sample_iters = 200
+        if args.corr == "KM":  # bound the CPU leg: time the first iterations, extrapolate the rest at their mean
+            sample_iters = 12
+        P.max_iter = sample_iters
+        tl = time.perf_counter()
+        ro = O.register(P, ds["S"][kp["S"]].astype(np.float64), ds["T"][kp["T"]].astype(np.float64), FD)
+        t_loop = time.perf_counter() - tl
+        done = ro["iters"]
+        total_iters = stats.iterations if done >= sample_iters else done
+        t_pair = t_front + t_loop * (total_iters / max(1, done))
+        cpu = {"value": round(1.0 / t_pair, 5), "unit": "pairs/s", "cores": 1, "kind": "port",
+               "sample": "same cfg2 pair: full front end + FD (%.1f s) + first %d of %d loop iterations (%.1f s), remaining iterations "
+                         "extrapolated at their mean; oracle = PCL-free restatement of the reference path, g++ -O2, 1 thread, host %s x%d"
+                         % (t_front, done, total_iters, t_loop, os.uname().machine, os.cpu_count())}
+        if args.check and done >= 1:
+            # parity on the sampled prefix: same keypoint counts; first iterations' correspondence counts
+            check = {"k_s_match": int(stats.k_s) == int(kp["S"].size), "k_t_match": int(stats.k_t) == int(kp["T"].size),
+                     "m_match": (int(stats.m_s), int(stats.m_t)) == (ds["S"].shape[0], ds["T"].shape[0])}
+
+    out = {
+        "metric": "registered_pairs_per_sec", "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cfg2: synthetic ETH-like TLS pair, %d pts/scan, voxel 0.1 m, r_pca 0.5, R_nms 1.5, BSC + %s, 6-DoF, 1 pair per GPU per step" % (args.hits, args.corr),
+                   "n_s": int(stats.n_s), "m_s": int(stats.m_s), "m_t": int(stats.m_t), "k_s": int(stats.k_s), "k_t": int(stats.k_t),
+                   "iterations": int(stats.iterations), "parallelism": "pairs sharded 1/rank, no data-path collective"},
+        "ms_per_iteration": round(stats.ms_loop / iters, 4),
+        "stage_ms": {"voxel": round(stats.ms_voxel, 3), "keypoints": round(stats.ms_keypoints, 3), "feature": round(stats.ms_feature, 3),
+                     "fd": round(stats.ms_fd, 3), "loop": round(stats.ms_loop, 3), "total": round(stats.ms_total, 3)},
+        "gt_error": {"rot": round(synth.rot_err(Rg, pair.gt), 6), "trans_m": round(synth.trans_err(Rg, pair.gt), 5)},
+        "roofline": roofline, "cpu_baseline": cpu, "parity_check": check, "gen_seconds": round(gen_s, 1),
+    }
+    if cpu:
+        out["speedup_vs_cpu_1thread"] = round(value / cpu["value"], 2)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

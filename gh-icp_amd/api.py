@@ -45,7 +45,7 @@ class PairStats(C.Structure):
 
 EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers",
-    "ghicp_ctx_synchronize", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
+    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
@@ -126,6 +126,15 @@ class Context:
 
     def sync(self):
         self._check(self.lib.ghicp_ctx_synchronize(self.h))
+
+    def kernel_timing(self, on=True):
+        self._check(self.lib.ghicp_ctx_kernel_timing(self.h, 1 if on else 0))
+
+    def kernel_time(self, name):
+        """(total_ms, launches) of a named kernel since kernel_timing(True)."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._check(self.lib.ghicp_ctx_kernel_time(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def _dev(self, a, dtype):
         t = self.torch

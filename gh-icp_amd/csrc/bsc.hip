@@ -284,7 +284,9 @@ int gh_bsc_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, const 
   GH_HIP(hipMemsetAsync(feat, 0, (size_t)4 * K * 56, s));
   hipLaunchKernelGGL(k_bsc_origins, dim3(cdiv(K, 256)), dim3(256), 0, s, xyz, stride, kp, (int)K, lcs);
   GridArgs A = {G.d, G.pts, G.start};
+  hipEvent_t kt = ctx->kt_begin(KT_BSC);
   hipLaunchKernelGGL(k_bsc, dim3((unsigned)K), dim3(BT), 0, s, A, kp, C, feat, lcs);
+  ctx->kt_end(KT_BSC, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
 }

@@ -65,7 +65,45 @@ enum BufSlot {
   B_NUM
 };
 
+enum KtSlot { KT_PCA = 0, KT_BSC, KT_KM_SOLVE, KT_CD_ROWMIN, KT_KM_WEIGHTS, KT_FD_BSC, KT_NMS_ROUND, KT_VOXEL_SORT, KT_NUM };
+static const char* const kKtNames[KT_NUM] = {"pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort"};
+
 struct ghicp_ctx {
+  // optional per-kernel timing
+  bool kt_on = false;
+  double kt_ms[KT_NUM] = {0};
+  long long kt_count[KT_NUM] = {0};
+  struct KtPending { int slot; hipEvent_t a, b; };
+  std::vector<KtPending> kt_pending;
+  std::vector<hipEvent_t> kt_pool;
+  hipEvent_t kt_event() {
+    if (!kt_pool.empty()) { hipEvent_t e = kt_pool.back(); kt_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  hipEvent_t kt_begin(int slot) {
+    if (!kt_on) return nullptr;
+    hipEvent_t a = kt_event();
+    (void)hipEventRecord(a, stream);
+    (void)slot;
+    return a;
+  }
+  void kt_end(int slot, hipEvent_t a) {
+    if (!kt_on || !a) return;
+    hipEvent_t b = kt_event();
+    (void)hipEventRecord(b, stream);
+    kt_pending.push_back({slot, a, b});
+  }
+  void kt_collect() {  // stream must be idle
+    for (auto& p : kt_pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { kt_ms[p.slot] += ms; kt_count[p.slot]++; }
+      kt_pool.push_back(p.a);
+      kt_pool.push_back(p.b);
+    }
+    kt_pending.clear();
+  }
   int device = 0;
   hipStream_t stream = nullptr;
   bool host_ptrs = false;

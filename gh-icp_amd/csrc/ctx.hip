@@ -47,6 +47,8 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   if (!ctx) return GHICP_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  ctx->kt_collect();
+  for (hipEvent_t e : ctx->kt_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
@@ -67,6 +69,27 @@ extern "C" int ghicp_ctx_synchronize(ghicp_ctx* ctx) {
   if (!ctx) return GHICP_ERR_ARG;
   GH_HIP(hipStreamSynchronize(ctx->stream));
   return GHICP_OK;
+}
+extern "C" int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->kt_collect();
+  ctx->kt_on = on != 0;
+  for (int i = 0; i < KT_NUM; i++) { ctx->kt_ms[i] = 0; ctx->kt_count[i] = 0; }
+  return GHICP_OK;
+}
+extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(name != nullptr);
+  GH_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->kt_collect();
+  for (int i = 0; i < KT_NUM; i++)
+    if (strcmp(name, kKtNames[i]) == 0) {
+      if (total_ms) *total_ms = ctx->kt_ms[i];
+      if (launches) *launches = ctx->kt_count[i];
+      return GHICP_OK;
+    }
+  return ctx->fail(GHICP_ERR_ARG, "unknown kernel name '%s'", name);
 }
 extern "C" const char* ghicp_last_error(const ghicp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void k_fd_fpfh(const float* __restrict__ hS, i
 int gh_fd_bsc_dev(ghicp_ctx* ctx, const uint8_t* featS, int ks, int V, const uint8_t* featT, int kt, uint16_t* FD) {
   if (ks <= 0 || kt <= 0) return GHICP_OK;
   dim3 g(cdiv(kt, TJ), cdiv(ks, TI));
+  hipEvent_t kev = ctx->kt_begin(KT_FD_BSC);
   hipLaunchKernelGGL(k_fd_bsc, g, dim3(256), 0, ctx->stream, (const uint32_t*)featS, ks, V, (const uint32_t*)featT, kt, FD);
+  ctx->kt_end(KT_FD_BSC, kev);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
 }

@@ -161,7 +161,9 @@ int gh_voxel_filter_dev(ghicp_ctx* ctx, const float* xyz, long long n, int strid
   GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));
   char* tmp;
   GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
+  hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
   GH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));  // stable: lowest input index leads its voxel
+  ctx->kt_end(KT_VOXEL_SORT, kev);
   hipLaunchKernelGGL(k_voxel_flags, dim3(cdiv(n, 256)), dim3(256), 0, s, keys2, n, flags);
   hipLaunchKernelGGL(k_set_first, dim3(1), dim3(1), 0, s, keep);
   GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));

@@ -209,6 +209,7 @@ int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t*
   GH_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_km_rowmax, dim3(cdiv(n, 4)), dim3(256), 0, s, done_flag, w, n, lx);
   const size_t lds_limit = 160 * 1024 - 512;
+  hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
   if (hot <= lds_limit) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -219,6 +220,7 @@ int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t*
   } else {
     hipLaunchKernelGGL(k_km_solve<false>, dim3(1), dim3(KM_THREADS), 0, s, done_flag, w, n, eps, lx, match, scratch, status);
   }
+  ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
 }

@@ -448,7 +448,9 @@ int run_loop(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS_in, int ks
   while (!done && launched < p->max_iter) {
     for (int r = 0; r < poll_every && launched < p->max_iter; r++, launched++) {
       dim3 gA(cdiv(ks, ROWS), C.nchunk_b);
+      hipEvent_t kev = ctx->kt_begin(KT_CD_ROWMIN);
       hipLaunchKernelGGL((k_cd_rowmin<FT, true>), gA, dim3(ROWS), 0, s, st, kpS, ks, kpT, kt, FDt, C.chunk_b, C.scale, wfd, pminA, pidxA, psum);
+      ctx->kt_end(KT_CD_ROWMIN, kev);
       if (p->corr == GHICP_CORR_NNR) {
         dim3 gB(cdiv(kt, ROWS), C.nchunk_a);
         hipLaunchKernelGGL((k_cd_rowmin<FT, false>), gB, dim3(ROWS), 0, s, st, kpT, kt, kpS, ks, FD, C.chunk_a, C.scale, wfd, pminB, pidxB,
@@ -457,7 +459,9 @@ int run_loop(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS_in, int ks
       hipLaunchKernelGGL(k_penalty, dim3(1), dim3(256), 0, s, st, C, psum, nparts, wfd);
       if (p->corr == GHICP_CORR_KM) {
         dim3 gw(cdiv(C.n, 256), C.n);
+        hipEvent_t kw = ctx->kt_begin(KT_KM_WEIGHTS);
         hipLaunchKernelGGL(k_km_weights<FT>, gw, dim3(256), 0, s, st, C, kpS, kpT, FD, wfd, kmw);
+        ctx->kt_end(KT_KM_WEIGHTS, kw);
         GH_TRY(gh_km_solve_dev(ctx, kmw, C.n, C.km_eps, kmmatch, &st->done));
       }
       hipLaunchKernelGGL(k_solve<FT>, dim3(1), dim3(1024), 0, s, st, C, kpS, kpT, FD, pminA, pidxA, pidxB, pminB, kmw, kmmatch, SP, TP, SVs,

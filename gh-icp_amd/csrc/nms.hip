@@ -135,7 +135,9 @@ int gh_nms_dev(ghicp_ctx* ctx, const float* xyz, int stride, const double* curva
   for (int round = 0;; round++) {
     for (int r = 0; r < 4; r++) {
       GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
+      hipEvent_t kev = ctx->kt_begin(KT_NMS_ROUND);
       hipLaunchKernelGGL(k_nms_round, dim3(cdiv(c, 256)), dim3(256), 0, s, A, r2, state, misc + 1);
+      ctx->kt_end(KT_NMS_ROUND, kev);
     }
     GH_HIP(hipMemcpyAsync(hflag, misc + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));

@@ -152,7 +152,9 @@ int gh_pca_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float 
   GridArgs A = {G.d, G.pts, G.start};
   const float r2 = (float)((double)radius * (double)radius);  // pcl radiusSearch: static_cast<float>(radius*radius)
   const int blocks = ctx->num_cu * 20;
+  hipEvent_t kt = ctx->kt_begin(KT_PCA);
   hipLaunchKernelGGL(k_pca_cells, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, lambda, curvature, count);
+  ctx->kt_end(KT_PCA, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
 }

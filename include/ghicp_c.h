@@ -74,6 +74,11 @@ int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* hip_stream);
 int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on);
 int ghicp_ctx_synchronize(ghicp_ctx* ctx);
 const char* ghicp_last_error(const ghicp_ctx* ctx);
+/* Optional per-kernel timing (hipEvent brackets on the context's stream around the named kernels:
+ * "pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort").
+ * ghicp_ctx_kernel_time synchronises the stream; returns total ms and launch count since enabling. */
+int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on);
+int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches);
 const char* ghicp_version(void);
 void ghicp_params_default(ghicp_params* p);
 
