@@ -49,6 +49,7 @@ EXPORTS = [
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
+    "ghicp_register_pairs",
 ]
 
 _lib = None
@@ -295,6 +296,27 @@ class Context:
                 d["Rt"] = np.array(r.Rt[:]).reshape(4, 4)
                 tr.append(d)
         return stats, tr
+
+
+def _register_pairs(self, cfg, pairs):
+    """pairs: list of (xyzS, xyzT) device tensors (float32, same column count). Returns list[PairStats]."""
+    n = len(pairs)
+    if n == 0:
+        return []
+    xs = [self._xyz(a) for a, _ in pairs]
+    xt = [self._xyz(b) for _, b in pairs]
+    stride = xs[0].shape[1]
+    assert all(t.shape[1] == stride for t in xs + xt)
+    PS = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+    PT = (C.c_void_p * n)(*[t.data_ptr() for t in xt])
+    NS = (C.c_int64 * n)(*[t.shape[0] for t in xs])
+    NT = (C.c_int64 * n)(*[t.shape[0] for t in xt])
+    stats = (PairStats * n)()
+    self._check(self.lib.ghicp_register_pairs(self.h, C.byref(cfg), n, PS, NS, PT, NT, stride, stats))
+    return list(stats)
+
+
+Context.register_pairs = _register_pairs
 
 
 def pair_config(feature=FEATURE_BSC, corr=CORR_KM, dof=6, est_iou=0.6, voxel=0.1, neighborhood_radius=0.5, radius_nonmax=1.5,

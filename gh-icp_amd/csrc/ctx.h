@@ -109,6 +109,7 @@ struct ghicp_ctx {
   bool host_ptrs = false;
   std::string err;
   DevBuf buf[B_NUM];
+  std::vector<DevBuf> pairbuf;  // per-pair outputs of the front end (batched API): 3 per pair slot
   void* pinned = nullptr;  // small pinned host scratch
   size_t pinned_cap = 0;
   int num_cu = 256;
@@ -169,6 +170,23 @@ struct Stager {
 };
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+__host__ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+// one job of a batched GH-ICP loop (all pointers device memory except Rt16 / trace / n_iter / converged: host)
+struct gh_loop_job {
+  const ghicp_params* p;
+  const double* kpS;
+  int ks;
+  const double* kpT;
+  int kt;
+  const void* FD;
+  double* Rt16;
+  ghicp_iter* trace;
+  int32_t* n_iter;
+  int32_t* converged;
+  int32_t* matchlist;
+};
+int gh_register_batch_dev(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs);
 
 // ---- internal (device-pointer) entry points shared between translation units
 int gh_fd_bsc_dev(ghicp_ctx* ctx, const uint8_t* featS, int ks, int V, const uint8_t* featT, int kt, uint16_t* FD);

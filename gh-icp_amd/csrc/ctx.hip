@@ -50,6 +50,7 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   ctx->kt_collect();
   for (hipEvent_t e : ctx->kt_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
+  for (auto& b : ctx->pairbuf) b.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
   return GHICP_OK;

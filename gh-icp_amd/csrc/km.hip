@@ -15,6 +15,8 @@
 #include "ctx.h"
 #include "devmath.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int KM_THREADS = 1024;
@@ -225,6 +227,9 @@ int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t*
   return GHICP_OK;
 }
 
+bool gh_km2_fits(int n);
+int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, int* status_dev);
+
 extern "C" int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double eps, int32_t* match) {
   if (!ctx) return GHICP_ERR_ARG;
   GH_ARG(n >= 0 && n < 46000 && (n == 0 || (w != nullptr && match != nullptr)));
@@ -233,12 +238,20 @@ extern "C" int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double
   int32_t* dm;
   GH_TRY(sg.in(w, (size_t)n * n, &dw));
   GH_TRY(sg.out(match, (size_t)n, &dm));
-  GH_TRY(gh_km_solve_dev(ctx, dw, (int)n, eps, dm, nullptr));
+  const bool v2 = n > 0 && gh_km2_fits((int)n) && !getenv("GHICP_KM_DENSE");
+  if (v2) {
+    int* stv;
+    GH_TRY(ctx->reserve(B_P_MISC, 16, &stv));
+    GH_HIP(hipMemsetAsync(stv, 0, sizeof(int), ctx->stream));
+    GH_TRY(gh_km2_solve_dense(ctx, dw, (int)n, eps, dm, stv));
+  } else {
+    GH_TRY(gh_km_solve_dev(ctx, dw, (int)n, eps, dm, nullptr));
+  }
   GH_TRY(sg.finish());
   GH_HIP(hipStreamSynchronize(ctx->stream));
   if (n > 0) {
     int st = 0;
-    GH_HIP(hipMemcpy(&st, ctx->buf[B_KM_MISC].p, sizeof(int), hipMemcpyDeviceToHost));
+    GH_HIP(hipMemcpy(&st, v2 ? ctx->buf[B_P_MISC].p : ctx->buf[B_KM_MISC].p, sizeof(int), hipMemcpyDeviceToHost));
     if (st != 0) return ctx->fail(GHICP_ERR_INTERNAL, "km_solve: solver status %d (non-finite weights?)", st);
   }
   return GHICP_OK;

@@ -1,17 +1,38 @@
 // GH-ICP iteration loop on gfx950: replaces GHRegistration::ghicp_reg and its private helpers
 // (reference src/ghicp_reg.cpp:24-112, 114-139, 216-341, 343-460, 548-578, 605-927).
 //
-// Per iteration (no host round-trip; the host only polls `done` every few iterations):
-//   k_cd_rowmin      fused calED + calCD_* + row arg-min (+ column arg-min pass for NNR) + sum/sum^2
-//                    over K_S x K_T; no f64 ED/CD matrix is ever materialised           (S5, HBM-bound)
-//   k_penalty        CDmean/CDstd -> penalty (calCD_* tail)                               (scalar)
-//   [KM] k_km_weights + km_solve (km.hip)                                                 (S5 KM)
-//   k_solve          accept correspondences, RMSE/FDM/FDstd, float-Umeyama rigid solve, apply to all
-//                    source keypoints, RMSE-after, Euler convergence test, adjustweight, Rt product (S6)
+// The loop is BATCHED: every kernel takes an array of per-pair descriptors (LoopProb) and one launch
+// advances all pairs of the batch by one stage; a pair that has converged makes its blocks exit at once.
+// Independent scan pairs are the parallel axis of this problem -- the per-pair KM solve is a
+// dependency chain, so throughput comes from many pairs in flight, one wave each (km2.hip).
+//
+// Per iteration, for all pairs (no host round-trip; the host polls the `done` flags every 2nd iteration):
+//   k_cd_rowmin      fused calED + calCD_* + row arg-min (+ column arg-min sweep for NNR) + sum / sum^2 over
+//                    K_S x K_T; no f64 ED/CD matrix is ever materialised                        (S5, HBM-bound)
+//   k_penalty        CDmean / CDstd -> penalty (calCD_* tails)                                    (scalar)
+//   [KM] k_km_csr x2 + scan + k_km2 (sparse exact Kuhn-Munkres, km2.hip)                          (S5 KM)
+//   k_solve          accept correspondences, RMSE/FDM/FDstd, float-Umeyama rigid solve, apply to all source
+//                    keypoints, RMSE-after, Euler convergence test, adjustweight, Rt product       (S6)
 #include "ctx.h"
 #include "devmath.h"
 
 #include <cmath>
+
+struct Km2Problem {
+  int n, pad_;
+  double bg, eps;
+  const unsigned* row_ptr;
+  const int* cols;
+  const double* vals;
+  const double* lx_init;
+  int* match_out;
+  int* status;
+  const int* done;
+  long long* steps;
+};
+int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
+bool gh_km2_fits(int n);
+int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, const int* done_flag);
 
 namespace {
 
@@ -22,26 +43,57 @@ struct LoopState {
 };
 
 struct LoopConst {
-  int ks, kt, n, feature, corr, max_iter, min_cor, nchunk_a, nchunk_b, chunk_a, chunk_b;
+  int ks, kt, n, feature, corr, max_iter, min_cor, nchunk_a, nchunk_b, chunk_a, chunk_b, nparts;
   float scale, est_iou, adjust_ratio, adjust_step;
   double converge_t, converge_r, penalty_initial, km_eps;
 };
 
-constexpr int ROWS = 256;      // threads per block in the sweep = rows handled per block
+// one registration job of the batch; every pointer is device memory
+struct LoopProb {
+  LoopConst C;
+  LoopState* st;
+  double* kpS;
+  const double* kpT;
+  const void* FD;   // [ks][kt]
+  const void* FDt;  // [kt][ks]
+  const double* wfd;
+  double *pminA, *pminB, *psum;
+  int *pidxA, *pidxB, *SP, *TP, *SVs, *TVs;
+  ghicp_iter* trace;
+  int* matchlist;
+  // KM
+  unsigned *km_cnt, *km_rptr;
+  int *km_cols, *kmmatch, *km_status;
+  double *km_vals, *km_lx, *kmw;
+  Km2Problem* km_desc;
+};
+
+constexpr int ROWS = 256;       // threads per block in the sweep = rows handled per block
 constexpr int CHUNK_MAX = 512;  // columns staged in LDS per block
 
+template <int FT>
+__device__ inline double combined_distance(double ed, const void* fd, size_t idx, double wed, double wfd, double inv_k) {
+  if (FT == GHICP_FEATURE_BSC) return wed * ed + wfd * (double)reinterpret_cast<const uint16_t*>(fd)[idx];     // ghicp_reg.cpp:259
+  if (FT == GHICP_FEATURE_FPFH) return 1.0 * ed / pow((double)reinterpret_cast<const float*>(fd)[idx], inv_k);  // ghicp_reg.cpp:308
+  return ed;                                                                                                     // ghicp_reg.cpp:224
+}
+
 // One sweep: thread = "row" a (keypoint of set A), loop over a chunk of set B staged in LDS.
-// FDt is [kb][ka] so that lanes (consecutive a) read consecutive addresses.
+// The feature matrix is read as [b][a] so that lanes (consecutive a) touch consecutive addresses.
 // Row arg-min semantics = ghicp_reg.cpp:715-724 / 622-650: start (9e20, 0), strict '<', ascending index.
-template <int FT, bool SUMS>
-__global__ __launch_bounds__(ROWS) void k_cd_rowmin(const LoopState* __restrict__ st, const double* __restrict__ A, int ka,
-                                                     const double* __restrict__ B, int kb, const void* __restrict__ FDt, int chunk,
-                                                     float scale, const double* __restrict__ wfd_tab, double* __restrict__ part_min,
-                                                     int* __restrict__ part_idx, double* __restrict__ part_sum) {
-  if (st->done) return;
+template <int FT, bool COLS>
+__global__ __launch_bounds__(ROWS) void k_cd_rowmin(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.z];
+  if (P.st->done) return;
+  const int ka = COLS ? P.C.kt : P.C.ks, kb = COLS ? P.C.ks : P.C.kt;
+  const int chunk = COLS ? P.C.chunk_a : P.C.chunk_b, nchunk = COLS ? P.C.nchunk_a : P.C.nchunk_b;
+  if ((int)blockIdx.y >= nchunk || (int)blockIdx.x * ROWS >= ka) return;
+  const double* __restrict__ A = COLS ? P.kpT : P.kpS;
+  const double* __restrict__ B = COLS ? P.kpS : P.kpT;
+  const void* __restrict__ F = COLS ? P.FD : P.FDt;
   __shared__ double sB[CHUNK_MAX * 3];
   __shared__ double red[16];
-  const int it = st->it;
+  const int it = P.st->it;
   const int jb = blockIdx.y * chunk;
   const int je = min(kb, jb + chunk);
   for (int t = threadIdx.x; t < (je - jb) * 3; t += ROWS) sB[t] = B[(size_t)jb * 3 + t];
@@ -50,50 +102,43 @@ __global__ __launch_bounds__(ROWS) void k_cd_rowmin(const LoopState* __restrict_
   const bool live = a < ka;
   double ax = 0, ay = 0, az = 0;
   if (live) { ax = A[(size_t)a * 3]; ay = A[(size_t)a * 3 + 1]; az = A[(size_t)a * 3 + 2]; }
-  double wfd = 0, wed = 1, inv_k = 1;
-  if (FT == GHICP_FEATURE_BSC) { wfd = wfd_tab[it]; wed = 1.0 - wfd; }
-  if (FT == GHICP_FEATURE_FPFH) inv_k = 1.0 / (double)(it + 1);
-  const double dscale = (double)scale;
+  double wfd = 0, wed = 1;
+  if (FT == GHICP_FEATURE_BSC) { wfd = P.wfd[it]; wed = 1.0 - wfd; }
+  const double inv_k = 1.0 / (double)(it + 1);
+  const double dscale = (double)P.C.scale;
   double best = 9e20, s = 0, s2 = 0;
   int bidx = 0;
   if (live) {
     for (int j = jb; j < je; j++) {
       const double dx = ax - sB[(j - jb) * 3], dy = ay - sB[(j - jb) * 3 + 1], dz = az - sB[(j - jb) * 3 + 2];
-      const double ed = dscale * sqrt(dx * dx + dy * dy + dz * dz);
-      double cd;
-      if (FT == GHICP_FEATURE_BSC) {
-        const double fd = (double)reinterpret_cast<const uint16_t*>(FDt)[(size_t)j * ka + a];
-        cd = wed * ed + wfd * fd;  // ghicp_reg.cpp:259
-      } else if (FT == GHICP_FEATURE_FPFH) {
-        const double fd = (double)reinterpret_cast<const float*>(FDt)[(size_t)j * ka + a];
-        cd = 1.0 * ed / pow(fd, inv_k);  // ghicp_reg.cpp:308
-      } else {
-        cd = ed;  // ghicp_reg.cpp:224
-      }
+      const double ed = dscale * sqrt(dx * dx + dy * dy + dz * dz);  // ghicp_reg.cpp:122
+      const double cd = combined_distance<FT>(ed, F, (size_t)j * ka + a, wed, wfd, inv_k);
       if (cd < best) { best = cd; bidx = j; }
-      if (SUMS) { s += cd; s2 += cd * cd; }
+      if (!COLS) { s += cd; s2 += cd * cd; }
     }
-    part_min[(size_t)blockIdx.y * ka + a] = best;
-    part_idx[(size_t)blockIdx.y * ka + a] = bidx;
+    (COLS ? P.pminB : P.pminA)[(size_t)blockIdx.y * ka + a] = best;
+    (COLS ? P.pidxB : P.pidxA)[(size_t)blockIdx.y * ka + a] = bidx;
   }
-  if (SUMS) {
+  if (!COLS) {
     const double bs = gh_block_sum(s, red);
     const double bs2 = gh_block_sum(s2, red);
     if (threadIdx.x == 0) {
-      const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-      part_sum[b * 2] = bs;
-      part_sum[b * 2 + 1] = bs2;
+      const size_t b = (size_t)blockIdx.y * cdiv_dev(ka, ROWS) + blockIdx.x;
+      P.psum[b * 2] = bs;
+      P.psum[b * 2 + 1] = bs2;
     }
   }
 }
 
 // calCD_* tails: CDmean, CDstd, penalty (ghicp_reg.cpp:228-239, 264-287, 317-335)
-__global__ __launch_bounds__(256) void k_penalty(LoopState* st, LoopConst C, const double* __restrict__ part_sum, int nparts,
-                                                 const double* __restrict__ wfd_tab) {
+__global__ __launch_bounds__(256) void k_penalty(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.x];
+  LoopState* st = P.st;
   if (st->done) return;
+  const LoopConst& C = P.C;
   __shared__ double red[16];
   double s = 0, s2 = 0;
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) { s += part_sum[i * 2]; s2 += part_sum[i * 2 + 1]; }
+  for (int i = threadIdx.x; i < C.nparts; i += blockDim.x) { s += P.psum[i * 2]; s2 += P.psum[i * 2 + 1]; }
   s = gh_block_sum(s, red);
   s2 = gh_block_sum(s2, red);
   if (threadIdx.x == 0) {
@@ -108,7 +153,7 @@ __global__ __launch_bounds__(256) void k_penalty(LoopState* st, LoopConst C, con
       pen = fmax(mean, 1.0);  // Q6: line 239 overrides 230-237
       st->CDstd = 0;
     } else if (C.feature == GHICP_FEATURE_BSC) {
-      const double wfd = wfd_tab[it], wed = 1.0 - wfd;
+      const double wfd = P.wfd[it], wed = 1.0 - wfd;
       if (it > 1) pen = st->RMS * st->para1 * (double)C.scale * wed + (st->FDM + st->para2 * st->FDstd) * wfd;
       else pen = mean - C.penalty_initial * sd;
       pen = fmax(pen, 5.0);
@@ -123,53 +168,123 @@ __global__ __launch_bounds__(256) void k_penalty(LoopState* st, LoopConst C, con
   }
 }
 
-// KM weights (ghicp_reg.cpp:348-365): w[i][j] = -CD if CD < penalty else -penalty, padded to n x n.
+// Dense KM weights for the large-n fallback (ghicp_reg.cpp:348-365).
 template <int FT>
-__global__ __launch_bounds__(256) void k_km_weights(const LoopState* __restrict__ st, LoopConst C, const double* __restrict__ kpS,
-                                                    const double* __restrict__ kpT, const void* __restrict__ FD,
-                                                    const double* __restrict__ wfd_tab, double* __restrict__ w) {
-  if (st->done) return;
+__global__ __launch_bounds__(256) void k_km_weights(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.z];
+  if (P.st->done || P.kmw == nullptr) return;
+  const LoopConst& C = P.C;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i = blockIdx.y;
-  if (j >= C.n) return;
-  const double pen = st->penalty;
+  if (j >= C.n || i >= C.n) return;
+  const double pen = P.st->penalty;
   double out = -pen;
   if (i < C.ks && j < C.kt) {
-    const int it = st->it;
-    const double dx = kpS[(size_t)i * 3] - kpT[(size_t)j * 3], dy = kpS[(size_t)i * 3 + 1] - kpT[(size_t)j * 3 + 1],
-                 dz = kpS[(size_t)i * 3 + 2] - kpT[(size_t)j * 3 + 2];
+    const int it = P.st->it;
+    const double dx = P.kpS[(size_t)i * 3] - P.kpT[(size_t)j * 3], dy = P.kpS[(size_t)i * 3 + 1] - P.kpT[(size_t)j * 3 + 1],
+                 dz = P.kpS[(size_t)i * 3 + 2] - P.kpT[(size_t)j * 3 + 2];
     const double ed = (double)C.scale * sqrt(dx * dx + dy * dy + dz * dz);
-    double cd;
-    if (FT == GHICP_FEATURE_BSC) {
-      const double wfd = wfd_tab[it], wed = 1.0 - wfd;
-      cd = wed * ed + wfd * (double)reinterpret_cast<const uint16_t*>(FD)[(size_t)i * C.kt + j];
-    } else if (FT == GHICP_FEATURE_FPFH) {
-      cd = 1.0 * ed / pow((double)reinterpret_cast<const float*>(FD)[(size_t)i * C.kt + j], 1.0 / (double)(it + 1));
-    } else {
-      cd = ed;
-    }
+    double wfd = 0, wed = 1;
+    if (FT == GHICP_FEATURE_BSC) { wfd = P.wfd[it]; wed = 1.0 - wfd; }
+    const double cd = combined_distance<FT>(ed, P.FD, (size_t)i * C.kt + j, wed, wfd, 1.0 / (double)(it + 1));
     if (cd < pen) out = -cd;
   }
-  w[(size_t)i * C.n + j] = out;
+  P.kmw[(size_t)i * C.n + j] = out;
 }
 
-// Everything after the sweep, one 1024-thread workgroup.
+// Sparse KM input (km2.hip): per row the explicit entries (j, -CD) with CD < penalty (ghicp_reg.cpp:358-365);
+// every other entry of the n x n graph is the background -penalty.  One wave per row, two passes (count, fill).
+template <int FT, int FILL>
+__global__ __launch_bounds__(256) void k_km_csr(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.y];
+  if (P.st->done || P.km_rptr == nullptr) return;
+  const LoopConst& C = P.C;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= C.n) return;
+  const double pen = P.st->penalty;
+  if (i >= C.ks) {  // padding rows: all background
+    if (!FILL && lane == 0) { P.km_cnt[i] = 0u; P.km_lx[i] = -pen; }
+    return;
+  }
+  const int it = P.st->it;
+  double wfd = 0, wed = 1;
+  if (FT == GHICP_FEATURE_BSC) { wfd = P.wfd[it]; wed = 1.0 - wfd; }
+  const double inv_k = 1.0 / (double)(it + 1);
+  const double sx = P.kpS[(size_t)i * 3], sy = P.kpS[(size_t)i * 3 + 1], sz = P.kpS[(size_t)i * 3 + 2];
+  const unsigned base = FILL ? P.km_rptr[i] : 0u;
+  unsigned c = 0;
+  double mx = -pen;  // km.cpp:56-62 row maximum; every explicit entry is > -penalty
+  for (int j0 = 0; j0 < C.kt; j0 += 64) {
+    const int j = j0 + lane;
+    bool e = false;
+    double wv = 0;
+    if (j < C.kt) {
+      const double dx = sx - P.kpT[(size_t)j * 3], dy = sy - P.kpT[(size_t)j * 3 + 1], dz = sz - P.kpT[(size_t)j * 3 + 2];
+      const double ed = (double)C.scale * sqrt(dx * dx + dy * dy + dz * dz);
+      const double cd = combined_distance<FT>(ed, P.FD, (size_t)i * C.kt + j, wed, wfd, inv_k);
+      e = cd < pen;
+      wv = -cd;
+    }
+    const unsigned long long b = __ballot(e);
+    if (FILL && e) {
+      const unsigned off = c + __popcll(b & ((1ull << lane) - 1ull));
+      P.km_cols[base + off] = j;
+      P.km_vals[base + off] = wv;
+    }
+    if (!FILL && e) mx = fmax(mx, wv);
+    c += __popcll(b);
+  }
+  if (!FILL) {
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) { P.km_cnt[i] = c; P.km_lx[i] = mx; }
+  }
+}
+
+// exclusive scan of the row counts (one block per pair) + the km2 problem descriptor
+__global__ __launch_bounds__(1024) void k_km_scan_desc(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.x];
+  if (P.st->done || P.km_rptr == nullptr) return;
+  __shared__ int sc[17];
+  const int n = P.C.n;
+  int carry = 0;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? (int)P.km_cnt[i] : 0;
+    int tot;
+    const int ex = gh_block_excl_scan(v, sc, &tot);
+    if (i < n) P.km_rptr[i] = (unsigned)(carry + ex);
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    P.km_rptr[n] = (unsigned)carry;
+    Km2Problem p;
+    p.n = n; p.pad_ = 0; p.bg = -P.st->penalty; p.eps = P.C.km_eps; p.row_ptr = P.km_rptr; p.cols = P.km_cols; p.vals = P.km_vals;
+    p.lx_init = P.km_lx; p.match_out = P.kmmatch; p.status = P.km_status; p.done = &P.st->done; p.steps = nullptr;
+    *P.km_desc = p;
+  }
+}
+
+// Everything after the sweep, one 1024-thread workgroup per pair.
 template <int FT>
-__global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, double* __restrict__ kpS, const double* __restrict__ kpT,
-                                                const void* __restrict__ FD, const double* __restrict__ pminA,
-                                                const int* __restrict__ pidxA, const int* __restrict__ pidxB,
-                                                const double* __restrict__ pminB, const double* __restrict__ kmw,
-                                                const int* __restrict__ kmmatch, int* __restrict__ SP, int* __restrict__ TP,
-                                                int* __restrict__ SVs, int* __restrict__ TVs, ghicp_iter* __restrict__ trace,
-                                                int* __restrict__ matchlist) {
+__global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.x];
+  LoopState* st = P.st;
   if (st->done) return;
+  const LoopConst& C = P.C;
+  double* __restrict__ kpS = P.kpS;
+  const double* __restrict__ kpT = P.kpT;
+  const void* __restrict__ FD = P.FD;
+  int* __restrict__ SP = P.SP;
+  int* __restrict__ TP = P.TP;
   __shared__ double red[16];
   __shared__ int ired[17];
   __shared__ double sh[32];
-  __shared__ int s_cor;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int it = st->it;
   const double penalty = st->penalty;
+  int* matchlist = P.matchlist;
   if (matchlist)
     for (int i = tid; i < C.ks; i += nt) matchlist[(size_t)it * C.ks + i] = -1;
 
@@ -177,19 +292,30 @@ __global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, doub
   int cor = 0;
   if (C.corr == GHICP_CORR_KM) {
     // Km::output (km.cpp:157-171): ascending y, kept iff w[match[y]][y] != -penalty (exact compare)
+    double e = 0;
     for (int base = 0; base < C.n; base += nt) {
       const int y = base + tid;
       int flag = 0, x = -1;
-      if (y < C.n) { x = kmmatch[y]; flag = (kmw[(size_t)x * C.n + y] != -penalty) ? 1 : 0; }
+      if (y < C.n) {
+        x = P.kmmatch[y];
+        double g = -penalty;
+        if (P.km_rptr) {  // sparse graph: (x,y) carries a weight != -penalty iff it is an explicit entry
+          unsigned lo = P.km_rptr[x], hi = P.km_rptr[x + 1];
+          const unsigned end = hi;
+          while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (P.km_cols[mid] < y) lo = mid + 1; else hi = mid; }
+          if (lo < end && P.km_cols[lo] == y) g = P.km_vals[lo];
+        } else {
+          g = P.kmw[(size_t)x * C.n + y];
+        }
+        flag = (g != -penalty) ? 1 : 0;
+        if (g != -10000.0) e -= g;  // Calenergy (km.cpp:128-141): INF = 10000 never matches
+      }
       int tot;
       const int pos = gh_block_excl_scan(flag, ired, &tot);
       if (flag) { SP[cor + pos] = x; TP[cor + pos] = y; }
       cor += tot;
       __syncthreads();
     }
-    // Calenergy (km.cpp:128-141): INF = 10000 never matches, so energy = -sum of matched weights
-    double e = 0;
-    for (int y = tid; y < C.n; y += nt) { const double g = kmw[(size_t)kmmatch[y] * C.n + y]; if (g != -10000.0) e -= g; }
     e = gh_block_sum(e, red);
     if (tid == 0) st->energy = e;
   } else {
@@ -197,20 +323,20 @@ __global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, doub
     for (int i = tid; i < C.ks; i += nt) {
       double best = 9e20; int bi = 0;
       for (int c = 0; c < C.nchunk_b; c++) {
-        const double v = pminA[(size_t)c * C.ks + i];
-        if (v < best) { best = v; bi = pidxA[(size_t)c * C.ks + i]; }
+        const double v = P.pminA[(size_t)c * C.ks + i];
+        if (v < best) { best = v; bi = P.pidxA[(size_t)c * C.ks + i]; }
       }
-      SVs[i] = bi;
-      TVs[C.kt + i] = (best < penalty) ? 1 : 0;  // NN acceptance flag (ghicp_reg.cpp:725)
+      P.SVs[i] = bi;
+      P.TVs[C.kt + i] = (best < penalty) ? 1 : 0;  // NN acceptance flag (ghicp_reg.cpp:725)
     }
     if (C.corr == GHICP_CORR_NNR) {
       for (int j = tid; j < C.kt; j += nt) {
         double best = 9e20; int bi = 0;
         for (int c = 0; c < C.nchunk_a; c++) {
-          const double v = pminB[(size_t)c * C.kt + j];
-          if (v < best) { best = v; bi = pidxB[(size_t)c * C.kt + j]; }
+          const double v = P.pminB[(size_t)c * C.kt + j];
+          if (v < best) { best = v; bi = P.pidxB[(size_t)c * C.kt + j]; }
         }
-        TVs[j] = bi;
+        P.TVs[j] = bi;
       }
     }
     __syncthreads();
@@ -218,9 +344,9 @@ __global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, doub
       const int i = base + tid;
       int flag = 0, sv = 0;
       if (i < C.ks) {
-        sv = SVs[i];
-        if (C.corr == GHICP_CORR_NN) flag = TVs[C.kt + i];
-        else flag = (C.kt > 0 && TVs[sv] == i) ? 1 : 0;  // Q7: reciprocal test only (ghicp_reg.cpp:654)
+        sv = P.SVs[i];
+        if (C.corr == GHICP_CORR_NN) flag = P.TVs[C.kt + i];
+        else flag = (C.kt > 0 && P.TVs[sv] == i) ? 1 : 0;  // Q7: reciprocal test only (ghicp_reg.cpp:654)
       }
       int tot;
       const int pos = gh_block_excl_scan(flag, ired, &tot);
@@ -259,7 +385,7 @@ __global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, doub
   const double FDstd = sqrt(fc / (double)cor);
   const double RMSE = sqrt(rm / (double)cor);
 
-  // ---- float Umeyama (ghicp_reg.cpp:839-866): inputs cast to f32, means/cross-covariance in f64 rounded to f32
+  // ---- float Umeyama (ghicp_reg.cpp:839-866): inputs cast to f32, means/cross-covariance in f64, matrix rounded once (N2)
   double m[6] = {0, 0, 0, 0, 0, 0};
   for (int c = tid; c < cor; c += nt) {
     const int i = SP[c], j = TP[c];
@@ -294,7 +420,6 @@ __global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, doub
       for (int q = 0; q < 3; q++) sh[r * 4 + q] = (double)Rf[r * 3 + q];
       sh[r * 4 + 3] = (double)tf[r];
     }
-    s_cor = cor;
   }
   __syncthreads();
   double Rt[12];
@@ -352,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_solve(LoopState* st, LoopConst C, doub
     rec.fdm = FDM; rec.fdstd = FDstd; rec.iou = IoU; rec.para1 = p1; rec.para2 = p2;
     rec.energy = (C.corr == GHICP_CORR_KM) ? st->energy : 0.0;
     for (int d = 0; d < 16; d++) rec.Rt[d] = Rt16[d];
-    trace[it] = rec;
+    P.trace[it] = rec;
     st->RMS = RMSE; st->FDM = FDM; st->FDstd = FDstd; st->IoU = IoU; st->para1 = p1; st->para2 = p2; st->cor = cor;
     st->it = it + 1;
     if (conv || it + 1 >= C.max_iter) { st->done = 1; st->converged_flag = conv ? 1 : 0; }
@@ -370,144 +495,225 @@ template <typename T> __global__ void k_transpose(const T* __restrict__ in, int 
     if (ox < rows && oy0 + r < cols) out[(size_t)(oy0 + r) * rows + ox] = tile[threadIdx.x][r];
 }
 
-static void pick_chunks(int ka, int kb, int* chunk, int* nchunk) {
-  // aim for >= ~2048 workgroups (256 CUs x 8) with chunks of at least 32 columns
-  const int rowblocks = cdiv(ka, ROWS);
+__global__ void k_collect_done(const LoopProb* __restrict__ probs, int n, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { out[i * 2] = probs[i].st->it; out[i * 2 + 1] = probs[i].st->done; }
+}
+
+static void pick_chunks(int ka, int kb, int batch, int* chunk, int* nchunk) {
+  // aim for >= ~2048 workgroups per launch (256 CUs x 8) with chunks of at least 32 columns
+  const int rowblocks = cdiv(ka > 0 ? ka : 1, ROWS) * (batch > 0 ? batch : 1);
   int want = cdiv(2048, rowblocks);
-  int ch = cdiv(kb, want);
+  int ch = cdiv(kb > 0 ? kb : 1, want);
   if (ch < 32) ch = 32;
   if (ch > CHUNK_MAX) ch = CHUNK_MAX;
-  if (kb <= 0) ch = 32;
   *chunk = ch;
   *nchunk = kb > 0 ? cdiv(kb, ch) : 1;
 }
 
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
 template <int FT>
-int run_loop(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS_in, int ks, const double* kpT, int kt, const void* FD, double* Rt16,
-             ghicp_iter* trace_host, int32_t* n_iter, int32_t* matchlist) {
+int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
   hipStream_t s = ctx->stream;
-  LoopConst C;
-  memset(&C, 0, sizeof(C));
-  C.ks = ks; C.kt = kt; C.n = ks > kt ? ks : kt; C.feature = p->feature; C.corr = p->corr; C.max_iter = p->max_iter; C.min_cor = p->min_cor;
-  C.scale = (float)(0.005 * p->bbx_magnitude);  // ghicp_reg.h:40 (double product stored to float)
-  C.est_iou = p->est_iou; C.adjust_ratio = p->adjust_ratio; C.adjust_step = p->adjust_step;
-  C.converge_t = (double)p->converge_t; C.converge_r = (double)p->converge_r; C.penalty_initial = p->penalty_initial; C.km_eps = p->km_eps;
-  pick_chunks(ks, kt, &C.chunk_b, &C.nchunk_b);
-  pick_chunks(kt, ks, &C.chunk_a, &C.nchunk_a);
+  const ghicp_params* p0 = jobs[0].p;
+  const int corr = p0->corr;
+  int max_iter = 1;
+  for (int b = 0; b < nb; b++) max_iter = jobs[b].p->max_iter > max_iter ? jobs[b].p->max_iter : max_iter;
+  // exp(-it/rate) from the host libm, exactly as calCD_BSC computes it (ghicp_reg.cpp:247); one table per batch
+  std::vector<double> wtab(max_iter + 1);
+  for (int i = 0; i <= max_iter; i++) wtab[i] = std::exp(-1.0 * i / p0->weight_changing_rate);
 
-  LoopState* st; double* kpS; double *pminA, *pminB, *psum, *wfd; int *pidxA, *pidxB, *SP, *TP, *SVs, *TVs; ghicp_iter* trace;
-  GH_TRY(ctx->reserve(B_LOOP_STATE, 1, &st));
-  GH_TRY(ctx->reserve(B_LOOP_KPS, (size_t)ks * 3 + 3, &kpS));
-  GH_TRY(ctx->reserve(B_LOOP_PARTMIN, (size_t)C.nchunk_b * ks + 1, &pminA));
-  GH_TRY(ctx->reserve(B_LOOP_PARTIDX, (size_t)C.nchunk_b * ks + 1, &pidxA));
-  GH_TRY(ctx->reserve(B_LOOP_PARTMIN2, (size_t)C.nchunk_a * kt + 1, &pminB));
-  GH_TRY(ctx->reserve(B_LOOP_PARTIDX2, (size_t)C.nchunk_a * kt + 1, &pidxB));
-  const int nparts = cdiv(ks, ROWS) * C.nchunk_b;
-  GH_TRY(ctx->reserve(B_LOOP_PARTSUM, (size_t)nparts * 2 + 2, &psum));
-  GH_TRY(ctx->reserve(B_LOOP_SP, (size_t)C.n + 1, &SP));
-  GH_TRY(ctx->reserve(B_LOOP_TP, (size_t)C.n + 1, &TP));
-  GH_TRY(ctx->reserve(B_LOOP_ACC, (size_t)ks + (size_t)kt + ks + 2, &SVs));
-  TVs = SVs + ks;  // TVs[0..kt) column arg-min, TVs[kt..kt+ks) NN acceptance flags
-  GH_TRY(ctx->reserve(B_LOOP_TRACE, (size_t)p->max_iter + 1, &trace));
-  GH_TRY(ctx->reserve(B_LOOP_WFD, (size_t)p->max_iter + 1, &wfd));
-
-  // exp(-it/rate) from the host libm, exactly as calCD_BSC computes it (ghicp_reg.cpp:247)
-  std::vector<double> wtab(p->max_iter + 1);
-  for (int i = 0; i <= p->max_iter; i++) wtab[i] = std::exp(-1.0 * i / p->weight_changing_rate);
-  GH_HIP(hipMemcpyAsync(wfd, wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  LoopState h;
-  memset(&h, 0, sizeof(h));
-  h.RMS = 99999; h.para1 = p->para1; h.para2 = p->para2;  // ghicp_reg.h:98, 33-34
-  for (int d = 0; d < 4; d++) h.Rt_till[d * 5] = 1.0;
-  GH_HIP(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, s));
-  GH_HIP(hipMemcpyAsync(kpS, kpS_in, (size_t)ks * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-
-  // FD transposed once so that the row sweep reads it coalesced; the original layout serves the column sweep
-  const void* FDt = nullptr;
-  if (FT != GHICP_FEATURE_NONE) {
-    const size_t esz = (FT == GHICP_FEATURE_BSC) ? 2 : 4;
-    char* t;
-    GH_TRY(ctx->reserve(B_LOOP_FDT, (size_t)ks * kt * esz + 16, &t));
-    dim3 g(cdiv(kt, 32), cdiv(ks, 32)), b(32, 8);
-    if (ks > 0 && kt > 0) {
-      if (FT == GHICP_FEATURE_BSC) hipLaunchKernelGGL(k_transpose<uint16_t>, g, b, 0, s, (const uint16_t*)FD, ks, kt, (uint16_t*)t);
-      else hipLaunchKernelGGL(k_transpose<float>, g, b, 0, s, (const float*)FD, ks, kt, (float*)t);
-    }
-    FDt = t;
-  }
-  double* kmw = nullptr; int* kmmatch = nullptr;
-  if (p->corr == GHICP_CORR_KM) {
-    GH_TRY(ctx->reserve(B_LOOP_KMW, (size_t)C.n * C.n + 1, &kmw));
-    GH_TRY(ctx->reserve(B_LOOP_KMMATCH, (size_t)C.n + 1, &kmmatch));
-  }
-
-  int* hflag = reinterpret_cast<int*>(ctx->pinned);
-  const int poll_every = (p->corr == GHICP_CORR_KM) ? 1 : 4;
-  int launched = 0;
-  bool done = (ks <= 0 || kt <= 0);
-  while (!done && launched < p->max_iter) {
-    for (int r = 0; r < poll_every && launched < p->max_iter; r++, launched++) {
-      dim3 gA(cdiv(ks, ROWS), C.nchunk_b);
-      hipEvent_t kev = ctx->kt_begin(KT_CD_ROWMIN);
-      hipLaunchKernelGGL((k_cd_rowmin<FT, true>), gA, dim3(ROWS), 0, s, st, kpS, ks, kpT, kt, FDt, C.chunk_b, C.scale, wfd, pminA, pidxA, psum);
-      ctx->kt_end(KT_CD_ROWMIN, kev);
-      if (p->corr == GHICP_CORR_NNR) {
-        dim3 gB(cdiv(kt, ROWS), C.nchunk_a);
-        hipLaunchKernelGGL((k_cd_rowmin<FT, false>), gB, dim3(ROWS), 0, s, st, kpT, kt, kpS, ks, FD, C.chunk_a, C.scale, wfd, pminB, pidxB,
-                           (double*)nullptr);
+  // ---- size pass, then carve every pair's buffers out of one allocation
+  std::vector<LoopProb> hp(nb);
+  std::vector<LoopState> hst(nb);
+  size_t total = 0;
+  int max_rowsA = 1, max_chunkB = 1, max_rowsB = 1, max_chunkA = 1, max_n = 1;
+  for (int pass = 0; pass < 2; pass++) {
+    char* arena = nullptr;
+    if (pass == 1) GH_TRY(ctx->reserve(B_LOOP_STATE, total + 4096, &arena));
+    Carver cv(arena);
+    const double* wfd = cv.take<double>(wtab.size());
+    LoopProb* dprobs = cv.take<LoopProb>(nb);
+    int* dflags = cv.take<int>((size_t)nb * 2);
+    Km2Problem* d_descs = cv.take<Km2Problem>(nb);  // contiguous: one k_km2 launch solves every pair's matching concurrently
+    for (int b = 0; b < nb; b++) {
+      const gh_loop_job& J = jobs[b];
+      const ghicp_params* p = J.p;
+      LoopProb& L = hp[b];
+      memset(&L, 0, sizeof(L));
+      LoopConst& C = L.C;
+      const int ks = J.ks, kt = J.kt;
+      C.ks = ks; C.kt = kt; C.n = ks > kt ? ks : kt; C.feature = p->feature; C.corr = p->corr; C.max_iter = p->max_iter; C.min_cor = p->min_cor;
+      C.scale = (float)(0.005 * p->bbx_magnitude);  // ghicp_reg.h:40 (double product stored to float)
+      C.est_iou = p->est_iou; C.adjust_ratio = p->adjust_ratio; C.adjust_step = p->adjust_step;
+      C.converge_t = (double)p->converge_t; C.converge_r = (double)p->converge_r; C.penalty_initial = p->penalty_initial; C.km_eps = p->km_eps;
+      pick_chunks(ks, kt, nb, &C.chunk_b, &C.nchunk_b);
+      pick_chunks(kt, ks, nb, &C.chunk_a, &C.nchunk_a);
+      C.nparts = cdiv(ks > 0 ? ks : 1, ROWS) * C.nchunk_b;
+      max_rowsA = std::max(max_rowsA, cdiv(ks > 0 ? ks : 1, ROWS)); max_chunkB = std::max(max_chunkB, C.nchunk_b);
+      max_rowsB = std::max(max_rowsB, cdiv(kt > 0 ? kt : 1, ROWS)); max_chunkA = std::max(max_chunkA, C.nchunk_a);
+      max_n = std::max(max_n, C.n);
+      L.wfd = wfd;
+      L.st = cv.take<LoopState>(1);
+      L.kpS = cv.take<double>((size_t)ks * 3 + 3);
+      L.kpT = J.kpT; L.FD = J.FD;
+      L.pminA = cv.take<double>((size_t)C.nchunk_b * ks + 1);
+      L.pidxA = cv.take<int>((size_t)C.nchunk_b * ks + 1);
+      L.psum = cv.take<double>((size_t)C.nparts * 2 + 2);
+      if (corr == GHICP_CORR_NNR) {
+        L.pminB = cv.take<double>((size_t)C.nchunk_a * kt + 1);
+        L.pidxB = cv.take<int>((size_t)C.nchunk_a * kt + 1);
       }
-      hipLaunchKernelGGL(k_penalty, dim3(1), dim3(256), 0, s, st, C, psum, nparts, wfd);
-      if (p->corr == GHICP_CORR_KM) {
-        dim3 gw(cdiv(C.n, 256), C.n);
-        hipEvent_t kw = ctx->kt_begin(KT_KM_WEIGHTS);
-        hipLaunchKernelGGL(k_km_weights<FT>, gw, dim3(256), 0, s, st, C, kpS, kpT, FD, wfd, kmw);
-        ctx->kt_end(KT_KM_WEIGHTS, kw);
-        GH_TRY(gh_km_solve_dev(ctx, kmw, C.n, C.km_eps, kmmatch, &st->done));
+      L.SP = cv.take<int>((size_t)C.n + 1);
+      L.TP = cv.take<int>((size_t)C.n + 1);
+      L.SVs = cv.take<int>((size_t)ks + 1);
+      L.TVs = cv.take<int>((size_t)kt + ks + 2);
+      L.trace = cv.take<ghicp_iter>((size_t)p->max_iter + 1);
+      L.matchlist = J.matchlist;
+      if (FT != GHICP_FEATURE_NONE) L.FDt = cv.take<char>((size_t)ks * kt * (FT == GHICP_FEATURE_BSC ? 2 : 4) + 16);
+      if (corr == GHICP_CORR_KM) {
+        L.kmmatch = cv.take<int>((size_t)C.n + 1);
+        L.km_status = cv.take<int>(4);
+        if (gh_km2_fits(C.n)) {
+          L.km_cnt = cv.take<unsigned>((size_t)C.n + 1);
+          L.km_rptr = cv.take<unsigned>((size_t)C.n + 2);
+          L.km_lx = cv.take<double>((size_t)C.n + 1);
+          L.km_cols = cv.take<int>((size_t)ks * kt + 1);
+          L.km_vals = cv.take<double>((size_t)ks * kt + 1);
+          L.km_desc = d_descs ? d_descs + b : nullptr;
+        } else {
+          L.kmw = cv.take<double>((size_t)C.n * C.n + 1);
+        }
       }
-      hipLaunchKernelGGL(k_solve<FT>, dim3(1), dim3(1024), 0, s, st, C, kpS, kpT, FD, pminA, pidxA, pidxB, pminB, kmw, kmmatch, SP, TP, SVs,
-                         TVs, trace, matchlist);
     }
-    GH_HIP(hipGetLastError());
-    GH_HIP(hipMemcpyAsync(hflag, st, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    GH_HIP(hipStreamSynchronize(s));
-    done = hflag[1] != 0;
-  }
-  LoopState fin;
-  if (ks <= 0 || kt <= 0) {
-    fin = h;
-  } else {
-    GH_HIP(hipMemcpyAsync(&fin, st, sizeof(fin), hipMemcpyDeviceToHost, s));
-    GH_HIP(hipStreamSynchronize(s));
-  }
-  for (int d = 0; d < 16; d++) Rt16[d] = fin.Rt_till[d];
-  if (n_iter) *n_iter = fin.it;
-  if (trace_host && fin.it > 0) {
-    GH_HIP(hipMemcpyAsync(trace_host, trace, (size_t)fin.it * sizeof(ghicp_iter), hipMemcpyDeviceToHost, s));
-    GH_HIP(hipStreamSynchronize(s));
+    total = cv.off;
+    if (pass == 1) {
+      // ---- upload tables, states, descriptors
+      GH_HIP(hipMemcpyAsync(const_cast<double*>(wfd), wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      GH_HIP(hipMemsetAsync(d_descs, 0, (size_t)nb * sizeof(Km2Problem), s));  // n = 0: "nothing to solve"
+      for (int b = 0; b < nb; b++) {
+        LoopState& h = hst[b];
+        memset(&h, 0, sizeof(h));
+        h.RMS = 99999; h.para1 = jobs[b].p->para1; h.para2 = jobs[b].p->para2;  // ghicp_reg.h:98, 33-34
+        for (int d = 0; d < 4; d++) h.Rt_till[d * 5] = 1.0;
+        if (jobs[b].ks <= 0 || jobs[b].kt <= 0) h.done = 1;
+        GH_HIP(hipMemcpyAsync(hp[b].st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+        if (jobs[b].ks > 0) GH_HIP(hipMemcpyAsync(hp[b].kpS, jobs[b].kpS, (size_t)jobs[b].ks * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (hp[b].km_status) GH_HIP(hipMemsetAsync(hp[b].km_status, 0, sizeof(int), s));
+        // the feature matrix transposed once so that the row sweep reads it coalesced
+        if (FT != GHICP_FEATURE_NONE && jobs[b].ks > 0 && jobs[b].kt > 0) {
+          dim3 g(cdiv(jobs[b].kt, 32), cdiv(jobs[b].ks, 32)), blk(32, 8);
+          if (FT == GHICP_FEATURE_BSC)
+            hipLaunchKernelGGL(k_transpose<uint16_t>, g, blk, 0, s, (const uint16_t*)jobs[b].FD, jobs[b].ks, jobs[b].kt, (uint16_t*)hp[b].FDt);
+          else
+            hipLaunchKernelGGL(k_transpose<float>, g, blk, 0, s, (const float*)jobs[b].FD, jobs[b].ks, jobs[b].kt, (float*)hp[b].FDt);
+        }
+      }
+      GH_HIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)nb * sizeof(LoopProb), hipMemcpyHostToDevice, s));
+
+      // ---- iterate
+      std::vector<int> hflags((size_t)nb * 2, 0);
+      const int poll_every = 2;
+      int launched = 0;
+      bool all_done = false;
+      bool any_dense = false;
+      for (int b = 0; b < nb; b++) any_dense |= (hp[b].kmw != nullptr);
+      bool any_sparse = false;
+      int max_n_sparse = 1;
+      for (int b = 0; b < nb; b++)
+        if (hp[b].km_rptr) { any_sparse = true; max_n_sparse = std::max(max_n_sparse, hp[b].C.n); }
+      while (!all_done && launched < max_iter) {
+        for (int r = 0; r < poll_every && launched < max_iter; r++, launched++) {
+          hipEvent_t kev = ctx->kt_begin(KT_CD_ROWMIN);
+          hipLaunchKernelGGL((k_cd_rowmin<FT, false>), dim3(max_rowsA, max_chunkB, nb), dim3(ROWS), 0, s, dprobs);
+          ctx->kt_end(KT_CD_ROWMIN, kev);
+          if (corr == GHICP_CORR_NNR) hipLaunchKernelGGL((k_cd_rowmin<FT, true>), dim3(max_rowsB, max_chunkA, nb), dim3(ROWS), 0, s, dprobs);
+          hipLaunchKernelGGL(k_penalty, dim3(nb), dim3(256), 0, s, dprobs);
+          if (corr == GHICP_CORR_KM) {
+            hipEvent_t kw = ctx->kt_begin(KT_KM_WEIGHTS);
+            hipLaunchKernelGGL((k_km_csr<FT, 0>), dim3(cdiv(max_n, 4), nb), dim3(256), 0, s, dprobs);
+            hipLaunchKernelGGL(k_km_scan_desc, dim3(nb), dim3(1024), 0, s, dprobs);
+            hipLaunchKernelGGL((k_km_csr<FT, 1>), dim3(cdiv(max_n, 4), nb), dim3(256), 0, s, dprobs);
+            ctx->kt_end(KT_KM_WEIGHTS, kw);
+            if (any_sparse) GH_TRY(gh_km2_launch(ctx, d_descs, nb, max_n_sparse));
+            if (any_dense) {  // matrices too large for the LDS-resident solver: dense fallback, one pair at a time
+              hipLaunchKernelGGL(k_km_weights<FT>, dim3(cdiv(max_n, 256), max_n, nb), dim3(256), 0, s, dprobs);
+              for (int b = 0; b < nb; b++)
+                if (hp[b].kmw) GH_TRY(gh_km_solve_dev(ctx, hp[b].kmw, hp[b].C.n, hp[b].C.km_eps, hp[b].kmmatch, &hp[b].st->done));
+            }
+          }
+          hipLaunchKernelGGL(k_solve<FT>, dim3(nb), dim3(1024), 0, s, dprobs);
+        }
+        GH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_collect_done, dim3(cdiv(nb, 256)), dim3(256), 0, s, dprobs, nb, dflags);
+        GH_HIP(hipMemcpyAsync(hflags.data(), dflags, hflags.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        GH_HIP(hipStreamSynchronize(s));
+        all_done = true;
+        for (int b = 0; b < nb; b++) all_done &= (hflags[(size_t)b * 2 + 1] != 0);
+      }
+      // ---- results
+      for (int b = 0; b < nb; b++) GH_HIP(hipMemcpyAsync(&hst[b], hp[b].st, sizeof(LoopState), hipMemcpyDeviceToHost, s));
+      GH_HIP(hipStreamSynchronize(s));
+      for (int b = 0; b < nb; b++) {
+        const gh_loop_job& J = jobs[b];
+        for (int d = 0; d < 16; d++) J.Rt16[d] = hst[b].Rt_till[d];
+        if (J.n_iter) *J.n_iter = hst[b].it;
+        if (J.converged) *J.converged = hst[b].converged_flag;
+        if (J.trace && hst[b].it > 0) GH_HIP(hipMemcpyAsync(J.trace, hp[b].trace, (size_t)hst[b].it * sizeof(ghicp_iter), hipMemcpyDeviceToHost, s));
+      }
+      GH_HIP(hipStreamSynchronize(s));
+      int kmst = 0;
+      for (int b = 0; b < nb; b++)
+        if (hp[b].km_status) {
+          int v = 0;
+          GH_HIP(hipMemcpy(&v, hp[b].km_status, sizeof(int), hipMemcpyDeviceToHost));
+          kmst |= v;
+        }
+      if (kmst) return ctx->fail(GHICP_ERR_INTERNAL, "KM solver status %d (non-finite energy?)", kmst);
+    }
   }
   return GHICP_OK;
 }
 
 }  // namespace
 
-int gh_register_dev(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int ks, const double* kpT, int kt, const void* FD,
-                    double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist) {
-  GH_ARG(p != nullptr && Rt16 != nullptr);
-  GH_ARG(ks >= 0 && kt >= 0 && p->max_iter > 0 && p->max_iter <= 100000);
-  GH_ARG(p->corr == GHICP_CORR_NN || p->corr == GHICP_CORR_NNR || p->corr == GHICP_CORR_KM);
-  switch (p->feature) {
-    case GHICP_FEATURE_BSC:
-      GH_ARG(FD != nullptr || ks == 0 || kt == 0);
-      return run_loop<GHICP_FEATURE_BSC>(ctx, p, kpS, ks, kpT, kt, FD, Rt16, trace, n_iter, matchlist);
-    case GHICP_FEATURE_FPFH:
-      GH_ARG(FD != nullptr || ks == 0 || kt == 0);
-      return run_loop<GHICP_FEATURE_FPFH>(ctx, p, kpS, ks, kpT, kt, FD, Rt16, trace, n_iter, matchlist);
+int gh_register_batch_dev(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
+  if (nb <= 0) return GHICP_OK;
+  for (int b = 0; b < nb; b++) {
+    const gh_loop_job& J = jobs[b];
+    GH_ARG(J.p != nullptr && J.Rt16 != nullptr);
+    GH_ARG(J.ks >= 0 && J.kt >= 0 && J.p->max_iter > 0 && J.p->max_iter <= 100000);
+    GH_ARG(J.p->corr == GHICP_CORR_NN || J.p->corr == GHICP_CORR_NNR || J.p->corr == GHICP_CORR_KM);
+    GH_ARG(J.p->feature == jobs[0].p->feature && J.p->corr == jobs[0].p->corr && J.p->weight_changing_rate == jobs[0].p->weight_changing_rate);
+    if (J.p->feature == GHICP_FEATURE_BSC || J.p->feature == GHICP_FEATURE_FPFH) GH_ARG(J.FD != nullptr || J.ks == 0 || J.kt == 0);
+  }
+  switch (jobs[0].p->feature) {
+    case GHICP_FEATURE_BSC: return run_loops<GHICP_FEATURE_BSC>(ctx, nb, jobs);
+    case GHICP_FEATURE_FPFH: return run_loops<GHICP_FEATURE_FPFH>(ctx, nb, jobs);
     case GHICP_FEATURE_NONE:
     case GHICP_FEATURE_ROPS:  // test/ghicp_main.cpp:130-134 falls through with no feature
-      return run_loop<GHICP_FEATURE_NONE>(ctx, p, kpS, ks, kpT, kt, nullptr, Rt16, trace, n_iter, matchlist);
-    default:
-      return ctx->fail(GHICP_ERR_ARG, "unknown feature type %d", p->feature);
+      return run_loops<GHICP_FEATURE_NONE>(ctx, nb, jobs);
+    default: return ctx->fail(GHICP_ERR_ARG, "unknown feature type %d", jobs[0].p->feature);
   }
+}
+
+int gh_register_dev(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int ks, const double* kpT, int kt, const void* FD,
+                    double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist) {
+  gh_loop_job J;
+  memset(&J, 0, sizeof(J));
+  J.p = p; J.kpS = kpS; J.ks = ks; J.kpT = kpT; J.kt = kt; J.FD = FD; J.Rt16 = Rt16; J.trace = trace; J.n_iter = n_iter; J.matchlist = matchlist;
+  return gh_register_batch_dev(ctx, 1, &J);
 }
 
 extern "C" int ghicp_register(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int64_t ks, const double* kpT, int64_t kt,

@@ -162,6 +162,12 @@ typedef struct ghicp_pair_stats {
 int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* xyzS, int64_t nS, const float* xyzT, int64_t nT,
                         int stride, ghicp_pair_stats* stats /*[host]*/, ghicp_iter* trace /*[host] or NULL*/);
 
+/* A batch of independent pairs (BASELINE configs[3]: many fragment pairs per GPU): the per-pair front ends run
+ * back to back, then one batched GH-ICP loop advances every pair concurrently (one KM solve per wave).
+ * Device pointers only.  xyzS/xyzT/nS/nT: host arrays of n_pairs device pointers / sizes; stats: n_pairs [host]. */
+int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const float* const* xyzS, const int64_t* nS,
+                         const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,3 +144,23 @@ def test_transform_cloud(ctx, oracle, tls):
     Rt = tls.gt
     og = ctx.transform_cloud(tls.source[:5000], Rt).cpu().numpy()
     np.testing.assert_array_equal(og, oracle.transform_cloud(tls.source[:5000], Rt))
+
+
+def test_register_pairs_batch_equals_single(ctx, api, synth, tls):
+    """Batched API (many pairs advance concurrently) must reproduce the single-pair API bit for bit."""
+    pat = synth.bsc_pattern_glibc()
+    other = synth.tls_pair(60_000, pair_id=3)
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, 6, 0.6, 0.1, 0.5, 1.5, pat, max_iter=60)
+    import torch
+
+    jobs = [(tls.source, tls.target), (other.source, other.target), (tls.target, tls.source), (other.source[:100], other.target[:100])]
+    dev = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in jobs]
+    batch = ctx.register_pairs(cfg, dev)
+    assert len(batch) == len(jobs)
+    for (a, b), st in zip(dev, batch):
+        single, _ = ctx.register_pair(cfg, a, b, want_trace=False)
+        assert (st.m_s, st.m_t, st.k_s, st.k_t, st.iterations, st.converged) == (single.m_s, single.m_t, single.k_s, single.k_t,
+                                                                                   single.iterations, single.converged)
+        ra, rb = np.array(st.Rt[:]), np.array(single.Rt[:])
+        assert np.array_equal(ra, rb) or (np.isnan(ra).any() and np.isnan(rb).any())
+    assert ctx.register_pairs(cfg, []) == []
