@@ -21,6 +21,7 @@
 #include "devmath.h"
 
 #include <climits>
+#include <cstdlib>
 
 struct Km2Problem {
   int n, pad_;
@@ -57,7 +58,7 @@ __device__ inline int first_clear(const unsigned* __restrict__ bits, int y0, int
     const unsigned long long b = __ballot(inv != 0u);
     if (b) {
       const int l = (int)__ffsll((long long)b) - 1;
-      const unsigned iv = (unsigned)__shfl((int)inv, l, 64);
+      const unsigned iv = (unsigned)__builtin_amdgcn_readlane((int)inv, l);
       return (wb + l) * 32 + (__ffs((int)iv) - 1);
     }
   }
@@ -179,6 +180,236 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
   }
 }
 
+}  // namespace
+
+// =====================================================================================================
+// Third-generation solver: same traversal, but the DFS never touches global memory.  Every row keeps in LDS a
+// small list (<= 2 entries, ascending column) that is a SUPERSET of its currently tight explicit entries:
+//   L1  an explicit entry (x,y) that is not tight can only become tight when lx[x] drops, i.e. after a failed
+//       phase that visited x -- exactly the rows whose lists are rebuilt at the end of that phase;
+//   L2  listed entries are re-tested with the fresh expression fl(fl(lx+ly[y]) - w) < eps at every use, so a
+//       stale member is harmless;
+//   L3  (E4 again) slack contributions of explicit entries are order independent within a failed phase and dead
+//       in a successful one, so they are applied once, at the end of a failed phase, for the visited rows.
+// A row with more than 2 tight explicit entries is flagged and scanned from its CSR row (global) instead.
+// LDS: 51.25 B per row/column -> n <= ~3100 in 160 KB; 16-bit match/stack entries (n <= 65534).
+constexpr int TL_CAP = 2;
+
+size_t gh_km3_lds_bytes(int n) {
+  return (size_t)n * (24 + 16 + 2 * 3 + 2 * TL_CAP) + (size_t)((n + 3) / 4) * 4 + 2 * (size_t)((n + 31) / 32) * 4 + 128;
+}
+
+namespace {
+
+__global__ __launch_bounds__(64) void k_km3(const Km2Problem* __restrict__ probs) {
+  const Km2Problem P = probs[blockIdx.x];
+  if (P.n <= 0 || (P.done && *P.done)) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = P.n, nw = (n + 31) / 32, lane = threadIdx.x;
+  double* lx = (double*)smem;
+  double* ly = lx + n;
+  double* slack = ly + n;
+  double* tlv = slack + n;                                   // [n][TL_CAP]
+  unsigned* visx = (unsigned*)(tlv + (size_t)n * TL_CAP);
+  unsigned* visy = visx + nw;
+  unsigned short* match = (unsigned short*)(visy + nw);
+  unsigned short* stx = match + n;
+  unsigned short* sty = stx + n;
+  unsigned short* tlc = sty + n;                             // [n][TL_CAP]
+  unsigned char* tln = (unsigned char*)(tlc + (size_t)n * TL_CAP);
+  const double bg = P.bg, eps = P.eps;
+  const int NONE = 0xFFFF;
+
+  for (int i = lane; i < n; i += 64) { lx[i] = P.lx_init[i]; ly[i] = 0.0; match[i] = (unsigned short)NONE; }
+  __syncthreads();
+
+  // (re)build the tight list of row x under the current labels; wave-uniform x
+  auto build_list = [&](int x) {
+    const unsigned cb = P.row_ptr[x], ce = P.row_ptr[x + 1];
+    const double lxv = lx[x];
+    int cnt = 0;
+    for (unsigned c0 = cb; c0 < ce; c0 += 64) {
+      const unsigned c = c0 + lane;
+      bool t = false;
+      int col = 0;
+      double val = 0;
+      if (c < ce) { col = P.cols[c]; val = P.vals[c]; t = ((lxv + ly[col]) - val) < eps; }
+      const unsigned long long b = __ballot(t);
+      if (t) {
+        const int r = cnt + __popcll(b & ((1ull << lane) - 1ull));
+        if (r < TL_CAP) { tlc[x * TL_CAP + r] = (unsigned short)col; tlv[x * TL_CAP + r] = val; }
+      }
+      cnt += __popcll(b);
+    }
+    if (lane == 0) tln[x] = (unsigned char)(cnt > TL_CAP ? (0x80 | TL_CAP) : cnt);
+  };
+  for (int x = 0; x < n; x++) build_list(x);
+  __syncthreads();
+
+  long long nsteps = 0, n_over = 0, n_flat = 0, n_failph = 0, n_failrows = 0, cyc_dfs = 0, cyc_fail = 0, cyc_init = 0;
+  const long long t_start = __builtin_readcyclecounter();
+  int bad = 0;
+  for (int root = 0; root < n && !bad; ++root) {
+    for (int i = lane; i < n; i += 64) slack[i] = KM_INF2;
+    for (int phase = 0;; ++phase) {
+      const long long t0 = __builtin_readcyclecounter();
+      for (int i = lane; i < nw; i += 64) { visx[i] = 0u; visy[i] = 0u; }
+      __syncthreads();
+      if (lane == 0) { stx[0] = (unsigned short)root; sty[0] = (unsigned short)NONE; visx[root >> 5] = 1u << (root & 31); }
+      __syncthreads();
+      int sp = 0, x = root, ystart = 0;
+      double lxmin = lx[root];
+      bool ok = false;
+      for (;;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
+        nsteps++;
+        // ---- LDS round trip A: the row record and the visited bitmap (independent addresses, issued together)
+        const double lxv = lx[x];
+        const int tn = tln[x];
+        int colL = 0xFFFF;
+        double valL = 0.0;
+        if (lane < TL_CAP) { colL = tlc[x * TL_CAP + lane]; valL = tlv[x * TL_CAP + lane]; }
+        const int u = first_clear(visy, ystart, n, nw, lane);  // first unvisited column >= ystart (n if none)
+        lxmin = fmin(lxmin, lxv);
+        // ---- LDS round trip B: every gather the decision needs
+        const bool act = lane < (tn & 0x7f);
+        double lyc = 0.0, lyu = 0.0;
+        unsigned visw = ~0u;
+        int mL = NONE, mU = NONE;
+        if (act) { lyc = ly[colL]; visw = visy[colL >> 5]; mL = match[colL]; }
+        const bool pen_tight = (lxv - bg) < eps;  // E2
+        if (pen_tight && u < n) { lyu = ly[u]; mU = match[u]; }
+        // ---- decide
+        const bool tl = act && colL >= ystart && !((visw >> (colL & 31)) & 1u) && ((lxv + lyc) - valL) < eps;
+        const unsigned long long bl = __ballot(tl);
+        int best = INT_MAX, mbest = NONE;
+        if (pen_tight && u < n && ((lxv + lyu) - bg) < eps) {
+          best = u; mbest = mU;  // every unvisited column is >= u, and background-tight implies tight (E3)
+        } else {
+          if (bl) {
+            const int l = (int)__ffsll((long long)bl) - 1;
+            best = __builtin_amdgcn_readlane(colL, l);
+            mbest = __builtin_amdgcn_readlane(mL, l);
+          } else if (tn & 0x80) {  // more tight explicit entries than the list holds: scan the CSR row beyond it
+            n_over++;
+            const int from = max(ystart, __builtin_amdgcn_readlane(colL, TL_CAP - 1) + 1);
+            const unsigned cb = P.row_ptr[x], ce = P.row_ptr[x + 1];
+            for (unsigned c0 = cb; c0 < ce; c0 += 64) {
+              const unsigned c = c0 + lane;
+              int col = INT_MAX;
+              bool tight = false;
+              if (c < ce) {
+                col = P.cols[c];
+                tight = col >= from && !bit_get(visy, col) && ((lxv + ly[col]) - P.vals[c]) < eps;
+              }
+              const unsigned long long b = __ballot(tight);
+              if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); mbest = match[best]; break; }
+            }
+          }
+          if (pen_tight && u < n) {  // u itself is not background-tight (ly[u] grew): look for a later one below `best`
+            n_flat++;
+            int y0 = u + 1;
+            for (;;) {
+              y0 = first_clear(visy, y0, n, nw, lane);
+              if (y0 >= n || y0 >= best) break;
+              const int y = y0 + lane;
+              bool t = false;
+              if (y < n && !bit_get(visy, y)) t = ((lxv + ly[y]) - bg) < eps;
+              const unsigned long long b = __ballot(t);
+              if (b) {
+                const int yy = y0 + (int)__ffsll((long long)b) - 1;
+                if (yy < best) { best = yy; mbest = match[yy]; }
+                break;
+              }
+              y0 += 64;
+            }
+          }
+        }
+        if (best != INT_MAX) {
+          const int ystar = best;
+          if (lane == 0) { visy[ystar >> 5] |= 1u << (ystar & 31); sty[sp] = (unsigned short)ystar; }
+          if (mbest == NONE) {  // augment: match[y] = x on every level of the recursion (km.cpp:26-29)
+            __builtin_amdgcn_wave_barrier();
+            for (int f = lane; f <= sp; f += 64) match[sty[f]] = stx[f];
+            ok = true;
+            break;
+          }
+          sp++;
+          if (lane == 0) { stx[sp] = (unsigned short)mbest; sty[sp] = NONE; visx[mbest >> 5] |= 1u << (mbest & 31); }
+          x = mbest; ystart = 0;
+        } else {
+          sp--;
+          if (sp < 0) break;
+          x = stx[sp]; ystart = (int)sty[sp] + 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
+      const long long t1 = __builtin_readcyclecounter();
+      cyc_dfs += t1 - t0;
+      if (ok) break;
+      n_failph++;
+      // ---- failed phase.  (1) explicit entries of every visited row feed slack (L3)
+      for (int w = 0; w < nw; w++) {
+        unsigned bits = visx[w];
+        while (bits) {
+          const int xr = w * 32 + (__ffs((int)bits) - 1);
+          bits &= bits - 1u;
+          n_failrows++;
+          const unsigned cb = P.row_ptr[xr], ce = P.row_ptr[xr + 1];
+          const double lxr = lx[xr];
+          for (unsigned c = cb + lane; c < ce; c += 64) {
+            const int col = P.cols[c];
+            const double d = (lxr + ly[col]) - P.vals[c];
+            if (!(d < eps)) slack[col] = fmin(slack[col], d);
+          }
+        }
+      }
+      __syncthreads();
+      // (2) deferred background slack (E4) + delta, (3) relabel (km.cpp:80-98)
+      double dl = KM_INF2;
+      for (int y = lane; y < n; y += 64)
+        if (!bit_get(visy, y)) {
+          const double s2 = fmin(slack[y], (lxmin + ly[y]) - bg);
+          slack[y] = s2;
+          dl = fmin(dl, s2);
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dl = fmin(dl, __shfl_xor(dl, o, 64));
+      for (int i = lane; i < n; i += 64) {
+        if (bit_get(visx, i)) lx[i] -= dl;
+        if (bit_get(visy, i)) ly[i] += dl;
+        else slack[i] -= dl;
+      }
+      __syncthreads();
+      // (4) lists of the visited rows under the new labels (L1)
+      for (int w = 0; w < nw; w++) {
+        unsigned bits = visx[w];
+        while (bits) {
+          const int xr = w * 32 + (__ffs((int)bits) - 1);
+          bits &= bits - 1u;
+          build_list(xr);
+        }
+      }
+      __syncthreads();
+      cyc_fail += __builtin_readcyclecounter() - t1;
+      if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) P.match_out[i] = match[i] == NONE ? -1 : (int)match[i];
+  if (lane == 0) {
+    if (bad && P.status) *P.status = bad;
+    if (P.steps) {
+      P.steps[0] = nsteps; P.steps[1] = n_over; P.steps[2] = n_flat; P.steps[3] = n_failph; P.steps[4] = n_failrows;
+      P.steps[5] = cyc_dfs; P.steps[6] = cyc_fail; P.steps[7] = __builtin_readcyclecounter() - t_start; (void)cyc_init;
+    }
+  }
+}
+
+}  // namespace
+
+namespace {
+
 // ---- dense matrix -> background + CSR (for the public ghicp_km_solve entry point)
 __global__ __launch_bounds__(256) void k_dense_min(const double* __restrict__ w, size_t total, unsigned long long* __restrict__ out) {
   // order-preserving key of a double (ascending)
@@ -243,15 +474,20 @@ __global__ __launch_bounds__(1024) void k_gh_scan_rows(const unsigned* __restric
 
 // launches one k_km2 block per problem; descriptors already on device
 int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max) {
-  const size_t lds = gh_km2_lds_bytes(n_max);
-  static size_t attr_done = 0;
-  if (lds > attr_done) {
+  static bool attr_done = false;
+  if (!attr_done) {
     const size_t want = 160 * 1024;
     GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
-    attr_done = want;
+    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    attr_done = true;
   }
+  // v2 and v3 solve at the same speed (the DFS is instruction-issue bound, not memory bound: profiles/r01_km_step_counters.txt);
+  // v2 needs less LDS per problem, so more problems are resident per CU -> default. GHICP_KM_V3=1 selects the list kernel.
+  const bool v3 = n_max <= 65534 && gh_km3_lds_bytes(n_max) <= 160 * 1024 - 256 && getenv("GHICP_KM_V3") != nullptr;
+  const size_t lds = v3 ? gh_km3_lds_bytes(n_max) : gh_km2_lds_bytes(n_max);
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
-  hipLaunchKernelGGL(k_km2, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
+  if (v3) hipLaunchKernelGGL(k_km3, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
+  else hipLaunchKernelGGL(k_km2, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
@@ -289,6 +525,20 @@ int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32
   memset(&hp, 0, sizeof(hp));
   hp.n = n; hp.bg = bg_h; hp.eps = eps; hp.row_ptr = rptr; hp.cols = cols; hp.vals = vals; hp.lx_init = lx; hp.match_out = match;
   hp.status = status_dev;
+  long long* dstats = nullptr;
+  if (getenv("GHICP_KM_STATS")) {
+    GH_TRY(ctx->reserve(B_P_PATTERN, 16, &dstats));
+    GH_HIP(hipMemsetAsync(dstats, 0, 8 * sizeof(long long), s));
+    hp.steps = dstats;
+  }
   GH_HIP(hipMemcpyAsync(dp, &hp, sizeof(hp), hipMemcpyHostToDevice, s));
-  return gh_km2_launch(ctx, dp, 1, n);
+  GH_TRY(gh_km2_launch(ctx, dp, 1, n));
+  if (dstats) {
+    long long h[8];
+    GH_HIP(hipMemcpyAsync(h, dstats, sizeof(h), hipMemcpyDeviceToHost, s));
+    GH_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "[km stats] n=%d steps=%lld overflow=%lld flat=%lld failph=%lld failrows=%lld cyc_dfs=%lld cyc_fail=%lld cyc_total=%lld\n", n, h[0], h[1],
+            h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
+  return GHICP_OK;
 }

@@ -57,24 +57,33 @@ __global__ __launch_bounds__(256) void k_nms_round(GridArgs G, float r2, int* __
   const int cx = gh_cell_coord(P.x, G.d.mn[0], G.d.inv, G.d.dim[0]);
   const int cy = gh_cell_coord(P.y, G.d.mn[1], G.d.inv, G.d.dim[1]);
   const int cz = gh_cell_coord(P.z, G.d.mn[2], G.d.inv, G.d.dim[2]);
-  for (int pass = 0; pass < 4; pass++) {  // a few in-kernel sweeps let decisions propagate several hops per launch
+  // Spin in place: a candidate decides as soon as every better-ranked neighbour within R has decided.  All
+  // candidates of a launch are co-resident for C <= ~0.5 M, so the globally best undecided one can always move;
+  // the bounded loop + host relaunch keeps this safe when they are not.  Inside a cell the points are in rank
+  // order (stable cell sort of a rank-ordered array), so a cell scan stops at the first rank >= own rank.
+  const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.d.dim[2] - 1);
+  for (int iter = 0; iter < 3; iter++) {
     bool pending = false, killed = false;
-    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
-      for (unsigned q = b; q < e && !killed; q++) {
-        const float4 Q = G.pts[q];
-        const int rq = (int)__float_as_uint(Q.w);
-        if (rq >= rp) continue;
-        const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
-        float d2 = dx * dx;
-        d2 += dy * dy;
-        d2 += dz * dz;
-        if (d2 < r2) {
-          const int sq = __hip_atomic_load(&state[rq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (sq == SELECTED) killed = true;
-          else if (sq == UNDECIDED) pending = true;
+    for (int x = max(cx - 1, 0); x <= min(cx + 1, G.d.dim[0] - 1) && !killed; x++)
+      for (int y = max(cy - 1, 0); y <= min(cy + 1, G.d.dim[1] - 1) && !killed; y++)
+        for (int z = z0; z <= z1 && !killed; z++) {
+          const unsigned key = ((unsigned)x * G.d.dim[1] + y) * G.d.dim[2] + z;
+          const unsigned e = G.start[key + 1];
+          for (unsigned q = G.start[key]; q < e; q++) {
+            const float4 Q = G.pts[q];
+            const int rq = (int)__float_as_uint(Q.w);
+            if (rq >= rp) break;
+            const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
+            float d2 = dx * dx;
+            d2 += dy * dy;
+            d2 += dz * dz;
+            if (d2 < r2) {
+              const int sq = __hip_atomic_load(&state[rq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (sq == SELECTED) { killed = true; break; }
+              if (sq == UNDECIDED) pending = true;
+            }
+          }
         }
-      }
-    });
     if (killed) { __hip_atomic_store(&state[rp], SUPPRESSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     if (!pending) { __hip_atomic_store(&state[rp], SELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
   }
