@@ -1,0 +1,48 @@
+"""The reference-named C++ classes (include/*.h) driven like test/ghicp_main.cpp, on the GPU, vs the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import rot_err, trans_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dump(path, pts):
+    with open(path, "wb") as f:
+        f.write(struct.pack("i", pts.shape[0]))
+        f.write(np.ascontiguousarray(pts, np.float32).tobytes())
+
+
+@pytest.mark.parametrize("corr", ["N", "K"])
+def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr):
+    exe = tmp_path / "test_dropin"
+    libdir = os.path.join(ROOT, "gh-icp_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
+                           "-L", libdir, "-lghicp_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    p = synth.tls_pair(100_000, pair_id=5)
+    dsT = p.target[oracle.voxel_filter(p.target, 0.1)]
+    dsS = p.source[oracle.voxel_filter(p.source, 0.1)]
+    _dump(tmp_path / "T.bin", dsT)
+    _dump(tmp_path / "S.bin", dsS)
+    out = subprocess.run([str(exe), str(tmp_path / "T.bin"), str(tmp_path / "S.bin"), corr], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l.split()[0] in ("KMKAT", "KP", "RT")}
+    assert lines["KMKAT"][:3] == ["0", "2", "1"] and float(lines["KMKAT"][4]) == 12.0  # km.cpp:237-259
+    pat = synth.bsc_pattern_glibc()
+    written = np.loadtxt(tmp_path / "sample_pattern.txt", dtype=np.int32)  # BSCEncoder(..., true) writes it like the reference (bfe:90-101)
+    np.testing.assert_array_equal(written, pat)
+    kpT, _ = oracle.keypoints(dsT, 0.5, 1.5)
+    kpS, _ = oracle.keypoints(dsS, 0.5, 1.5)
+    fT, _, _ = oracle.bsc(dsT, kpT, 1.5, 0, pat)
+    fS, _, _ = oracle.bsc(dsS, kpS, 1.5, 6, pat)
+    assert [int(v) for v in lines["KP"][:2]] == [kpS.size, kpT.size]
+    P = oracle.default_params(oracle.BSC, oracle.KM if corr == "K" else oracle.NN, 6, 0.6, 1.5, oracle.bbx_magnitude(dsS), max_iter=80)
+    ro = oracle.register(P, dsS[kpS].astype(np.float64), dsT[kpT].astype(np.float64), oracle.fd_bsc(fS, fT[0]))
+    assert int(lines["KP"][3]) == ro["iters"]
+    Rg = np.array([float(v) for v in lines["RT"]]).reshape(4, 4)
+    assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3

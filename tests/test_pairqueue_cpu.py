@@ -1,0 +1,69 @@
+"""Multi-GPU pair queue logic on CPU: world_size-2 gloo processes (the N>1 path of SURVEY.md §8e)."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    manifest = [{"seed": 100 + i} for i in range(7)] if rank == 0 else []
+    seen = []
+
+    def register(i, item):  # stands in for ctx.register_pair: a pure function of the manifest entry
+        seen.append(i)
+        return {"pair": i, "rank": rank, "value": item["seed"] * 2}
+
+    out = pq.run_sharded(manifest, register, dist)
+    q.put((rank, seen, out))
+    dist.destroy_process_group()
+
+
+def test_static_partition():
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    for n, w in ((64, 8), (7, 2), (3, 4), (0, 2)):
+        parts = [pq.pairs_for_rank(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        pq.pairs_for_rank(4, 2, 2)
+    assert pq.run_sharded([1, 2, 3], lambda i, x: {"v": x * x}) == [{"v": 1}, {"v": 4}, {"v": 9}]
+
+
+def test_two_rank_gloo_pair_queue():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort()
+    assert got[0][1] == [0, 2, 4, 6] and got[1][1] == [1, 3, 5]  # pair p -> rank p mod 2
+    for _, _, out in got:  # every rank holds every pair's record, in pair order
+        assert [r["pair"] for r in out] == list(range(7))
+        assert [r["rank"] for r in out] == [0, 1, 0, 1, 0, 1, 0]
+        assert [r["value"] for r in out] == [2 * (100 + i) for i in range(7)]
