@@ -33,9 +33,11 @@ def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l.split()[0] in ("KMKAT", "KP", "RT")}
     assert lines["KMKAT"][:3] == ["0", "2", "1"] and float(lines["KMKAT"][4]) == 12.0  # km.cpp:237-259
-    pat = synth.bsc_pattern_glibc()
-    written = np.loadtxt(tmp_path / "sample_pattern.txt", dtype=np.int32)  # BSCEncoder(..., true) writes it like the reference (bfe:90-101)
-    np.testing.assert_array_equal(written, pat)
+    # BSCEncoder(..., true) draws the pattern from rand() and writes it like the reference (bfe:75-101); the sequence
+    # depends on how often the process called rand() before (the HIP runtime does), so the oracle is fed the written file.
+    pat = np.loadtxt(tmp_path / "sample_pattern.txt", dtype=np.int32)
+    assert pat.shape == (49, 2) and pat.min() >= 0 and pat.max() <= 48 and (pat[:, 0] != pat[:, 1]).all()
+    assert len({tuple(sorted(r)) for r in pat.tolist()}) == 49  # contain2DPair: no repeated pair (bfe:856-871)
     kpT, _ = oracle.keypoints(dsT, 0.5, 1.5)
     kpS, _ = oracle.keypoints(dsS, 0.5, 1.5)
     fT, _, _ = oracle.bsc(dsT, kpT, 1.5, 0, pat)
