@@ -47,7 +47,7 @@ EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers",
     "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
-    "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
+    "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
     "ghicp_register_pairs",
 ]
@@ -272,6 +272,16 @@ class Context:
         self._check(self.lib.ghicp_bsc_encode(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], _ptr(kp), C.c_int64(K), C.c_float(radius), dof,
                                               pat.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(feat), _ptr(lcs)))
         return feat, lcs
+
+    def fpfh(self, xyz):
+        """pcl NormalEstimation(k=20) + FPFHEstimation(k=20): returns (normals (m,3), hist (m,33)) device tensors."""
+        t = self.torch
+        x = self._xyz(xyz)
+        m = x.shape[0]
+        nrm = t.empty((m, 3), dtype=t.float32, device=self.dev)
+        hist = t.empty((m, 33), dtype=t.float32, device=self.dev)
+        self._check(self.lib.ghicp_fpfh(self.h, _ptr(x), C.c_int64(m), x.shape[1], 20, 20, _ptr(nrm), _ptr(hist)))
+        return nrm, hist
 
     def transform_cloud(self, xyz, Rt):
         t = self.torch

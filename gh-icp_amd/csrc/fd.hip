@@ -91,6 +91,14 @@ int gh_fd_bsc_dev(ghicp_ctx* ctx, const uint8_t* featS, int ks, int V, const uin
   return GHICP_OK;
 }
 
+int gh_fd_fpfh_dev(ghicp_ctx* ctx, const float* histS, int ks, const float* histT, int kt, float* FD) {
+  if (ks <= 0 || kt <= 0) return GHICP_OK;
+  dim3 g(cdiv(kt, TJ), cdiv(ks, TI));
+  hipLaunchKernelGGL(k_fd_fpfh, g, dim3(256), 0, ctx->stream, histS, ks, histT, kt, FD);
+  GH_HIP(hipGetLastError());
+  return GHICP_OK;
+}
+
 extern "C" int ghicp_fd_bsc(ghicp_ctx* ctx, const uint8_t* featS, int64_t ks, int V, const uint8_t* featT, int64_t kt, uint16_t* FD) {
   if (!ctx) return GHICP_ERR_ARG;
   GH_ARG(ks >= 0 && kt >= 0 && V >= 1 && V <= 4 && ks < (1 << 24) && kt < (1 << 24));

@@ -11,6 +11,9 @@ int gh_keypoints_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, 
 int gh_bsc_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, const int32_t* kp, long long K, float R, int dof, const int32_t* pattern_host,
                uint8_t* feat, float* lcs);
 int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float* mm_host6);
+int gh_fpfh_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float* normals_opt, float* hist);
+int gh_gather_rows33_dev(ghicp_ctx* ctx, const float* hist, const int32_t* idx, long long k, float* out);
+int gh_fd_fpfh_dev(ghicp_ctx* ctx, const float* histS, int ks, const float* histT, int kt, float* FD);
 
 namespace {
 
@@ -119,6 +122,21 @@ static int front_end(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* 
     const int V = F->reg.dof == 6 ? 4 : 2;  // use_6dof_case_ (ghicp_reg.h:109-112, ghicp_reg.cpp:178-182)
     GH_TRY(gh_fd_bsc_dev(ctx, fS, (int)k[0], V, fT, (int)k[1], out_fd->as<uint16_t>()));
     F->FD = out_fd->p;
+  } else if (F->reg.feature == GHICP_FEATURE_FPFH) {
+    // compute_fpfh_feature over the WHOLE down-sampled clouds, then keyfpfh (main:122-127, fpfh.hpp:36-58, 93-115)
+    float *hist, *kS, *kT;
+    const long long mmax = m[0] > m[1] ? m[0] : m[1];
+    GH_TRY(ctx->reserve(B_P_FEAT_S, (size_t)mmax * 33 * sizeof(float) + 64, (char**)&hist));
+    GH_TRY(ctx->reserve(B_P_FEAT_T, (size_t)(k[0] + k[1]) * 33 * sizeof(float) + 64, (char**)&kS));
+    kT = kS + (size_t)k[0] * 33;
+    GH_TRY(gh_fpfh_dev(ctx, reinterpret_cast<const float*>(ds[1]), m[1], 4, nullptr, hist));
+    GH_TRY(gh_gather_rows33_dev(ctx, hist, kp[1], k[1], kT));
+    GH_TRY(gh_fpfh_dev(ctx, reinterpret_cast<const float*>(ds[0]), m[0], 4, nullptr, hist));
+    GH_TRY(gh_gather_rows33_dev(ctx, hist, kp[0], k[0], kS));
+    if (ev) GH_HIP(hipEventRecord(ev[3], s));
+    GH_HIP(out_fd->reserve(((size_t)k[0] * k[1] + 8) * sizeof(float)));
+    GH_TRY(gh_fd_fpfh_dev(ctx, kS, (int)k[0], kT, (int)k[1], out_fd->as<float>()));
+    F->FD = out_fd->p;
   } else if (ev) {
     GH_HIP(hipEventRecord(ev[3], s));
   }
@@ -130,7 +148,7 @@ extern "C" int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg,
                                    int stride, ghicp_pair_stats* stats, ghicp_iter* trace) {
   if (!ctx) return GHICP_ERR_ARG;
   GH_ARG(cfg != nullptr && stats != nullptr && stride >= 3 && nS >= 0 && nT >= 0 && nS < (1ll << 31) - 2 && nT < (1ll << 31) - 2);
-  GH_ARG(cfg->reg.feature == GHICP_FEATURE_BSC || cfg->reg.feature == GHICP_FEATURE_NONE || cfg->reg.feature == GHICP_FEATURE_ROPS);
+  GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   hipStream_t s = ctx->stream;
   Stager sg(ctx);
   const float *dS, *dT;
@@ -172,7 +190,7 @@ extern "C" int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg
                                     const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats) {
   if (!ctx) return GHICP_ERR_ARG;
   GH_ARG(cfg != nullptr && stats != nullptr && n_pairs >= 0 && n_pairs <= 65535 && stride >= 3 && xyzS && xyzT && nS && nT);
-  GH_ARG(cfg->reg.feature == GHICP_FEATURE_BSC || cfg->reg.feature == GHICP_FEATURE_NONE || cfg->reg.feature == GHICP_FEATURE_ROPS);
+  GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_register_pairs: device-pointer mode only");
   if (n_pairs == 0) return GHICP_OK;
   hipStream_t s = ctx->stream;

@@ -113,6 +113,12 @@ int ghicp_keypoints(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, flo
 int ghicp_bsc_encode(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, const int32_t* kp_idx, int64_t k, float radius, int dof,
                      const int32_t* pattern, uint8_t* feat, float* lcs);
 
+/* FPFHfeature::compute_fpfh_feature (include/fpfh.hpp:36-58): pcl::NormalEstimation k=20 + pcl::FPFHEstimationOMP k=20
+ * over the whole cloud.  normals: m x 3 f32 or NULL; hist: m x 33 f32 (pcl::FPFHSignature33 rows). */
+int ghicp_fpfh(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, int k_normal, int k_feature, float* normals, float* hist);
+/* FPFHfeature::keyfpfh (include/fpfh.hpp:93-115): out[i] = hist[kp_idx[i]] (k x 33). Device pointers. */
+int ghicp_fpfh_keypoints(ghicp_ctx* ctx, const float* hist, const int32_t* kp_idx, int64_t k, float* out);
+
 /* ------------------------------------------------------------------ per pair */
 /* GHRegistration::calFD_BSC (src/ghicp_reg.cpp:143-200) + StereoBinaryFeature::hammingDistance
  * (src/stereo_binary_feature.cpp:87-104).  featS: V x ks x 56, featT: kt x 56, FD: ks x kt u16 row-major. */

@@ -501,6 +501,154 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
   if (mean_nb) *mean_nb = K ? nb_sum / K : 0;
 }
 
+// ------------------------------------------------------------------ a9: FPFH (PCL semantics restated)
+// FPFHfeature::compute_fpfh_feature (fpfh.hpp:36-58): pcl::NormalEstimation k=20 (viewpoint origin) followed by
+// pcl::FPFHEstimationOMP k=20 over the whole cloud.  PCL's sources are not on disk: this restates upstream
+// behaviour and is the least certain part of the oracle -- kept in one place on purpose.
+//   kNN      : exact, float L2 ((dx^2+dy^2)+dz^2), k nearest incl. the query, ties -> lower index
+//   normal   : covariance of the k neighbours (f64 sums, N2 rounding), eigenvector of the smallest eigenvalue
+//              (Jacobi), flipped towards the viewpoint (0,0,0) with float arithmetic (flipNormalTowardsViewpoint)
+//   SPFH     : computePairFeatures (Darboux frame), 3 x 11 bins, increment 100/(k-1), failed pairs skipped
+//   FPFH     : sum over neighbours with squared distance != 0 of SPFH / d^2, each 11-bin block rescaled to 100
+static void knn_grid(const Grid& g, const float* xyz, int stride, int i, int k, std::vector<std::pair<float, int>>& best) {
+  const float* q = &xyz[(size_t)i * stride];
+  const int c[3] = {g.coord(q[0], 0), g.coord(q[1], 1), g.coord(q[2], 2)};
+  best.clear();
+  const int rmax = std::max(g.dim[0], std::max(g.dim[1], g.dim[2]));
+  for (int r = 0; r <= rmax; r++) {
+    for (int x = std::max(c[0] - r, 0); x <= std::min(c[0] + r, g.dim[0] - 1); x++)
+      for (int y = std::max(c[1] - r, 0); y <= std::min(c[1] + r, g.dim[1] - 1); y++)
+        for (int z = std::max(c[2] - r, 0); z <= std::min(c[2] + r, g.dim[2] - 1); z++) {
+          if (std::max(std::abs(x - c[0]), std::max(std::abs(y - c[1]), std::abs(z - c[2]))) != r) continue;  // shell r only
+          const int ci = (x * g.dim[1] + y) * g.dim[2] + z;
+          for (int t = g.start[ci]; t < g.start[ci + 1]; t++) {
+            const int j = g.order[t];
+            const float* p = &xyz[(size_t)j * stride];
+            const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+            float d2 = dx * dx;
+            d2 += dy * dy;
+            d2 += dz * dz;
+            best.emplace_back(d2, j);
+          }
+        }
+    std::sort(best.begin(), best.end());
+    if ((int)best.size() > k) best.resize(k);
+    // every unscanned point is farther than r*cell from the query
+    const float reach = (float)r * g.cell;
+    if ((int)best.size() == k && best.back().first < reach * reach) break;
+  }
+}
+
+static void fpfh_cloud(const float* xyz, int m, int stride, int k, float* normals /*m x 3*/, float* hist /*m x 33*/) {
+  Grid g;
+  // cell ~ the radius that holds k points on a surface sampled like this cloud would be ideal; any cell is exact
+  float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+  for (int i = 0; i < m; i++)
+    for (int d = 0; d < 3; d++) { mn[d] = std::min(mn[d], xyz[(size_t)i * stride + d]); mx[d] = std::max(mx[d], xyz[(size_t)i * stride + d]); }
+  const double vol = std::max(1e-9, (double)(mx[0] - mn[0] + 1e-3) * (mx[1] - mn[1] + 1e-3) * (mx[2] - mn[2] + 1e-3));
+  float cell = (float)std::cbrt(vol / std::max(1, m) * 8.0);
+  cell = std::max(cell, 0.05f);
+  g.build(xyz, m, stride, cell);
+  std::vector<int> nn((size_t)m * k, -1);
+  std::vector<float> nd((size_t)m * k, 0.f);
+  std::vector<int> nk(m, 0);
+  std::vector<std::pair<float, int>> best;
+  for (int i = 0; i < m; i++) {
+    knn_grid(g, xyz, stride, i, k, best);
+    nk[i] = (int)best.size();
+    for (int t = 0; t < nk[i]; t++) { nn[(size_t)i * k + t] = best[t].second; nd[(size_t)i * k + t] = best[t].first; }
+  }
+  // ---- normals
+  for (int i = 0; i < m; i++) {
+    const int kk = nk[i];
+    double c[3] = {0, 0, 0};
+    for (int t = 0; t < kk; t++)
+      for (int d = 0; d < 3; d++) c[d] += (double)xyz[(size_t)nn[(size_t)i * k + t] * stride + d];
+    for (int d = 0; d < 3; d++) c[d] /= kk;
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < kk; t++) {
+      const float* p = &xyz[(size_t)nn[(size_t)i * k + t] * stride];
+      const double dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+      S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz; S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
+    }
+    for (int t = 0; t < 6; t++) S[t] /= kk;
+    quant_grid(S, 6);
+    double a[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}}, v[3][3];
+    jacobi3(a, v);
+    int im = 0;
+    if (a[1][1] < a[im][im]) im = 1;
+    if (a[2][2] < a[im][im]) im = 2;
+    float nx = (float)v[0][im], ny = (float)v[1][im], nz = (float)v[2][im];
+    const float* p = &xyz[(size_t)i * stride];
+    const float vx = 0.f - p[0], vy = 0.f - p[1], vz = 0.f - p[2];
+    const float cs = (vx * nx + vy * ny) + vz * nz;  // flipNormalTowardsViewpoint
+    if (cs < 0) { nx = -nx; ny = -ny; nz = -nz; }
+    normals[(size_t)i * 3] = nx; normals[(size_t)i * 3 + 1] = ny; normals[(size_t)i * 3 + 2] = nz;
+  }
+  // ---- SPFH
+  std::vector<float> spfh((size_t)m * 33, 0.f);
+  auto dot3 = [](const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; };
+  for (int i = 0; i < m; i++) {
+    const int kk = nk[i];
+    const float incr = 100.0f / (float)(kk - 1);
+    float* H = &spfh[(size_t)i * 33];
+    const float* p1 = &xyz[(size_t)i * stride];
+    const float* n1 = &normals[(size_t)i * 3];
+    for (int t = 0; t < kk; t++) {
+      const int j = nn[(size_t)i * k + t];
+      if (j == i) continue;
+      const float* p2 = &xyz[(size_t)j * stride];
+      const float* n2 = &normals[(size_t)j * 3];
+      float dp[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      const float f4 = std::sqrt(dot3(dp, dp));
+      if (f4 == 0.0f) continue;
+      float a1[3] = {n1[0], n1[1], n1[2]}, a2[3] = {n2[0], n2[1], n2[2]};
+      const float angle1 = dot3(a1, dp) / f4, angle2 = dot3(a2, dp) / f4;
+      float f3;
+      if (std::fabs(angle1) < std::fabs(angle2)) {  // acos(|angle1|) > acos(|angle2|): switch the roles of the two points
+        for (int d = 0; d < 3; d++) { a1[d] = n2[d]; a2[d] = n1[d]; dp[d] = -dp[d]; }
+        f3 = -angle2;
+      } else {
+        f3 = angle1;
+      }
+      float vv[3] = {dp[1] * a1[2] - dp[2] * a1[1], dp[2] * a1[0] - dp[0] * a1[2], dp[0] * a1[1] - dp[1] * a1[0]};
+      const float vn = std::sqrt(dot3(vv, vv));
+      if (vn == 0.0f) continue;
+      const float iv = 1.0f / vn;
+      for (int d = 0; d < 3; d++) vv[d] *= iv;
+      const float ww[3] = {a1[1] * vv[2] - a1[2] * vv[1], a1[2] * vv[0] - a1[0] * vv[2], a1[0] * vv[1] - a1[1] * vv[0]};
+      const float f2 = dot3(vv, a2);
+      const float f1 = std::atan2(dot3(ww, a2), dot3(a1, a2));
+      int h = (int)std::floor(11 * (((double)f1 + M_PI) * (1.0 / (2.0 * M_PI))));
+      h = std::min(std::max(h, 0), 10);
+      H[h] += incr;
+      h = (int)std::floor(11 * (((double)f2 + 1.0) * 0.5));
+      h = std::min(std::max(h, 0), 10);
+      H[11 + h] += incr;
+      h = (int)std::floor(11 * (((double)f3 + 1.0) * 0.5));
+      h = std::min(std::max(h, 0), 10);
+      H[22 + h] += incr;
+    }
+  }
+  // ---- weighting (weightPointSPFHSignature)
+  for (int i = 0; i < m; i++) {
+    float* F = &hist[(size_t)i * 33];
+    for (int b = 0; b < 33; b++) F[b] = 0.f;
+    float sum[3] = {0, 0, 0};
+    for (int t = 0; t < nk[i]; t++) {
+      const float d = nd[(size_t)i * k + t];
+      if (d == 0) continue;
+      const float w = 1.0f / d;
+      const float* H = &spfh[(size_t)nn[(size_t)i * k + t] * 33];
+      for (int b = 0; b < 33; b++) { const float val = H[b] * w; sum[b / 11] += val; F[b] += val; }
+    }
+    for (int s3 = 0; s3 < 3; s3++) {
+      if (sum[s3] != 0) sum[s3] = 100.0f / sum[s3];
+      for (int b = 0; b < 11; b++) F[s3 * 11 + b] *= sum[s3];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ a10/a11: feature distance
 static inline int popcount8(uint8_t b) { return __builtin_popcount((unsigned)b); }
 // stereo_binary_feature.cpp:87-104 (byte LUT popcount of XOR) + ghicp_reg.cpp:174-187
@@ -640,6 +788,12 @@ void orc_bsc(const float* xyz, int m, int stride, const int* kp, int K, float R,
 void orc_bsc_binarize(const float* weight, const float* depth, int ncell, const int* pattern, uint8_t* out56) {
   std::memset(out56, 0, 56);
   orc::bsc_binarize(weight, depth, ncell, pattern, out56);
+}
+// normals: m x 3 (may be NULL), hist: m x 33
+void orc_fpfh(const float* xyz, int m, int stride, int k, float* normals, float* hist) {
+  std::vector<float> tmp;
+  if (!normals) { tmp.resize((size_t)m * 3); normals = tmp.data(); }
+  orc::fpfh_cloud(xyz, m, stride, k, normals, hist);
 }
 void orc_fd_bsc(const uint8_t* fS, int ks, int V, const uint8_t* fT, int kt, double* FD) { orc::fd_bsc(fS, ks, V, fT, kt, FD); }
 void orc_fd_fpfh(const float* hS, int ks, const float* hT, int kt, double* FD) {

@@ -149,6 +149,16 @@ def bsc_binarize(weight, depth, pattern):
     return out
 
 
+def fpfh(xyz, k=20):
+    """pcl NormalEstimation(k) + FPFHEstimation(k) restated: returns (normals (m,3), hist (m,33))."""
+    xyz = _f32(xyz)
+    m = xyz.shape[0]
+    nrm = np.zeros((m, 3), np.float32)
+    hist = np.zeros((m, 33), np.float32)
+    lib().orc_fpfh(_p(xyz, C.c_float), m, xyz.shape[1], k, _p(nrm, C.c_float), _p(hist, C.c_float))
+    return nrm, hist
+
+
 def fd_bsc(fS, fT):
     """fS: (V,ks,56) u8, fT: (kt,56) u8 -> (ks,kt) f64"""
     fS = np.ascontiguousarray(fS, np.uint8)

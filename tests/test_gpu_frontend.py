@@ -164,3 +164,35 @@ def test_register_pairs_batch_equals_single(ctx, api, synth, tls):
         ra, rb = np.array(st.Rt[:]), np.array(single.Rt[:])
         assert np.array_equal(ra, rb) or (np.isnan(ra).any() and np.isnan(rb).any())
     assert ctx.register_pairs(cfg, []) == []
+
+
+def test_fpfh_normals_and_histograms(ctx, oracle, ds_target):
+    """PCL NormalEstimation(k=20) + FPFHEstimation(k=20) restated: GPU vs oracle on the same cloud."""
+    sub = ds_target[:30000]
+    no, ho = oracle.fpfh(sub)
+    ng, hg = ctx.fpfh(sub)
+    ng, hg = ng.cpu().numpy(), hg.cpu().numpy()
+    np.testing.assert_array_equal(ng, no)  # normals: N2/N3 contract -> f32 bit-exact
+    # histograms: float tolerance; a pair whose feature sits on a bin edge may land in the neighbouring bin because
+    # atan2f differs by an ulp between glibc and the device library -> allow a small fraction of points to differ
+    close = np.isclose(hg, ho, rtol=1e-4, atol=1e-3).all(axis=1)
+    assert close.mean() > 0.995, close.mean()
+    np.testing.assert_allclose(hg.reshape(-1, 3, 11).sum(-1), 100.0, rtol=1e-4)
+
+
+def test_pair_pipeline_fpfh_nnr(ctx, api, oracle, synth, tls):
+    """BASELINE configs[2] shape (FPFH feature + reciprocal NN) at test scale, vs the oracle pipeline."""
+    cfg = api.pair_config(api.FEATURE_FPFH, api.CORR_NNR, 6, 0.6, 0.1, 0.5, 1.5, None, max_iter=60)
+    stats, tr = ctx.register_pair(cfg, tls.source, tls.target)
+    ds, kp, hist = {}, {}, {}
+    for name, cloud in (("T", tls.target), ("S", tls.source)):
+        ds[name] = cloud[oracle.voxel_filter(cloud, 0.1)]
+        kp[name], _ = oracle.keypoints(ds[name], 0.5, 1.5)
+        hist[name] = oracle.fpfh(ds[name])[1][kp[name]]
+    assert (stats.k_s, stats.k_t) == (kp["S"].size, kp["T"].size)
+    FD = oracle.fd_fpfh(hist["S"], hist["T"])
+    P = oracle.default_params(oracle.FPFH, oracle.NNR, 6, 0.6, 1.5, oracle.bbx_magnitude(ds["S"]), max_iter=60)
+    ro = oracle.register(P, ds["S"][kp["S"]].astype(np.float64), ds["T"][kp["T"]].astype(np.float64), FD)
+    Rg = np.array(stats.Rt[:]).reshape(4, 4)
+    assert stats.iterations == ro["iters"]
+    assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
