@@ -1,0 +1,74 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py): the oracle must keep reproducing
+them (CPU), and the HIP path must reproduce them too (GPU)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return {k: np.load(os.path.join(HERE, "golden", k + ".npz")) for k in ("km", "frontend", "loop")}
+
+
+@pytest.fixture(scope="module")
+def gin():
+    mg = importlib.import_module("make_golden")
+    synth, O, tls, ds, g = mg.inputs()
+    return dict(synth=synth, tls=tls, ds=ds, g=g)
+
+
+def test_oracle_reproduces_golden(oracle, gold, gin):
+    np.testing.assert_array_equal(oracle.km(gold["km"]["W3"])[0], gold["km"]["match3"])
+    np.testing.assert_array_equal(oracle.km(gold["km"]["W40"])[0], gold["km"]["match40"])
+    assert gold["km"]["match3"].tolist() == [0, 2, 1]
+    fe, ds, pat = gold["frontend"], gin["ds"], gin["synth"].bsc_pattern_glibc()
+    np.testing.assert_array_equal(oracle.voxel_filter(gin["tls"].target, 0.1), fe["keep"])
+    lam, curv, cnt = oracle.pca(ds, 0.5)
+    np.testing.assert_array_equal(cnt, fe["count"])
+    np.testing.assert_array_equal(lam, fe["lam"])
+    kp = oracle.nms(ds, curv, oracle.prune(lam, cnt), 1.5)
+    np.testing.assert_array_equal(kp, fe["kp"])
+    feat, lcs, _ = oracle.bsc(ds, kp, 1.5, 6, pat)
+    np.testing.assert_array_equal(feat, fe["feat"])
+    np.testing.assert_array_equal(lcs, fe["lcs"])
+    g = gin["g"]
+    kpS, kpT = g.source[g.kp_source].astype(np.float64), g.target[g.kp_target].astype(np.float64)
+    for name, corr in (("nn", oracle.NN), ("nnr", oracle.NNR), ("km", oracle.KM)):
+        r = oracle.register(oracle.default_params(oracle.NONE, corr, 6, 0.9, 1.5, oracle.bbx_magnitude(g.source), max_iter=60), kpS, kpT, want_matchlist=True)
+        np.testing.assert_array_equal(r["matchlist"], gold["loop"][name + "_matchlist"])
+        np.testing.assert_array_equal(r["Rt"], gold["loop"][name + "_Rt"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden(ctx, api, gold, gin):
+    np.testing.assert_array_equal(ctx.km_solve(gold["km"]["W3"]).cpu().numpy(), gold["km"]["match3"])
+    np.testing.assert_array_equal(ctx.km_solve(gold["km"]["W40"]).cpu().numpy(), gold["km"]["match40"])
+    fe, ds, pat = gold["frontend"], gin["ds"], gin["synth"].bsc_pattern_glibc()
+    np.testing.assert_array_equal(ctx.voxel_filter(gin["tls"].target, 0.1).cpu().numpy(), fe["keep"])
+    lam, curv, cnt = ctx.pca_curvature(ds, 0.5)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), fe["count"])
+    assert (lam.cpu().numpy() != fe["lam"]).any(axis=1).sum() <= 3
+    np.testing.assert_array_equal(ctx.keypoints(ds, 0.5, 1.5).cpu().numpy(), fe["kp"])
+    feat, lcs = ctx.bsc_encode(ds, fe["kp"], 1.5, 6, pat)
+    np.testing.assert_array_equal(lcs.cpu().numpy(), fe["lcs"])
+    ham = np.unpackbits(feat.cpu().numpy() ^ fe["feat"], axis=-1).sum(-1)
+    assert ham.max() <= 1 and (ham > 0).sum() <= max(1, fe["kp"].size // 200)
+    nrm, hist = ctx.fpfh(ds[:3000])
+    np.testing.assert_array_equal(nrm.cpu().numpy(), fe["normals"])
+    assert np.isclose(hist.cpu().numpy(), fe["fpfh"], rtol=1e-4, atol=1e-3).all(axis=1).mean() > 0.995
+    g = gin["g"]
+    kpS, kpT = g.source[g.kp_source].astype(np.float64), g.target[g.kp_target].astype(np.float64)
+    import ctypes
+
+    out = ctypes.c_float(0)
+    bbx = ctx.bbx_magnitude(g.source)
+    for name, corr in (("nn", api.CORR_NN), ("nnr", api.CORR_NNR), ("km", api.CORR_KM)):
+        r = ctx.register(api.default_params(api.FEATURE_NONE, corr, 6, 0.9, 1.5, bbx, max_iter=60), kpS, kpT, want_matchlist=True)
+        np.testing.assert_array_equal(r["matchlist"], gold["loop"][name + "_matchlist"])
+        np.testing.assert_allclose(r["Rt"], gold["loop"][name + "_Rt"], rtol=0, atol=1e-6)
