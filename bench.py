@@ -61,8 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hits", type=int, default=1_000_000, help="points per scan (cfg2 = 1M)")
     ap.add_argument("--corr", default="KM", choices=["KM", "NN", "NNR"])
-    ap.add_argument("--pairs-per-step", type=int, default=512, help="independent pairs in flight per GPU per step")
-    ap.add_argument("--streams", type=int, default=2, help="contexts/streams the batch is split over (front end / loop overlap)")
+    ap.add_argument("--pairs-per-step", type=int, default=2048, help="independent pairs in flight per GPU per step")
+    ap.add_argument("--streams", type=int, default=4, help="contexts/streams the batch is split over (front end / loop overlap)")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic pairs generated per rank (cycled inside the batch)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU (oracle) baseline leg")
     args = ap.parse_args()
@@ -99,14 +99,19 @@ def main():
     shards = [[dev[(i * nstream + s) % len(dev)] for i in range((B - s + nstream - 1) // nstream)] for s in range(nstream)]
     results = [None] * nstream
 
-    def run_shard(s):
-        results[s] = ctxs[s].register_pairs(cfg, shards[s])
+    def run_shard(s, nsteps):
+        # every stream works through its shard of each step back to back; the streams are NOT re-synchronised between
+        # steps, so one stream's front end overlaps another stream's KM-bound loop (that is the point of the split)
+        for _ in range(nsteps):
+            results[s] = ctxs[s].register_pairs(cfg, shards[s])
 
-    def step():
-        if nstream == 1:
-            run_shard(0)
+    def run_steps(nsteps):
+        if nsteps <= 0:
             return
-        th = [threading.Thread(target=run_shard, args=(s,)) for s in range(nstream)]
+        if nstream == 1:
+            run_shard(0, nsteps)
+            return
+        th = [threading.Thread(target=run_shard, args=(s, nsteps)) for s in range(nstream)]
         for t in th:
             t.start()
         for t in th:
@@ -118,14 +123,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     for c in ctxs:
         c.kernel_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -61,7 +61,7 @@ enum BufSlot {
   // pair pipeline
   B_P_KEEP_S, B_P_KEEP_T, B_P_DS_S, B_P_DS_T, B_P_KP_S, B_P_KP_T, B_P_KPXYZ_S, B_P_KPXYZ_T, B_P_FEAT_S, B_P_FEAT_T, B_P_LCS,
   B_P_FD, B_P_MISC, B_P_PATTERN,
-  B_KM_LX, B_KM_MISC,
+  B_KM_LX, B_KM_MISC, B_KM_SLACK,
   B_NUM
 };
 

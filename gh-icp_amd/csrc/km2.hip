@@ -34,9 +34,10 @@ struct Km2Problem {
   int* status;              // 0 = ok
   const int* done;          // optional early-exit flag (device)
   long long* steps;         // optional: number of findpath() calls (profiling)
+  double* slack;            // n doubles of global scratch (k_km2)
 };
 
-size_t gh_km2_lds_bytes(int n) { return (size_t)n * 40 + 4 + 2 * (size_t)((n + 31) / 32) * 4 + 64; }
+size_t gh_km2_lds_bytes(int n) { return (size_t)n * 26 + 16 + 2 * (size_t)((n + 31) / 32) * 4 + 64; }
 
 namespace {
 
@@ -65,6 +66,13 @@ __device__ inline int first_clear(const unsigned* __restrict__ bits, int y0, int
   return n;
 }
 
+typedef __attribute__((address_space(1))) const int* gc_int;
+typedef __attribute__((address_space(1))) const double* gc_f64;
+typedef __attribute__((address_space(1))) unsigned long long* g_u64;
+
+// LDS per problem: lx, ly (f64), rptr (u32), match / stack x / stack y (u16), two bitmaps = 26.25 B per row.
+// slack lives in global memory (L2): explicit entries hit it with fire-and-forget 64-bit atomic minima (d >= eps > 0,
+// so the IEEE bit pattern orders like the value), the end of a failed phase reads it with L1-bypassing loads.
 __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs) {
   const Km2Problem P = probs[blockIdx.x];
   if (P.n <= 0 || (P.done && *P.done)) return;
@@ -72,27 +80,32 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
   const int n = P.n, nw = (n + 31) / 32, lane = threadIdx.x;
   double* lx = (double*)smem;
   double* ly = lx + n;
-  double* slack = ly + n;
-  int* match = (int*)(slack + n);
-  int* stx = match + n;
-  int* sty = stx + n;
-  unsigned* rptr = (unsigned*)(sty + n);
-  unsigned* visx = rptr + n + 1;
+  unsigned* rptr = (unsigned*)(ly + n);
+  unsigned* visx = rptr + ((n + 2) & ~1);
   unsigned* visy = visx + nw;
+  unsigned short* match = (unsigned short*)(visy + nw);
+  unsigned short* stx = match + n;
+  unsigned short* sty = stx + n;
+  const gc_int cols = (gc_int)P.cols;
+  const gc_f64 vals = (gc_f64)P.vals;
+  const g_u64 slack = (g_u64)P.slack;
   const double bg = P.bg, eps = P.eps;
+  const int NONE = 0xFFFF;
+  const unsigned long long INF_BITS = (unsigned long long)__double_as_longlong(KM_INF2);
 
-  for (int i = lane; i < n; i += 64) { lx[i] = P.lx_init[i]; ly[i] = 0.0; match[i] = -1; rptr[i] = P.row_ptr[i]; }
+  for (int i = lane; i < n; i += 64) { lx[i] = P.lx_init[i]; ly[i] = 0.0; match[i] = (unsigned short)NONE; rptr[i] = P.row_ptr[i]; }
   if (lane == 0) rptr[n] = P.row_ptr[n];
   __syncthreads();
 
   long long nsteps = 0;
   int bad = 0;
   for (int root = 0; root < n && !bad; ++root) {
-    for (int i = lane; i < n; i += 64) slack[i] = KM_INF2;
+    for (int i = lane; i < n; i += 64) slack[i] = INF_BITS;
+    __threadfence_block();
     for (int phase = 0;; ++phase) {
       for (int i = lane; i < nw; i += 64) { visx[i] = 0u; visy[i] = 0u; }
       __syncthreads();
-      if (lane == 0) { stx[0] = root; sty[0] = -1; visx[root >> 5] = 1u << (root & 31); }
+      if (lane == 0) { stx[0] = (unsigned short)root; sty[0] = (unsigned short)NONE; visx[root >> 5] = 1u << (root & 31); }
       __syncthreads();
       int sp = 0, x = root, ystart = 0;
       double lxmin = lx[root];
@@ -100,6 +113,7 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
       for (;;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
         nsteps++;
         const double lxv = lx[x];
+        lxmin = fmin(lxmin, lxv);
         int best = INT_MAX;
         // ---- explicit entries of row x (E3); non-tight ones feed slack (km.cpp:33)
         const unsigned cb = rptr[x], ce = rptr[x + 1];
@@ -108,13 +122,13 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
           int col = INT_MAX;
           bool tight = false;
           if (c < ce) {
-            col = P.cols[c];
-            const double d = (lxv + ly[col]) - P.vals[c];
+            col = cols[c];
+            const double d = (lxv + ly[col]) - vals[c];
             if (d < eps) tight = col >= ystart && !bit_get(visy, col);
-            else slack[col] = fmin(slack[col], d);
+            else __hip_atomic_fetch_min(&slack[col], (unsigned long long)__double_as_longlong(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           const unsigned long long b = __ballot(tight);
-          if (b) { best = __shfl(col, (int)__ffsll((long long)b) - 1, 64); break; }
+          if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); break; }
         }
         // ---- background entries (E1, E2)
         if ((lxv - bg) < eps) {
@@ -133,50 +147,57 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
         if (best != INT_MAX) {
           const int ystar = best;
           const int m = match[ystar];
-          if (lane == 0) { visy[ystar >> 5] |= 1u << (ystar & 31); sty[sp] = ystar; }
+          if (lane == 0) { visy[ystar >> 5] |= 1u << (ystar & 31); sty[sp] = (unsigned short)ystar; }
           __builtin_amdgcn_wave_barrier();
-          if (m == -1) {  // augment: match[y] = x on every level of the recursion (km.cpp:26-29)
+          if (m == NONE) {  // augment: match[y] = x on every level of the recursion (km.cpp:26-29)
             for (int f = lane; f <= sp; f += 64) match[sty[f]] = stx[f];
             ok = true;
             break;
           }
           sp++;
-          if (lane == 0) { stx[sp] = m; sty[sp] = -1; visx[m >> 5] |= 1u << (m & 31); }
-          lxmin = fmin(lxmin, lx[m]);
+          if (lane == 0) { stx[sp] = (unsigned short)m; sty[sp] = (unsigned short)NONE; visx[m >> 5] |= 1u << (m & 31); }
           x = m; ystart = 0;
         } else {
           sp--;
           if (sp < 0) break;
-          x = stx[sp]; ystart = sty[sp] + 1;
+          x = stx[sp]; ystart = (int)sty[sp] + 1;
         }
         __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
       if (ok) break;
       // ---- failed phase: deferred background slack (E4) + relabel (km.cpp:80-98)
+      __threadfence_block();  // every slack atomic of this phase has reached L2
       double dl = KM_INF2;
-      for (int y = lane; y < n; y += 64)
+      for (int y = lane; y < n; y += 64) {
         if (!bit_get(visy, y)) {
-          const double s = fmin(slack[y], (lxmin + ly[y]) - bg);
-          slack[y] = s;
-          dl = fmin(dl, s);
+          const double cur = __longlong_as_double((long long)__hip_atomic_load(&slack[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          const double s2 = fmin(cur, (lxmin + ly[y]) - bg);
+          dl = fmin(dl, s2);
+          __hip_atomic_store(&slack[y], (unsigned long long)__double_as_longlong(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) dl = fmin(dl, __shfl_xor(dl, o, 64));
+      __threadfence_block();
       for (int i = lane; i < n; i += 64) {
         if (bit_get(visx, i)) lx[i] -= dl;
         if (bit_get(visy, i)) ly[i] += dl;
-        else slack[i] -= dl;
+        else {
+          const double cur = __longlong_as_double((long long)__hip_atomic_load(&slack[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          __hip_atomic_store(&slack[i], (unsigned long long)__double_as_longlong(cur - dl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
+      __threadfence_block();
       __syncthreads();
       if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
     }
   }
   __syncthreads();
-  for (int i = lane; i < n; i += 64) P.match_out[i] = match[i];
+  for (int i = lane; i < n; i += 64) P.match_out[i] = match[i] == NONE ? -1 : (int)match[i];
   if (lane == 0) {
     if (bad && P.status) *P.status = bad;
-    if (P.steps) *P.steps = nsteps;
+    if (P.steps) P.steps[0] = nsteps;
   }
 }
 
@@ -493,7 +514,7 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   return GHICP_OK;
 }
 
-bool gh_km2_fits(int n) { return gh_km2_lds_bytes(n) <= 160 * 1024 - 256; }
+bool gh_km2_fits(int n) { return n <= 65534 && gh_km2_lds_bytes(n) <= 160 * 1024 - 256; }
 
 // dense front door: background = the matrix minimum, everything above it explicit
 int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, int* status_dev) {
@@ -525,6 +546,7 @@ int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32
   memset(&hp, 0, sizeof(hp));
   hp.n = n; hp.bg = bg_h; hp.eps = eps; hp.row_ptr = rptr; hp.cols = cols; hp.vals = vals; hp.lx_init = lx; hp.match_out = match;
   hp.status = status_dev;
+  GH_TRY(ctx->reserve(B_KM_SLACK, (size_t)n + 2, &hp.slack));
   long long* dstats = nullptr;
   if (getenv("GHICP_KM_STATS")) {
     GH_TRY(ctx->reserve(B_P_PATTERN, 16, &dstats));

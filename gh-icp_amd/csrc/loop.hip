@@ -29,6 +29,7 @@ struct Km2Problem {
   int* status;
   const int* done;
   long long* steps;
+  double* slack;
 };
 int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
 bool gh_km2_fits(int n);
@@ -64,7 +65,7 @@ struct LoopProb {
   // KM
   unsigned *km_cnt, *km_rptr;
   int *km_cols, *kmmatch, *km_status;
-  double *km_vals, *km_lx, *kmw;
+  double *km_vals, *km_lx, *kmw, *km_slack;
   Km2Problem* km_desc;
 };
 
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_km_scan_desc(const LoopProb* __restric
     P.km_rptr[n] = (unsigned)carry;
     Km2Problem p;
     p.n = n; p.pad_ = 0; p.bg = -P.st->penalty; p.eps = P.C.km_eps; p.row_ptr = P.km_rptr; p.cols = P.km_cols; p.vals = P.km_vals;
-    p.lx_init = P.km_lx; p.match_out = P.kmmatch; p.status = P.km_status; p.done = &P.st->done; p.steps = nullptr;
+    p.lx_init = P.km_lx; p.match_out = P.kmmatch; p.status = P.km_status; p.done = &P.st->done; p.steps = nullptr; p.slack = P.km_slack;
     *P.km_desc = p;
   }
 }
@@ -589,6 +590,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
           L.km_cnt = cv.take<unsigned>((size_t)C.n + 1);
           L.km_rptr = cv.take<unsigned>((size_t)C.n + 2);
           L.km_lx = cv.take<double>((size_t)C.n + 1);
+          L.km_slack = cv.take<double>((size_t)C.n + 2);
           L.km_cols = cv.take<int>((size_t)ks * kt + 1);
           L.km_vals = cv.take<double>((size_t)ks * kt + 1);
           L.km_desc = d_descs ? d_descs + b : nullptr;

@@ -13,6 +13,10 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cmath>
+#include <cstdlib>
+#include "devmath.h"
+
 namespace {
 
 struct GridArgs {
@@ -90,6 +94,103 @@ __global__ __launch_bounds__(256) void k_nms_round(GridArgs G, float r2, int* __
   atomicAdd(undecided, 1);
 }
 
+// Exact greedy NMS in ONE launch: a single 1024-thread workgroup walks the rank-ordered candidates in chunks.
+//   (1) a candidate within R of an already selected keypoint is suppressed (selected keypoints live in per-cell linked
+//       lists: they are >= R apart, so a 27-cell probe touches a handful of them instead of hundreds of candidates);
+//   (2) the chunk's survivors (compacted in rank order into LDS) settle their mutual conflicts by the same
+//       fixed-point rule as k_nms_round, now over LDS;
+//   (3) winners are appended to the output in rank order and pushed into the selected grid for the next chunk.
+constexpr int NMS_T = 256;
+constexpr int NMS_SEL_CAP = 4096;  // selected keypoints kept in LDS (48 KB); beyond that the grid lists take over
+__global__ __launch_bounds__(NMS_T) void k_nms_greedy(const float* __restrict__ cpts, int c, GridDesc g, float r2, int* __restrict__ head,
+                                                      int* __restrict__ next, const int* __restrict__ cand, const int* __restrict__ ord,
+                                                      int* __restrict__ kp, int* __restrict__ kcount) {
+  __shared__ float sx[NMS_T], sy[NMS_T], sz[NMS_T];
+  __shared__ float selx[NMS_SEL_CAP], sely[NMS_SEL_CAP], selz[NMS_SEL_CAP];
+  __shared__ int srank[NMS_T];
+  __shared__ unsigned char sst[NMS_T];
+  __shared__ int scan[17];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  int nsel_total = 0;
+  for (int base = 0; base < c; base += NMS_T) {
+    const int r = base + tid;
+    bool alive = r < c;
+    float px = 0, py = 0, pz = 0;
+    if (alive) { px = cpts[(size_t)r * 3]; py = cpts[(size_t)r * 3 + 1]; pz = cpts[(size_t)r * 3 + 2]; }
+    if (alive && nsel_total <= NMS_SEL_CAP) {  // brute force over the LDS list (broadcast reads)
+      for (int j = 0; j < nsel_total; j++) {
+        const float dx = selx[j] - px, dy = sely[j] - py, dz = selz[j] - pz;
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        if (d2 < r2) { alive = false; break; }
+      }
+    } else if (alive) {
+      const int cx = gh_cell_coord(px, g.mn[0], g.inv, g.dim[0]);
+      const int cy = gh_cell_coord(py, g.mn[1], g.inv, g.dim[1]);
+      const int cz = gh_cell_coord(pz, g.mn[2], g.inv, g.dim[2]);
+      for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dim[0] - 1) && alive; x++)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dim[1] - 1) && alive; y++)
+          for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dim[2] - 1) && alive; z++)
+            for (int j = head[((unsigned)x * g.dim[1] + y) * g.dim[2] + z]; j >= 0; j = next[j]) {
+              const float dx = cpts[(size_t)j * 3] - px, dy = cpts[(size_t)j * 3 + 1] - py, dz = cpts[(size_t)j * 3 + 2] - pz;
+              float d2 = dx * dx;
+              d2 += dy * dy;
+              d2 += dz * dz;
+              if (d2 < r2) { alive = false; break; }
+            }
+    }
+    int ns;
+    const int pos = gh_block_excl_scan(alive ? 1 : 0, scan, &ns);
+    __syncthreads();
+    if (alive) { sx[pos] = px; sy[pos] = py; sz[pos] = pz; srank[pos] = r; sst[pos] = 0; }
+    __syncthreads();
+    for (int guard = 0; guard <= NMS_T; guard++) {
+      if (tid == 0) s_flag = 0;
+      __syncthreads();
+      if (tid < ns && sst[tid] == 0) {
+        bool pending = false, killed = false;
+        const float qx = sx[tid], qy = sy[tid], qz = sz[tid];
+        for (int j = 0; j < tid; j++) {
+          const unsigned char sj = sst[j];
+          if (sj == 2) continue;
+          const float dx = sx[j] - qx, dy = sy[j] - qy, dz = sz[j] - qz;
+          float d2 = dx * dx;
+          d2 += dy * dy;
+          d2 += dz * dz;
+          if (d2 < r2) {
+            if (sj == 1) { killed = true; break; }
+            pending = true;
+          }
+        }
+        if (killed) sst[tid] = 2;
+        else if (!pending) sst[tid] = 1;
+        else s_flag = 1;
+      }
+      __syncthreads();
+      if (!s_flag) break;
+      __syncthreads();
+    }
+    const bool sel = tid < ns && sst[tid] == 1;
+    int nsel;
+    const int opos = gh_block_excl_scan(sel ? 1 : 0, scan, &nsel);
+    if (sel) {
+      const int rr = srank[tid];
+      kp[nsel_total + opos] = cand[ord[rr]];
+      if (nsel_total + opos < NMS_SEL_CAP) { selx[nsel_total + opos] = sx[tid]; sely[nsel_total + opos] = sy[tid]; selz[nsel_total + opos] = sz[tid]; }
+      const int cx = gh_cell_coord(sx[tid], g.mn[0], g.inv, g.dim[0]);
+      const int cy = gh_cell_coord(sy[tid], g.mn[1], g.inv, g.dim[1]);
+      const int cz = gh_cell_coord(sz[tid], g.mn[2], g.inv, g.dim[2]);
+      next[rr] = atomicExch(&head[((unsigned)cx * g.dim[1] + cy) * g.dim[2] + cz], rr);
+    }
+    nsel_total += nsel;
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (tid == 0) *kcount = nsel_total;
+}
+
 __global__ __launch_bounds__(256) void k_nms_flags(const int* __restrict__ state, int c, unsigned char* __restrict__ flags) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r < c) flags[r] = state[r] == SELECTED ? 1 : 0;
@@ -133,20 +234,52 @@ int gh_nms_dev(ghicp_ctx* ctx, const float* xyz, int stride, const double* curva
   GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
   GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, keys, keys2, vals, ord, (int)c, 0, 64, s));  // stable
   hipLaunchKernelGGL(k_nms_points, dim3(cdiv(c, 256)), dim3(256), 0, s, xyz, stride, cand, ord, (int)c, cpts);
+  const float r2 = (float)((double)radius * (double)radius);
+  int* hflag = reinterpret_cast<int*>(ctx->pinned);
+  if (!getenv("GHICP_NMS_ROUNDS")) {
+    // ---- single-launch exact greedy NMS over a grid of SELECTED keypoints
+    float mm[6];
+    GH_TRY(gh_bbox_dev(ctx, cpts, c, 3, mm));
+    GridDesc g;
+    memset(&g, 0, sizeof(g));
+    float cell = radius * 1.0001f;
+    for (;;) {
+      g.inv = 1.0f / cell;
+      unsigned long long nc = 1;
+      for (int d = 0; d < 3; d++) {
+        g.mn[d] = mm[d];
+        g.dim[d] = (int)std::floor((mm[3 + d] - mm[d]) * g.inv) + 1;
+        if (g.dim[d] < 1) g.dim[d] = 1;
+        nc *= (unsigned long long)g.dim[d];
+      }
+      if (nc <= (1ull << 26)) { g.ncell = (unsigned)nc; break; }
+      cell *= 1.5f;
+    }
+    g.n = (int)c;
+    int *head, *next;
+    GH_TRY(ctx->reserve(B_GRID_START, (size_t)g.ncell + 2, &head));
+    GH_TRY(ctx->reserve(B_FE_STATE, (size_t)c + 1, &next));
+    GH_HIP(hipMemsetAsync(head, 0xff, (size_t)g.ncell * sizeof(int), s));
+    hipEvent_t kev = ctx->kt_begin(KT_NMS_ROUND);
+    hipLaunchKernelGGL(k_nms_greedy, dim3(1), dim3(NMS_T), 0, s, cpts, (int)c, g, r2, head, next, cand, ord, kp, misc);
+    ctx->kt_end(KT_NMS_ROUND, kev);
+    GH_HIP(hipGetLastError());
+    GH_HIP(hipMemcpyAsync(hflag, misc, sizeof(int), hipMemcpyDeviceToHost, s));
+    GH_HIP(hipStreamSynchronize(s));
+    *k_out = hflag[0];
+    return GHICP_OK;
+  }
+  // ---- multi-launch fixed-point rounds (kept as a cross-check: GHICP_NMS_ROUNDS=1)
   DeviceGrid G;
   const GridSlots sl = {B_GRID_KEYS, B_GRID_KEYS2, B_GRID_VALS, B_GRID_VALS2, B_GRID_START, B_GRID_PTS};
   GH_TRY(gh_grid_build(ctx, cpts, c, 3, radius * 1.0001f, sl, &G));  // float4.w of the grid points = rank
   GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
   GH_HIP(hipMemsetAsync(state, 0, (size_t)c * sizeof(int), s));
   GridArgs A = {G.d, G.pts, G.start};
-  const float r2 = (float)((double)radius * (double)radius);
-  int* hflag = reinterpret_cast<int*>(ctx->pinned);
   for (int round = 0;; round++) {
     for (int r = 0; r < 4; r++) {
       GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
-      hipEvent_t kev = ctx->kt_begin(KT_NMS_ROUND);
       hipLaunchKernelGGL(k_nms_round, dim3(cdiv(c, 256)), dim3(256), 0, s, A, r2, state, misc + 1);
-      ctx->kt_end(KT_NMS_ROUND, kev);
     }
     GH_HIP(hipMemcpyAsync(hflag, misc + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));
