@@ -1,0 +1,97 @@
+"""BASELINE.json configs[3] and [4] at test scale, and edge cases of the ABI, on the GPU vs the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import rot_err, trans_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_pair(oracle, synth, S, T, voxel, r_pca, R, dof, corr, est_iou, pat, max_iter=80):
+    ds, kp, feat = {}, {}, {}
+    for name, cloud, d in (("T", T, 0), ("S", S, dof)):
+        ds[name] = cloud[oracle.voxel_filter(cloud, voxel)]
+        kp[name], _ = oracle.keypoints(ds[name], r_pca, R)
+        feat[name], _, _ = oracle.bsc(ds[name], kp[name], R, d, pat)
+    V = 4 if dof == 6 else 2
+    FD = oracle.fd_bsc(feat["S"][:V], feat["T"][0])
+    P = oracle.default_params(oracle.BSC, corr, dof, est_iou, R, oracle.bbx_magnitude(ds["S"]), max_iter=max_iter)
+    return oracle.register(P, ds["S"][kp["S"]].astype(np.float64), ds["T"][kp["T"]].astype(np.float64), FD), kp
+
+
+def test_cfg4_indoor_fragment_batch(ctx, api, oracle, synth):
+    """configs[3]: a batch of 3DMatch-like fragment pairs (voxel 0.025, r 0.10, R 0.30, BSC + NN) through the batched API."""
+    import torch
+
+    pat = synth.bsc_pattern_glibc()
+    pairs = [synth.indoor_pair(i, 60_000) for i in range(3)]
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_NN, 6, 0.6, 0.025, 0.10, 0.30, pat, max_iter=80)
+    stats = ctx.register_pairs(cfg, [(torch.from_numpy(p.source).cuda(), torch.from_numpy(p.target).cuda()) for p in pairs])
+    for p, st in zip(pairs, stats):
+        ro, kp = _oracle_pair(oracle, synth, p.source, p.target, 0.025, 0.10, 0.30, 6, oracle.NN, 0.6, pat)
+        assert (st.k_s, st.k_t, st.iterations) == (kp["S"].size, kp["T"].size, ro["iters"])
+        Rg = np.array(st.Rt[:]).reshape(4, 4)
+        if np.isfinite(ro["Rt"]).all():
+            assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
+        else:
+            assert not np.isfinite(Rg).all()
+
+
+def test_cfg5_four_dof_km(ctx, api, oracle, synth):
+    """configs[4] shape: levelled low-overlap pair, BSC + KM, dof 4 (only 2 source variants, ghicp_reg.cpp:178-182)."""
+    p = synth.tls_pair(120_000, config_id=5)
+    pat = synth.bsc_pattern_glibc()
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, 4, 0.3, 0.1, 0.5, 1.5, pat, max_iter=60)
+    st, tr = ctx.register_pair(cfg, p.source, p.target)
+    ro, kp = _oracle_pair(oracle, synth, p.source, p.target, 0.1, 0.5, 1.5, 4, oracle.KM, 0.3, pat, max_iter=60)
+    assert (st.k_s, st.k_t, st.iterations) == (kp["S"].size, kp["T"].size, ro["iters"])
+    assert [t["cor"] for t in tr] == [t["cor"] for t in ro["trace"]]
+    Rg = np.array(st.Rt[:]).reshape(4, 4)
+    assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
+
+
+def test_edge_cases(ctx, api, oracle):
+    import torch
+
+    # no keypoints at all: the loop does not run, Rt stays identity
+    pg = api.default_params(api.FEATURE_NONE, api.CORR_NN, 6, 0.6, 1.5, 10.0, max_iter=5)
+    r = ctx.register(pg, np.zeros((0, 3)), np.zeros((0, 3)))
+    assert r["iters"] == 0 and np.array_equal(r["Rt"], np.eye(4))
+    # fewer than min_cor correspondences: one iteration, converged flag (ghicp_reg.cpp:796)
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(6, 3))
+    ro = oracle.register(oracle.default_params(oracle.NONE, oracle.NN, 6, 0.6, 1.5, 10.0, max_iter=5), a, a + 0.01)
+    rg = ctx.register(pg, a, a + 0.01)
+    assert rg["iters"] == ro["iters"] == 1 and rg["trace"][0]["converged"] == 1
+    np.testing.assert_allclose(rg["Rt"], ro["Rt"], atol=1e-6)
+    # max_iter guard
+    pk = api.default_params(api.FEATURE_NONE, api.CORR_NNR, 6, 0.6, 1.5, 100.0, max_iter=2)
+    b = rng.normal(size=(200, 3)) * 5
+    assert ctx.register(pk, b, b[::-1] + 1.0)["iters"] <= 2
+    # argument validation returns an error code and a message instead of crashing
+    bad = api.default_params(api.FEATURE_BSC, api.CORR_KM, 6, 0.6, 1.5, 10.0, max_iter=5)
+    with pytest.raises(api.GhicpError):
+        ctx.register(bad, a, a)  # BSC without an FD matrix
+    with pytest.raises(api.GhicpError):
+        ctx.voxel_filter(a.astype(np.float32), -1.0)
+    with pytest.raises(api.GhicpError):
+        ctx.bsc_encode(a.astype(np.float32), np.zeros(1, np.int32), 1.5, 6, np.full((49, 2), 77))
+    # empty cloud front end
+    assert ctx.keypoints(np.zeros((0, 3), np.float32), 0.5, 1.5).numel() == 0
+    assert ctx.voxel_filter(np.zeros((0, 3), np.float32), 0.1).numel() == 0
+    # a tiny cloud: nothing survives the prune (ptNum > 20), the pair API still returns cleanly
+    tiny = torch.from_numpy(rng.normal(size=(50, 3)).astype(np.float32)).cuda()
+    st, _ = ctx.register_pair(api.pair_config(api.FEATURE_BSC, api.CORR_NN, 6, 0.6, 0.1, 0.5, 1.5, None, max_iter=5), tiny, tiny)
+    assert (st.k_s, st.k_t, st.iterations) == (0, 0, 0)
+    # host-pointer mode of the C ABI (what the C++ drop-in classes use)
+    lib = ctx.lib
+    h = ctypes.c_void_p()
+    assert lib.ghicp_ctx_create(0, ctypes.byref(h)) == 0
+    lib.ghicp_ctx_set_host_pointers(h, 1)
+    W = np.ascontiguousarray([[-5, -2, -100], [-4, -2, -6], [-100, -1, -7]], dtype=np.float64)
+    m = np.zeros(3, np.int32)
+    assert lib.ghicp_km_solve(h, W.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(3), ctypes.c_double(0.01), m.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert m.tolist() == [0, 2, 1]
+    lib.ghicp_ctx_destroy(h)
