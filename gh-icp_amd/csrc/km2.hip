@@ -73,7 +73,7 @@ typedef __attribute__((address_space(1))) unsigned long long* g_u64;
 // LDS per problem: lx, ly (f64), rptr (u32), match / stack x / stack y (u16), two bitmaps = 26.25 B per row.
 // slack lives in global memory (L2): explicit entries hit it with fire-and-forget 64-bit atomic minima (d >= eps > 0,
 // so the IEEE bit pattern orders like the value), the end of a failed phase reads it with L1-bypassing loads.
-__global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs) {
+__global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs, int flags) {
   const Km2Problem P = probs[blockIdx.x];
   if (P.n <= 0 || (P.done && *P.done)) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,6 +115,72 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
         const double lxv = lx[x];
         lxmin = fmin(lxmin, lxv);
         int best = INT_MAX;
+        // ---- E6 (experimental, OFF by default: measured 1.5-2.5x SLOWER on the cfg2 matrices because every lane walks a
+        // whole CSR row from L2 and runs are cut short by live children): retire runs of IMMEDIATELY DEAD children,
+        // 64 columns per wave iteration.
+        // A background-tight row selects every unvisited background-tight column in ascending order (E3) and
+        // recurses into its owner c = match[y].  findpath(c) returns false at once -- having visited nothing but c --
+        // when c has no background-tight edge (E2) and none of its explicit entries is tight and still unvisited,
+        // where "visited" at that moment = visited now, or inside [u, y] (every column of that span is visited by
+        // then: this holds for all lanes below the first lane that needs the generic path).  Retiring such a child
+        // is exactly what the recursion does: visy[y], visx[c], slack minima of c's explicit entries, lx[c] into lxmin.
+        if (!(flags & 1)) {
+          if ((lxv - bg) < eps) {
+            for (;;) {
+              const int u = first_clear(visy, ystart, n, nw, lane);
+              if (u >= n) break;
+              const int y = u + lane;
+              bool unv = false, tbg = false;
+              int c = NONE;
+              if (y < n) {
+                unv = !bit_get(visy, y);
+                if (unv) { tbg = ((lxv + ly[y]) - bg) < eps; c = match[y]; }
+              }
+              bool stop = unv && !tbg;  // the generic path must look at this column (it may be explicit-tight, or skipped)
+              bool deadc = false;
+              double lxc = 0.0;
+              if (unv && tbg) {
+                if (c == NONE) stop = true;  // free column: the generic path takes it and augments
+                else {
+                  lxc = lx[c];
+                  if ((lxc - bg) < eps) stop = true;  // the child has background-tight edges of its own
+                  else {
+                    bool live = false;
+                    const unsigned re = rptr[c + 1];
+                    for (unsigned e = rptr[c]; e < re; e++) {
+                      const int col = cols[e];
+                      if (((lxc + ly[col]) - vals[e]) < eps && !bit_get(visy, col) && (col < u || col > y)) { live = true; break; }
+                    }
+                    if (live) stop = true;
+                    else deadc = true;
+                  }
+                }
+              }
+              const unsigned long long bs = __ballot(stop);
+              const int L = bs ? (int)__ffsll((long long)bs) - 1 : 64;  // lanes below L are decided
+              const bool commit = deadc && lane < L;
+              double lm = 1.0e300;
+              if (commit) {
+                atomicOr(&visy[y >> 5], 1u << (y & 31));
+                atomicOr(&visx[c >> 5], 1u << (c & 31));
+                lm = lxc;
+                const unsigned re = rptr[c + 1];
+                for (unsigned e = rptr[c]; e < re; e++) {  // km.cpp:33 for the child's non-tight entries
+                  const int col = cols[e];
+                  const double d = (lxc + ly[col]) - vals[e];
+                  if (!(d < eps)) __hip_atomic_fetch_min(&slack[col], (unsigned long long)__double_as_longlong(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) lm = fmin(lm, __shfl_xor(lm, o, 64));
+              lxmin = fmin(lxmin, lm);
+              __builtin_amdgcn_wave_barrier();
+              if (L < 64) { ystart = u + L; break; }
+              ystart = u + 64;
+              if (ystart >= n) break;
+            }
+          }
+        }
         // ---- explicit entries of row x (E3); non-tight ones feed slack (km.cpp:33)
         const unsigned cb = rptr[x], ce = rptr[x + 1];
         for (unsigned c0 = cb; c0 < ce; c0 += 64) {
@@ -508,7 +574,7 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   const size_t lds = v3 ? gh_km3_lds_bytes(n_max) : gh_km2_lds_bytes(n_max);
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
   if (v3) hipLaunchKernelGGL(k_km3, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
-  else hipLaunchKernelGGL(k_km2, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
+  else hipLaunchKernelGGL(k_km2, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_E6") ? 0 : 1);  // E6 (batched dead children) is exact but slower: off unless GHICP_KM_E6=1
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
