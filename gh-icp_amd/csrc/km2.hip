@@ -66,6 +66,28 @@ __device__ inline int first_clear(const unsigned* __restrict__ bits, int y0, int
   return n;
 }
 
+
+// First unvisited background-tight column in [start, limit): groups of 4 x 64 columns, the eight LDS reads of a group
+// issued together, ballots taken in ascending column order.  (Measured alternatives, all exact, all slower on the cfg2
+// matrices: one 64-column block per round; a 16 x 64 full sweep; a monotone "first unvisited" hint.)
+__device__ inline int bg_scan(const unsigned* __restrict__ visy, const double* __restrict__ ly, double lxv, double bg, double eps, int start,
+                              int limit, int lane) {
+  for (int y0 = start; y0 < limit; y0 += 256) {
+    bool t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int y = y0 + 64 * k + lane;
+      t[k] = (y < limit) && !((visy[y >> 5] >> (y & 31)) & 1u) && ((lxv + ly[y]) - bg) < eps;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned long long b = __ballot(t[k]);
+      if (b) return y0 + 64 * k + (int)__ffsll((long long)b) - 1;
+    }
+  }
+  return INT_MAX;
+}
+
 typedef __attribute__((address_space(1))) const int* gc_int;
 typedef __attribute__((address_space(1))) const double* gc_f64;
 typedef __attribute__((address_space(1))) unsigned long long* g_u64;
@@ -108,6 +130,7 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
       if (lane == 0) { stx[0] = (unsigned short)root; sty[0] = (unsigned short)NONE; visx[root >> 5] = 1u << (root & 31); }
       __syncthreads();
       int sp = 0, x = root, ystart = 0;
+      int par_sp = -1, par_x = 0, par_ys = 0;  // register copy of the frame we just descended from
       double lxmin = lx[root];
       bool ok = false;
       for (;;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
@@ -198,17 +221,7 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
         }
         // ---- background entries (E1, E2)
         if ((lxv - bg) < eps) {
-          int y0 = ystart;
-          for (;;) {
-            y0 = first_clear(visy, y0, n, nw, lane);
-            if (y0 >= n || y0 >= best) break;
-            const int y = y0 + lane;
-            bool t = false;
-            if (y < n && !bit_get(visy, y)) t = ((lxv + ly[y]) - bg) < eps;
-            const unsigned long long b = __ballot(t);
-            if (b) { best = min(best, y0 + (int)__ffsll((long long)b) - 1); break; }
-            y0 += 64;
-          }
+          best = min(best, bg_scan(visy, ly, lxv, bg, eps, ystart, min(n, best), lane));
         }
         if (best != INT_MAX) {
           const int ystar = best;
@@ -220,13 +233,15 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
             ok = true;
             break;
           }
+          par_sp = sp; par_x = x; par_ys = ystar + 1;
           sp++;
           if (lane == 0) { stx[sp] = (unsigned short)m; sty[sp] = (unsigned short)NONE; visx[m >> 5] |= 1u << (m & 31); }
           x = m; ystart = 0;
         } else {
           sp--;
           if (sp < 0) break;
-          x = stx[sp]; ystart = (int)sty[sp] + 1;
+          if (sp == par_sp) { x = par_x; ystart = par_ys; par_sp = -1; }
+          else { x = stx[sp]; ystart = (int)sty[sp] + 1; }
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(64) void k_km3(const Km2Problem* __restrict__ probs
   for (int x = 0; x < n; x++) build_list(x);
   __syncthreads();
 
-  long long nsteps = 0, n_over = 0, n_flat = 0, n_failph = 0, n_failrows = 0, cyc_dfs = 0, cyc_fail = 0, cyc_init = 0;
+  long long nsteps = 0, n_over = 0, n_flat = 0, n_failph = 0, n_failrows = 0, cyc_dfs = 0, cyc_fail = 0, cyc_init = 0, cycA = 0, cycB = 0, cycC = 0, cycD = 0, cycE = 0;
   const long long t_start = __builtin_readcyclecounter();
   int bad = 0;
   for (int root = 0; root < n && !bad; ++root) {
@@ -345,18 +360,20 @@ __global__ __launch_bounds__(64) void k_km3(const Km2Problem* __restrict__ probs
       if (lane == 0) { stx[0] = (unsigned short)root; sty[0] = (unsigned short)NONE; visx[root >> 5] = 1u << (root & 31); }
       __syncthreads();
       int sp = 0, x = root, ystart = 0;
+      int par_sp = -1, par_x = 0, par_ys = 0;  // register copy of the frame we just descended from
       double lxmin = lx[root];
       bool ok = false;
       for (;;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
         nsteps++;
+        const long long tA0 = __builtin_readcyclecounter();
         // ---- LDS round trip A: the row record and the visited bitmap (independent addresses, issued together)
         const double lxv = lx[x];
         const int tn = tln[x];
         int colL = 0xFFFF;
         double valL = 0.0;
         if (lane < TL_CAP) { colL = tlc[x * TL_CAP + lane]; valL = tlv[x * TL_CAP + lane]; }
-        const int u = first_clear(visy, ystart, n, nw, lane);  // first unvisited column >= ystart (n if none)
         lxmin = fmin(lxmin, lxv);
+        const long long tA1 = __builtin_readcyclecounter(); cycA += tA1 - tA0;
         // ---- LDS round trip B: every gather the decision needs
         const bool act = lane < (tn & 0x7f);
         double lyc = 0.0, lyu = 0.0;
@@ -364,53 +381,40 @@ __global__ __launch_bounds__(64) void k_km3(const Km2Problem* __restrict__ probs
         int mL = NONE, mU = NONE;
         if (act) { lyc = ly[colL]; visw = visy[colL >> 5]; mL = match[colL]; }
         const bool pen_tight = (lxv - bg) < eps;  // E2
-        if (pen_tight && u < n) { lyu = ly[u]; mU = match[u]; }
+        (void)lyu; (void)mU;
+        const long long tB1 = __builtin_readcyclecounter(); cycB += tB1 - tA1;
         // ---- decide
         const bool tl = act && colL >= ystart && !((visw >> (colL & 31)) & 1u) && ((lxv + lyc) - valL) < eps;
         const unsigned long long bl = __ballot(tl);
         int best = INT_MAX, mbest = NONE;
-        if (pen_tight && u < n && ((lxv + lyu) - bg) < eps) {
-          best = u; mbest = mU;  // every unvisited column is >= u, and background-tight implies tight (E3)
-        } else {
-          if (bl) {
-            const int l = (int)__ffsll((long long)bl) - 1;
-            best = __builtin_amdgcn_readlane(colL, l);
-            mbest = __builtin_amdgcn_readlane(mL, l);
-          } else if (tn & 0x80) {  // more tight explicit entries than the list holds: scan the CSR row beyond it
-            n_over++;
-            const int from = max(ystart, __builtin_amdgcn_readlane(colL, TL_CAP - 1) + 1);
-            const unsigned cb = P.row_ptr[x], ce = P.row_ptr[x + 1];
-            for (unsigned c0 = cb; c0 < ce; c0 += 64) {
-              const unsigned c = c0 + lane;
-              int col = INT_MAX;
-              bool tight = false;
-              if (c < ce) {
-                col = P.cols[c];
-                tight = col >= from && !bit_get(visy, col) && ((lxv + ly[col]) - P.vals[c]) < eps;
-              }
-              const unsigned long long b = __ballot(tight);
-              if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); mbest = match[best]; break; }
+        if (bl) {
+          const int l = (int)__ffsll((long long)bl) - 1;
+          best = __builtin_amdgcn_readlane(colL, l);
+          mbest = __builtin_amdgcn_readlane(mL, l);
+        } else if (tn & 0x80) {  // more tight explicit entries than the list holds: scan the CSR row beyond it
+          n_over++;
+          const int from = max(ystart, __builtin_amdgcn_readlane(colL, TL_CAP - 1) + 1);
+          const unsigned cb = P.row_ptr[x], ce = P.row_ptr[x + 1];
+          for (unsigned c0 = cb; c0 < ce; c0 += 64) {
+            const unsigned c = c0 + lane;
+            int col = INT_MAX;
+            bool tight = false;
+            if (c < ce) {
+              col = P.cols[c];
+              tight = col >= from && !bit_get(visy, col) && ((lxv + ly[col]) - P.vals[c]) < eps;
             }
-          }
-          if (pen_tight && u < n) {  // u itself is not background-tight (ly[u] grew): look for a later one below `best`
-            n_flat++;
-            int y0 = u + 1;
-            for (;;) {
-              y0 = first_clear(visy, y0, n, nw, lane);
-              if (y0 >= n || y0 >= best) break;
-              const int y = y0 + lane;
-              bool t = false;
-              if (y < n && !bit_get(visy, y)) t = ((lxv + ly[y]) - bg) < eps;
-              const unsigned long long b = __ballot(t);
-              if (b) {
-                const int yy = y0 + (int)__ffsll((long long)b) - 1;
-                if (yy < best) { best = yy; mbest = match[yy]; }
-                break;
-              }
-              y0 += 64;
-            }
+            const unsigned long long b = __ballot(tight);
+            if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); mbest = match[best]; break; }
           }
         }
+        const long long tC0 = __builtin_readcyclecounter();
+        cycE += tC0 - tB1;
+        if (pen_tight) {  // background entries (E1-E3): lowest unvisited background-tight column below `best`
+          n_flat++;
+          const int yb = bg_scan(visy, ly, lxv, bg, eps, ystart, min(n, best), lane);
+          if (yb < best) { best = yb; mbest = match[yb]; }
+        }
+        const long long tC1 = __builtin_readcyclecounter(); cycC += tC1 - tB1;
         if (best != INT_MAX) {
           const int ystar = best;
           if (lane == 0) { visy[ystar >> 5] |= 1u << (ystar & 31); sty[sp] = (unsigned short)ystar; }
@@ -420,14 +424,17 @@ __global__ __launch_bounds__(64) void k_km3(const Km2Problem* __restrict__ probs
             ok = true;
             break;
           }
+          par_sp = sp; par_x = x; par_ys = ystar + 1;
           sp++;
           if (lane == 0) { stx[sp] = (unsigned short)mbest; sty[sp] = NONE; visx[mbest >> 5] |= 1u << (mbest & 31); }
           x = mbest; ystart = 0;
         } else {
           sp--;
           if (sp < 0) break;
-          x = stx[sp]; ystart = (int)sty[sp] + 1;
+          if (sp == par_sp) { x = par_x; ystart = par_ys; par_sp = -1; }
+          else { x = stx[sp]; ystart = (int)sty[sp] + 1; }
         }
+        cycD += __builtin_readcyclecounter() - tC1;
         __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
@@ -489,6 +496,7 @@ __global__ __launch_bounds__(64) void k_km3(const Km2Problem* __restrict__ probs
     if (P.steps) {
       P.steps[0] = nsteps; P.steps[1] = n_over; P.steps[2] = n_flat; P.steps[3] = n_failph; P.steps[4] = n_failrows;
       P.steps[5] = cyc_dfs; P.steps[6] = cyc_fail; P.steps[7] = __builtin_readcyclecounter() - t_start; (void)cyc_init;
+      P.steps[8] = cycA; P.steps[9] = cycB; P.steps[10] = cycC; P.steps[11] = cycD; P.steps[12] = cycE;
     }
   }
 }
@@ -615,18 +623,18 @@ int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32
   GH_TRY(ctx->reserve(B_KM_SLACK, (size_t)n + 2, &hp.slack));
   long long* dstats = nullptr;
   if (getenv("GHICP_KM_STATS")) {
-    GH_TRY(ctx->reserve(B_P_PATTERN, 16, &dstats));
-    GH_HIP(hipMemsetAsync(dstats, 0, 8 * sizeof(long long), s));
+    GH_TRY(ctx->reserve(B_P_PATTERN, 32, &dstats));
+    GH_HIP(hipMemsetAsync(dstats, 0, 13 * sizeof(long long), s));
     hp.steps = dstats;
   }
   GH_HIP(hipMemcpyAsync(dp, &hp, sizeof(hp), hipMemcpyHostToDevice, s));
   GH_TRY(gh_km2_launch(ctx, dp, 1, n));
   if (dstats) {
-    long long h[8];
+    long long h[13];
     GH_HIP(hipMemcpyAsync(h, dstats, sizeof(h), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));
-    fprintf(stderr, "[km stats] n=%d steps=%lld overflow=%lld flat=%lld failph=%lld failrows=%lld cyc_dfs=%lld cyc_fail=%lld cyc_total=%lld\n", n, h[0], h[1],
-            h[2], h[3], h[4], h[5], h[6], h[7]);
+    fprintf(stderr, "[km stats] n=%d steps=%lld overflow=%lld flat=%lld failph=%lld failrows=%lld cyc_dfs=%lld cyc_fail=%lld cyc_total=%lld | A=%lld B=%lld C=%lld (list+overflow %lld) D=%lld\n", n, h[0], h[1],
+            h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[12], h[11]);
   }
   return GHICP_OK;
 }
