@@ -50,6 +50,8 @@ EXPORTS = [
     "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
     "ghicp_register_pairs",
+    "ghicp_icp_params_default", "ghicp_cal_overlap", "ghicp_icp", "ghicp_knn_normals", "ghicp_nn_search", "ghicp_inv_transform",
+    "ghicp_transform_cloud_f32",
 ]
 
 _lib = None
@@ -79,6 +81,39 @@ def default_params(feature=FEATURE_BSC, corr=CORR_KM, dof=6, est_iou=0.6, radius
     p.feature, p.corr, p.dof, p.est_iou, p.radius_nonmax = feature, corr, dof, est_iou, radius_nonmax
     p.bbx_magnitude, p.max_iter = bbx_magnitude, max_iter
     return p
+
+
+ICP_POINT_TO_POINT, ICP_POINT_TO_PLANE = 0, 1
+
+
+class IcpParams(C.Structure):
+    """ghicp_icp_params: the arguments of CRegistration::icp_reg / ptplicp_reg (common_reg.cpp:45-55, 122-133)."""
+    _fields_ = [("max_iter", C.c_int32), ("use_reciprocal", C.c_int32), ("use_trimmed", C.c_int32), ("metric", C.c_int32),
+                ("thre_dis", C.c_float), ("min_overlap", C.c_float), ("covariance_k", C.c_int32), ("pad_", C.c_int32),
+                ("transformation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double)]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("done", C.c_int32), ("iterations", C.c_int32), ("converged", C.c_int32), ("reason", C.c_int32),
+                ("correspondences", C.c_int64), ("overlap", C.c_float), ("pad_", C.c_float),
+                ("mse", C.c_double), ("fitness", C.c_double)]
+
+
+def icp_params(max_iter=50, reciprocal=False, trimmed=False, metric=ICP_POINT_TO_POINT, thre_dis=0.5, min_overlap=0.1,
+               covariance_k=15) -> IcpParams:
+    p = IcpParams()
+    load().ghicp_icp_params_default(C.byref(p))
+    p.max_iter, p.use_reciprocal, p.use_trimmed, p.metric = max_iter, int(reciprocal), int(trimmed), metric
+    p.thre_dis, p.min_overlap, p.covariance_k = thre_dis, min_overlap, covariance_k
+    return p
+
+
+def inv_transform(T):
+    """CRegistration::invTransform (common_reg.cpp:357-370), host-side."""
+    T = np.ascontiguousarray(T, np.float32)
+    out = np.zeros(16, np.float32)
+    load().ghicp_inv_transform(T.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out.reshape(4, 4)
 
 
 def _ptr(t):
@@ -290,6 +325,52 @@ class Context:
         out = t.empty((x.shape[0], 3), dtype=t.float32, device=self.dev)
         self._check(self.lib.ghicp_transform_cloud(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], Rt.ctypes.data_as(C.POINTER(C.c_double)), _ptr(out)))
         return out
+
+    # ---------------------------------------------------------------- fine registration (common_reg)
+    def cal_overlap(self, c1, c2, thre_dis):
+        a, b = self._xyz(c1), self._xyz(c2)
+        r = C.c_float(0)
+        self._check(self.lib.ghicp_cal_overlap(self.h, _ptr(a), C.c_int64(a.shape[0]), a.shape[1], _ptr(b), C.c_int64(b.shape[0]), b.shape[1],
+                                               C.c_float(thre_dis), C.byref(r)))
+        return r.value
+
+    def knn_normals(self, xyz, k):
+        t = self.torch
+        x = self._xyz(xyz)
+        out = t.empty((x.shape[0], 3), dtype=t.float32, device=self.dev)
+        self._check(self.lib.ghicp_knn_normals(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], int(k), _ptr(out)))
+        return out
+
+    def nn_search(self, query, target):
+        t = self.torch
+        q, x = self._xyz(query), self._xyz(target)
+        idx = t.empty((q.shape[0],), dtype=t.int32, device=self.dev)
+        d2 = t.empty((q.shape[0],), dtype=t.float32, device=self.dev)
+        self._check(self.lib.ghicp_nn_search(self.h, _ptr(q), C.c_int64(q.shape[0]), q.shape[1], _ptr(x), C.c_int64(x.shape[0]), x.shape[1],
+                                             _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def transform_cloud_f32(self, xyz, T):
+        t = self.torch
+        x = self._xyz(xyz)
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        out = t.empty((x.shape[0], 3), dtype=t.float32, device=self.dev)
+        self._check(self.lib.ghicp_transform_cloud_f32(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], T.ctypes.data_as(C.POINTER(C.c_float)),
+                                                       _ptr(out)))
+        return out
+
+    def icp(self, xyzS, xyzT, params: IcpParams, want_transformed=True):
+        """icp_reg / ptplicp_reg.  Returns dict(done, T (4,4) f32, transformed tensor, + ghicp_icp_stats fields)."""
+        t = self.torch
+        xS, xT = self._xyz(xyzS), self._xyz(xyzT)
+        T = np.zeros(16, np.float32)
+        out = t.empty((xS.shape[0], 3), dtype=t.float32, device=self.dev) if want_transformed else None
+        st = IcpStats()
+        self._check(self.lib.ghicp_icp(self.h, _ptr(xS), C.c_int64(xS.shape[0]), xS.shape[1], _ptr(xT), C.c_int64(xT.shape[0]), xT.shape[1],
+                                       C.byref(params), T.ctypes.data_as(C.POINTER(C.c_float)), _ptr(out), C.byref(st)))
+        d = {k: getattr(st, k) for k, _ in IcpStats._fields_ if k != "pad_"}
+        d.update(T=T.reshape(4, 4), transformed=out)
+        return d
 
     def register_pair(self, cfg: PairConfig, xyzS, xyzT, want_trace=True):
         xS, xT = self._xyz(xyzS), self._xyz(xyzT)

@@ -62,6 +62,11 @@ enum BufSlot {
   B_P_KEEP_S, B_P_KEEP_T, B_P_DS_S, B_P_DS_T, B_P_KP_S, B_P_KP_T, B_P_KPXYZ_S, B_P_KPXYZ_T, B_P_FEAT_S, B_P_FEAT_T, B_P_LCS,
   B_P_FD, B_P_MISC, B_P_PATTERN,
   B_KM_LX, B_KM_MISC, B_KM_SLACK,
+  // fine registration (icp.hip): coarse target grid, source grids (reciprocal), per-point state
+  B_ICP_TC_KEYS, B_ICP_TC_KEYS2, B_ICP_TC_VALS, B_ICP_TC_VALS2, B_ICP_TC_START, B_ICP_TC_PTS,
+  B_ICP_SC_KEYS, B_ICP_SC_KEYS2, B_ICP_SC_VALS, B_ICP_SC_VALS2, B_ICP_SC_START, B_ICP_SC_PTS,
+  B_ICP_CUR, B_ICP_Q, B_ICP_NN, B_ICP_ND, B_ICP_NN2, B_ICP_ND2, B_ICP_KEYS, B_ICP_KEYS2, B_ICP_SORTTMP, B_ICP_PART, B_ICP_STATE,
+  B_ICP_PEND, B_ICP_TNRM, B_ICP_OUT,
   B_NUM
 };
 
@@ -192,4 +197,5 @@ int gh_register_batch_dev(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs);
 int gh_fd_bsc_dev(ghicp_ctx* ctx, const uint8_t* featS, int ks, int V, const uint8_t* featT, int kt, uint16_t* FD);
 int gh_register_dev(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int ks, const double* kpT, int kt, const void* FD,
                     double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist);
+int gh_knn_normals_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, int k, float* normals);
 int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, const int* done_flag);

@@ -23,7 +23,8 @@ struct GridArgs {
 
 __device__ inline bool pair_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
-__global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int* __restrict__ nn, float* __restrict__ nd, int* __restrict__ nk) {
+// `kk` <= KNN neighbours are kept (rows of nn/nd stay KNN wide; slots >= kk are never filled)
+__global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int kk, int* __restrict__ nn, float* __restrict__ nd, int* __restrict__ nk) {
   const int p = blockIdx.x * 128 + threadIdx.x;
   if (p >= G.d.n) return;
   const float4 P = G.pts[p];
@@ -51,17 +52,17 @@ __global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int* __rest
         float d2 = dx * dx;
         d2 += dy * dy;
         d2 += dz * dz;
-        if (cnt < KNN) {
+        if (cnt < kk) {
 #pragma unroll
           for (int t = 0; t < KNN; t++)
             if (t == cnt) { bd[t] = d2; bi[t] = qi; }
           cnt++;
-          if (cnt == KNN) {  // locate the worst
+          if (cnt == kk) {  // locate the worst
             wpos = 0;
             float wd = bd[0]; int wi = bi[0];
 #pragma unroll
             for (int t = 1; t < KNN; t++)
-              if (pair_less(wd, wi, bd[t], bi[t])) { wpos = t; wd = bd[t]; wi = bi[t]; }
+              if (t < kk && pair_less(wd, wi, bd[t], bi[t])) { wpos = t; wd = bd[t]; wi = bi[t]; }
           }
         } else {
           float wd = 0; int wi = 0;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int* __rest
             int np_ = 0; float nwd = bd[0]; int nwi = bi[0];
 #pragma unroll
             for (int t = 1; t < KNN; t++)
-              if (pair_less(nwd, nwi, bd[t], bi[t])) { np_ = t; nwd = bd[t]; nwi = bi[t]; }
+              if (t < kk && pair_less(nwd, nwi, bd[t], bi[t])) { np_ = t; nwd = bd[t]; nwi = bi[t]; }
             wpos = np_;
           }
         }
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int* __rest
           if (cz + r <= G.d.dim[2] - 1) scan_cell(x, y, cz + r);
         }
       }
-    if (cnt == KNN) {
+    if (cnt == kk) {
       float wd = 0;
 #pragma unroll
       for (int u = 0; u < KNN; u++) if (u == wpos) wd = bd[u];
@@ -114,10 +115,14 @@ __global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int* __rest
 }
 
 __global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, int stride, long long m, const int* __restrict__ nn,
-                                                 const int* __restrict__ nk, float* __restrict__ normals) {
+                                                 const int* __restrict__ nk, float* __restrict__ normals, int check_normals) {
   const long long i = blockIdx.x * 256ll + threadIdx.x;
   if (i >= m) return;
   const int kk = nk[i];
+  if (check_normals && kk < 3) {  // PrincipleComponentAnalysis::CheckNormals (pca.h:258-271): non-finite normal -> 0.577
+    normals[i * 3] = 0.577f; normals[i * 3 + 1] = 0.577f; normals[i * 3 + 2] = 0.577f;
+    return;
+  }
   double c[3] = {0, 0, 0};
   for (int t = 0; t < kk; t++) {
     const long long j = nn[i * KNN + t];
@@ -255,10 +260,36 @@ int gh_fpfh_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float
   GH_TRY(ctx->reserve(B_FE_LAMBDA, (size_t)m * 3 + 3, &nrm));
   if (normals_opt) nrm = normals_opt;
   GridArgs A = {G.d, G.pts, G.start};
-  hipLaunchKernelGGL(k_knn, dim3(cdiv(m, 128)), dim3(128), 0, s, A, cell_eff, nn, nd, nk);
-  hipLaunchKernelGGL(k_normals, dim3(cdiv(m, 256)), dim3(256), 0, s, xyz, stride, m, nn, nk, nrm);
+  hipLaunchKernelGGL(k_knn, dim3(cdiv(m, 128)), dim3(128), 0, s, A, cell_eff, KNN, nn, nd, nk);
+  hipLaunchKernelGGL(k_normals, dim3(cdiv(m, 256)), dim3(256), 0, s, xyz, stride, m, nn, nk, nrm, 0);
   hipLaunchKernelGGL(k_spfh, dim3(cdiv(m, 128)), dim3(128), 0, s, xyz, stride, m, nn, nk, nrm, spfh);
   hipLaunchKernelGGL(k_fpfh, dim3(cdiv(m, 128)), dim3(128), 0, s, m, nn, nd, nk, spfh, hist);
+  GH_HIP(hipGetLastError());
+  return GHICP_OK;
+}
+
+// PrincipleComponentAnalysis::CalculateNormalVector_KNN (include/pca.h:92-109): pcl::NormalEstimation with setKSearch(k)
+// followed by CheckNormals.  Shares the exact-kNN and covariance kernels with the FPFH path; k <= 20.
+int gh_knn_normals_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, int k, float* normals) {
+  if (m <= 0) return GHICP_OK;
+  if (k < 1 || k > KNN) return ctx->fail(GHICP_ERR_ARG, "knn normals: k must be in [1, %d]", KNN);
+  hipStream_t s = ctx->stream;
+  float mm[6];
+  GH_TRY(gh_bbox_dev(ctx, xyz, m, stride, mm));
+  const double vol = fmax(1e-9, (double)(mm[3] - mm[0] + 1e-3) * (mm[4] - mm[1] + 1e-3) * (mm[5] - mm[2] + 1e-3));
+  float cell = (float)cbrt(vol / (double)m * 8.0);
+  if (cell < 0.05f) cell = 0.05f;
+  DeviceGrid G;
+  const GridSlots sl = {B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS};
+  GH_TRY(gh_grid_build(ctx, xyz, m, stride, cell, sl, &G));
+  int *nn, *nk;
+  float* nd;
+  GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)m * KNN + 1, &nn));
+  GH_TRY(ctx->reserve(B_FE_SORTK2, (size_t)m * KNN + 1, &nd));
+  GH_TRY(ctx->reserve(B_FE_COUNT, (size_t)m + 1, &nk));
+  GridArgs A = {G.d, G.pts, G.start};
+  hipLaunchKernelGGL(k_knn, dim3(cdiv(m, 128)), dim3(128), 0, s, A, 1.0f / G.d.inv, k, nn, nd, nk);
+  hipLaunchKernelGGL(k_normals, dim3(cdiv(m, 256)), dim3(256), 0, s, xyz, stride, m, nn, nk, normals, 1);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
 }

@@ -174,6 +174,68 @@ int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const floa
 int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const float* const* xyzS, const int64_t* nS,
                          const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Fine registration: CRegistration<PointT> (include/common_reg.h:26-110, src/common_reg.cpp).
+ * The reference wraps PCL's IterativeClosestPoint / IterativeClosestPointWithNormals; these entry
+ * points run the same loop (1-NN correspondences, optional reciprocal test and trimmed rejector,
+ * closed-form solve, PCL's default convergence criteria) on the device.
+ * ------------------------------------------------------------------------------------------------ */
+enum { GHICP_ICP_POINT_TO_POINT = 0, GHICP_ICP_POINT_TO_PLANE = 1 };
+/* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
+enum { GHICP_ICP_NOT_CONVERGED = 0, GHICP_ICP_ITERATIONS = 1, GHICP_ICP_TRANSFORM = 2, GHICP_ICP_ABS_MSE = 3, GHICP_ICP_REL_MSE = 4,
+       GHICP_ICP_NO_CORRESPONDENCES = 5 };
+
+typedef struct ghicp_icp_params {
+  int32_t max_iter;        /* icp_reg / ptplicp_reg argument (common_reg.cpp:51,130) */
+  int32_t use_reciprocal;  /* use_reciprocal_correspondence */
+  int32_t use_trimmed;     /* use_trimmed_rejector: overlap = calOverlap(S, T, thre_dis) */
+  int32_t metric;          /* GHICP_ICP_POINT_TO_POINT (icp_reg) or GHICP_ICP_POINT_TO_PLANE (ptplicp_reg) */
+  float thre_dis;          /* search radius of the overlap estimate */
+  float min_overlap;       /* min_overlap_for_reg: below it the registration is refused (reference returns false) */
+  int32_t covariance_k;    /* ptplicp_reg: k of the target normals (CalculatePointCloudWithNormal_KNN), <= 20 */
+  int32_t pad_;
+  double transformation_epsilon;     /* 1e-8 (common_reg.cpp:82,156) */
+  double euclidean_fitness_epsilon;  /* 1e-5 (common_reg.cpp:84,158) */
+} ghicp_icp_params;
+
+typedef struct ghicp_icp_stats {
+  int32_t done;        /* 0: refused because overlap < min_overlap (T untouched), 1: ran */
+  int32_t iterations;
+  int32_t converged;
+  int32_t reason;      /* GHICP_ICP_* convergence state */
+  int64_t correspondences; /* used by the last solve */
+  float overlap;       /* calOverlap result when use_trimmed, else 0 */
+  float pad_;
+  double mse;          /* mean squared correspondence distance of the last iteration */
+  double fitness;      /* getFitnessScore(): mean squared 1-NN distance of the transformed source */
+} ghicp_icp_stats;
+
+void ghicp_icp_params_default(ghicp_icp_params* p);
+
+/* CRegistration::calOverlap (common_reg.cpp:294-317): share of cloud1 points with a cloud2 point at d^2 < thre_dis^2,
+ * (0.01 + count) / n1. */
+int ghicp_cal_overlap(ghicp_ctx* ctx, const float* xyz1, int64_t n1, int stride1, const float* xyz2, int64_t n2, int stride2, float thre_dis,
+                      float* ratio /*[host]*/);
+
+/* CRegistration::icp_reg (common_reg.cpp:45-107) and ptplicp_reg (122-199), selected by params->metric.
+ * T16: row-major float 4x4 source->target [host]; transformed: ns x 3 (device/host per mode) or NULL. */
+int ghicp_icp(ghicp_ctx* ctx, const float* xyzS, int64_t ns, int strideS, const float* xyzT, int64_t nt, int strideT,
+              const ghicp_icp_params* params, float* T16 /*[host]*/, float* transformed, ghicp_icp_stats* stats /*[host]*/);
+
+/* PrincipleComponentAnalysis::CalculateNormalVector_KNN (include/pca.h:92-109): k-NN normals + CheckNormals. */
+int ghicp_knn_normals(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, int k, float* normals /*n x 3*/);
+
+/* exact 1-NN of every query in the target (the correspondence step of the ICP loop): ties -> lower target index. */
+int ghicp_nn_search(ghicp_ctx* ctx, const float* query, int64_t nq, int strideQ, const float* xyzT, int64_t nt, int strideT,
+                    int32_t* idx /*nq*/, float* d2 /*nq*/);
+
+/* CRegistration::invTransform (common_reg.cpp:357-370): R^T with the NEGATED translation, as the reference does. */
+void ghicp_inv_transform(const float* T16, float* inv16);
+
+/* CRegistration::transformcloud (common_reg.cpp:325-349): float 4x4 * (x, y, z, 1). */
+int ghicp_transform_cloud_f32(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const float* T16 /*[host]*/, float* out /*n x 3*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1036,3 +1036,5 @@ float orc_bbx_magnitude(const float* xyz, int n, int stride) {
 }
 
 }  // extern "C"
+
+#include "icp_oracle.inc"

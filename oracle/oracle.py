@@ -249,3 +249,71 @@ def transform_cloud(xyz, Rt):
 def bbx_magnitude(xyz):
     xyz = _f32(xyz)
     return float(lib().orc_bbx_magnitude(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1]))
+
+
+# ---------------------------------------------------------------- fine registration (common_reg.cpp), see icp_oracle.inc
+P2P, P2PLANE = 0, 1
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("use_reciprocal", C.c_int), ("use_trimmed", C.c_int), ("metric", C.c_int),
+                ("thre_dis", C.c_float), ("min_overlap", C.c_float), ("covariance_k", C.c_int), ("pad_", C.c_int),
+                ("transformation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double)]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("done", C.c_int), ("iterations", C.c_int), ("converged", C.c_int), ("reason", C.c_int),
+                ("correspondences", C.c_longlong), ("overlap", C.c_float), ("pad_", C.c_float),
+                ("mse", C.c_double), ("fitness", C.c_double)]
+
+
+def icp_params(max_iter=50, reciprocal=False, trimmed=False, metric=P2P, thre_dis=0.5, min_overlap=0.1, covariance_k=15):
+    """common_reg.cpp:78-85: transformation epsilon 1e-8, Euclidean fitness epsilon 1e-5."""
+    return IcpParams(max_iter, int(reciprocal), int(trimmed), metric, thre_dis, min_overlap, covariance_k, 0, 1e-8, 1e-5)
+
+
+def cal_overlap(c1, c2, thre_dis):
+    c1, c2 = _f32(c1), _f32(c2)
+    f = lib().orc_cal_overlap
+    f.restype = C.c_float
+    return float(f(_p(c1, C.c_float), c1.shape[0], c1.shape[1], _p(c2, C.c_float), c2.shape[0], c2.shape[1], C.c_float(thre_dis)))
+
+
+def inv_transform(T):
+    T = np.ascontiguousarray(T, np.float32)
+    out = np.zeros(16, np.float32)
+    lib().orc_inv_transform(_p(T, C.c_float), _p(out, C.c_float))
+    return out.reshape(4, 4)
+
+
+def knn_normals(xyz, k):
+    xyz = _f32(xyz)
+    out = np.zeros((xyz.shape[0], 3), np.float32)
+    lib().orc_knn_normals(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], int(k), _p(out, C.c_float))
+    return out
+
+
+def nn1(q, tgt):
+    q, tgt = _f32(q), _f32(tgt)
+    idx = np.zeros(q.shape[0], np.int32)
+    d2 = np.zeros(q.shape[0], np.float32)
+    lib().orc_nn1(_p(q, C.c_float), q.shape[0], q.shape[1], _p(tgt, C.c_float), tgt.shape[0], tgt.shape[1], _p(idx, C.c_int), _p(d2, C.c_float))
+    return idx, d2
+
+
+def icp(src, tgt, params: IcpParams, want_trace=False):
+    """Returns dict(done, T (4,4) f32, transformed, stats fields, corr0, trace)."""
+    src, tgt = _f32(src), _f32(tgt)
+    ns = src.shape[0]
+    T = np.zeros(16, np.float32)
+    out = np.zeros((ns, 3), np.float32)
+    st = IcpStats()
+    corr0 = np.full(ns, -2, np.int32)
+    tr = np.zeros((max(params.max_iter, 1), 16), np.float32) if want_trace else None
+    done = lib().orc_icp(_p(src, C.c_float), ns, src.shape[1], _p(tgt, C.c_float), tgt.shape[0], tgt.shape[1], C.byref(params),
+                         _p(T, C.c_float), _p(out, C.c_float), C.byref(st), _p(corr0, C.c_int),
+                         _p(tr, C.c_float) if tr is not None else None)
+    d = {k: getattr(st, k) for k, _ in IcpStats._fields_ if k != "pad_"}
+    d.update(done=int(done), T=T.reshape(4, 4), transformed=out, corr0=corr0,
+             trace=None if tr is None else tr[:st.iterations].reshape(-1, 4, 4))
+    return d
