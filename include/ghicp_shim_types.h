@@ -35,6 +35,12 @@ struct Matrix4d {
   double operator()(int r, int c) const { return m[r * 4 + c]; }
   static Matrix4d Identity() { Matrix4d M; for (int i = 0; i < 16; i++) M.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return M; }
 };
+struct Matrix4f {
+  float m[16];  // row-major
+  float& operator()(int r, int c) { return m[r * 4 + c]; }
+  float operator()(int r, int c) const { return m[r * 4 + c]; }
+  static Matrix4f Identity() { Matrix4f M; for (int i = 0; i < 16; i++) M.m[i] = (i % 5 == 0) ? 1.0f : 0.0f; return M; }
+};
 struct MatrixX3d {
   std::vector<double> d;  // row-major rows() x 3
   long n = 0;

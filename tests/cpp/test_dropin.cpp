@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "binary_feature_extraction.hpp"
+#include "common_reg.h"
 #include "ghicp_reg.h"
 #include "keypoint_detect.hpp"
 #include "km.h"
@@ -68,5 +69,23 @@ int main(int argc, char** argv) {
   printf("RT");
   for (int i = 0; i < 16; i++) printf(" %.17g", Rt.m[i]);
   printf("\n");
+  // fine registration after GH-ICP (CRegistration, common_reg.h): coarse-aligned source -> trimmed point-to-point ICP
+  {
+    CRegistration<Point_T> creg;
+    Eigen::Matrix4f Rf, Ticp, Tinv;
+    for (int i = 0; i < 16; i++) Rf.m[i] = (float)Rt.m[i];
+    pcl::PointCloud<Point_T>::Ptr S1(new pcl::PointCloud<Point_T>()), S2(new pcl::PointCloud<Point_T>());
+    creg.transformcloud(S, S1, Rf);
+    printf("OVERLAP %.9g\n", creg.calOverlap(S1, T, 0.3f));
+    const bool ok = creg.icp_reg(S1, T, S2, Ticp, 20, false, true, 0.3f, 0.1f);
+    creg.invTransform(Ticp, Tinv);
+    printf("ICP %d %d %d %zu", ok ? 1 : 0, creg.last_stats.iterations, creg.last_stats.reason, S2->points.size());
+    for (int i = 0; i < 16; i++) printf(" %.9g", Ticp.m[i]);
+    printf("\n");
+    printf("INV");
+    for (int i = 0; i < 16; i++) printf(" %.9g", Tinv.m[i]);
+    printf("\n");
+    printf("S1 %.9g %.9g %.9g\n", S1->points[7].x, S1->points[7].y, S1->points[7].z);
+  }
   return 0;
 }

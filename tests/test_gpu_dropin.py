@@ -31,7 +31,7 @@ def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr):
     _dump(tmp_path / "S.bin", dsS)
     out = subprocess.run([str(exe), str(tmp_path / "T.bin"), str(tmp_path / "S.bin"), corr], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l.split()[0] in ("KMKAT", "KP", "RT")}
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l.split()[0] in ("KMKAT", "KP", "RT", "OVERLAP", "ICP", "INV", "S1")}
     assert lines["KMKAT"][:3] == ["0", "2", "1"] and float(lines["KMKAT"][4]) == 12.0  # km.cpp:237-259
     # BSCEncoder(..., true) draws the pattern from rand() and writes it like the reference (bfe:75-101); the sequence
     # depends on how often the process called rand() before (the HIP runtime does), so the oracle is fed the written file.
@@ -48,3 +48,16 @@ def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr):
     assert int(lines["KP"][3]) == ro["iters"]
     Rg = np.array([float(v) for v in lines["RT"]]).reshape(4, 4)
     assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
+    # CRegistration (common_reg.h): transformcloud -> calOverlap -> icp_reg -> invTransform, against the CPU restatement
+    Rf = Rg.astype(np.float32)
+    S1 = oracle.transform_cloud(dsS, Rf.astype(np.float64))
+    np.testing.assert_array_equal(np.array([float(v) for v in lines["S1"]], np.float32), S1[7])
+    assert np.float32(lines["OVERLAP"][0]) == np.float32(oracle.cal_overlap(S1, dsT, 0.3))
+    io = oracle.icp(S1, dsT, oracle.icp_params(20, False, True, 0, 0.3, 0.1))
+    ok, iters, reason, nout = (int(v) for v in lines["ICP"][:4])
+    assert ok == 1 and nout == len(dsS) and (iters, reason) == (io["iterations"], io["reason"])
+    Ti = np.array([float(v) for v in lines["ICP"][4:]]).reshape(4, 4)
+    assert rot_err(Ti, io["T"].astype(np.float64)) < 1e-4 and trans_err(Ti, io["T"].astype(np.float64)) < 1e-3
+    inv = np.array([float(v) for v in lines["INV"]]).reshape(4, 4)
+    np.testing.assert_allclose(inv[:3, :3], Ti[:3, :3].T, atol=1e-7)
+    np.testing.assert_allclose(inv[:3, 3], -Ti[:3, 3], atol=1e-7)
