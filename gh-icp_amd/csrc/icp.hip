@@ -4,7 +4,7 @@
 //   k_nn_fine / k_nn_coarse  exact 1-NN of every (transformed) source point in the target: thread-per-query ring search
 //                            on a fine uniform grid, the unresolved tail (queries far from the target) handed to a
 //                            wave-per-query search on an 8x coarser grid.  float L2, ties -> lower index.
-//   k_corr_keys + radix sort the trimmed rejector (keep the floor(overlap * count) smallest by (d^2, source index))
+//   k_sel_pass (radix select) the trimmed rejector (keep the floor(overlap * count) smallest by (d^2, source index))
 //   k_acc_means / k_acc_cov  float Umeyama sums in f64 (N2), per-block partials reduced in a fixed order
 //   k_acc_plane              point-to-plane LLS normal equations (6x6, f64 sums of float terms)
 //   k_icp_step               the closed-form solve + pcl DefaultConvergenceCriteria, one thread
@@ -49,6 +49,10 @@ struct IcpState {
   int trimmed, metric;
   float ratio;
   unsigned pend;
+  // radix select of the trimming threshold K* = (d2star, istar): correspondences with a smaller (d2 bits, index) are kept
+  unsigned sel_prefix[6], sel_rank[6];
+  unsigned d2star, istar;
+  int sel_done;
 };
 
 // ------------------------------------------------------------------------------------------------ 1-NN search
@@ -67,31 +71,51 @@ __device__ inline float block_reach(const NnGrid& G, float px, float py, float p
   return m - 2e-3f * G.cell;
 }
 
+// squared distance from coordinate p to the cell interval [lo, hi] of one axis (cells as the grid assigns them, shrunk
+// by the same rounding margin as block_reach)
+__device__ inline float axis_gap2(const NnGrid& G, int a, float p, int lo, int hi) {
+  const float m = 2e-3f * G.cell;
+  const float l = G.d.mn[a] + (float)lo * G.cell + m, h = G.d.mn[a] + (float)(hi + 1) * G.cell - m;
+  const float d = fmaxf(fmaxf(l - p, p - h), 0.f);
+  return d * d;
+}
+
 // The cells of block r that are not in block rlo (rlo = -1: the whole block), as z-contiguous runs of the point array.
-template <typename F>
-__device__ inline void for_shell_runs(const GridDesc& g, const unsigned* __restrict__ start, int cx, int cy, int cz, int rlo, int r, F&& f) {
+// bound(x) is called before every x slab and returns the squared distance beyond which a run cannot matter; runs whose
+// box lies farther than that from P are skipped (a point at exactly the bound still ties, hence the strict test).
+template <typename B, typename F>
+__device__ inline void for_shell_runs(const NnGrid& G, float px, float py, float pz, int cx, int cy, int cz, int rlo, int r, B&& bound, F&& f) {
+  const GridDesc& g = G.d;
+  const unsigned* __restrict__ start = G.start;
   const int x0 = max(cx - r, 0), x1 = min(cx + r, g.dim[0] - 1);
   const int y0 = max(cy - r, 0), y1 = min(cy + r, g.dim[1] - 1);
   const int zl = max(cz - r, 0), zh = min(cz + r, g.dim[2] - 1);
-  for (int x = x0; x <= x1; x++)
+  for (int x = x0; x <= x1; x++) {
+    const float lim = bound(x);
+    const float gx = axis_gap2(G, 0, px, x, x);
+    if (gx > lim) continue;
     for (int y = y0; y <= y1; y++) {
+      const float gxy = gx + axis_gap2(G, 1, py, y, y);
+      if (gxy > lim) continue;
       const unsigned base = ((unsigned)x * g.dim[1] + y) * g.dim[2];
       if (max(abs(x - cx), abs(y - cy)) > rlo) {
+        if (gxy + axis_gap2(G, 2, pz, zl, zh) > lim) continue;
         const unsigned b = start[base + zl], e = start[base + zh + 1];
         if (e > b) f(b, e);
       } else {
         const int a1 = min(cz - rlo - 1, g.dim[2] - 1);
-        if (zl <= a1) {
+        if (zl <= a1 && !(gxy + axis_gap2(G, 2, pz, zl, a1) > lim)) {
           const unsigned b = start[base + zl], e = start[base + a1 + 1];
           if (e > b) f(b, e);
         }
         const int b0 = max(cz + rlo + 1, 0);
-        if (b0 <= zh) {
+        if (b0 <= zh && !(gxy + axis_gap2(G, 2, pz, b0, zh) > lim)) {
           const unsigned b = start[base + b0], e = start[base + zh + 1];
           if (e > b) f(b, e);
         }
       }
     }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_nn_fine(NnGrid G, const float4* __restrict__ q, int nq, int* __restrict__ nn, float* __restrict__ nd,
@@ -107,7 +131,7 @@ __global__ __launch_bounds__(256) void k_nn_fine(NnGrid G, const float4* __restr
   bool done = false;
   int rlo = -1;
   for (int r = 1; r <= RCAP; r++) {
-    for_shell_runs(G.d, G.start, cx, cy, cz, rlo, r, [&](unsigned b, unsigned e) {
+    for_shell_runs(G, P.x, P.y, P.z, cx, cy, cz, rlo, r, [&](int) { return bd; }, [&](unsigned b, unsigned e) {
       for (unsigned t = b; t < e; t++) {
         const float4 Q = G.pts[t];
         const int qi = (int)__float_as_uint(Q.w);
@@ -149,20 +173,49 @@ __global__ __launch_bounds__(256) void k_nn_coarse(NnGrid G, const float4* __res
     const int cy = gh_cell_coord(P.y, G.d.mn[1], G.d.inv, G.d.dim[1]);
     const int cz = gh_cell_coord(P.z, G.d.mn[2], G.d.inv, G.d.dim[2]);
     unsigned long long best = ((unsigned long long)__float_as_uint(nd[i]) << 32) | (unsigned)nn[i];
-    int rlo = -1;
     for (int r = 0;; r++) {
-      for_shell_runs(G.d, G.start, cx, cy, cz, rlo, r, [&](unsigned b, unsigned e) {
-        for (unsigned t = b + lane; t < e; t += 64) {
-          const float4 Q = G.pts[t];
-          const float dx = P.x - Q.x, dy = P.y - Q.y, dz = P.z - Q.z;
-          float d2 = dx * dx;
-          d2 += dy * dy;
-          d2 += dz * dz;
-          const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(Q.w);
-          best = key < best ? key : best;
+      // Shell r as 2 slots per (x, y) column of the block: a rim column is one z run (slot 0), an interior column its two
+      // cap cells.  The lanes look the slots up in parallel (box test against the wave's best, then the cell table), then
+      // the wave walks the non-empty runs together: no serial chain of table lookups per column.
+      const int side = 2 * r + 1, slots = 2 * side * side;
+      for (int s0 = 0; s0 < slots; s0 += 64) {
+        best = wave_min_u64(best);
+        const float lim = __uint_as_float((unsigned)(best >> 32));
+        unsigned rb = 0, re = 0;
+        const int sl = s0 + lane;
+        if (sl < slots) {
+          const int c = sl >> 1, h = sl & 1;
+          const int x = cx + c / side - r, y = cy + c % side - r;
+          if (x >= 0 && x < G.d.dim[0] && y >= 0 && y < G.d.dim[1]) {
+            const bool rim = max(abs(x - cx), abs(y - cy)) == r;
+            int zl, zh;
+            if (rim) { zl = cz - r; zh = h ? zl - 1 : cz + r; }
+            else { zl = zh = h ? cz + r : cz - r; }
+            if (r == 0 && h) zh = zl - 1;
+            zl = max(zl, 0); zh = min(zh, G.d.dim[2] - 1);
+            if (zl <= zh && !(axis_gap2(G, 0, P.x, x, x) + axis_gap2(G, 1, P.y, y, y) + axis_gap2(G, 2, P.z, zl, zh) > lim)) {
+              const unsigned base = ((unsigned)x * G.d.dim[1] + y) * G.d.dim[2];
+              rb = G.start[base + zl];
+              re = G.start[base + zh + 1];
+            }
+          }
         }
-      });
-      rlo = r;
+        unsigned long long live = __ballot(re > rb);
+        while (live) {
+          const int l = __ffsll((long long)live) - 1;
+          live &= live - 1;
+          const unsigned b = __shfl(rb, l, 64), e = __shfl(re, l, 64);
+          for (unsigned t = b + lane; t < e; t += 64) {
+            const float4 Q = G.pts[t];
+            const float dx = P.x - Q.x, dy = P.y - Q.y, dz = P.z - Q.z;
+            float d2 = dx * dx;
+            d2 += dy * dy;
+            d2 += dz * dz;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(Q.w);
+            best = key < best ? key : best;
+          }
+        }
+      }
       best = wave_min_u64(best);
       const float bd = __uint_as_float((unsigned)(best >> 32));
       const float reach = block_reach(G, P.x, P.y, P.z, cx, cy, cz, r);
@@ -175,11 +228,22 @@ __global__ __launch_bounds__(256) void k_nn_coarse(NnGrid G, const float4* __res
   }
 }
 
+// adds the number of threads of a 256-thread block with `flag` set to *dst: one atomic per block
+__device__ inline void block_count_add(bool flag, unsigned* dst) {
+  __shared__ unsigned wsum[4];
+  const unsigned long long b = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (t) atomicAdd(dst, t);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_count_occupied(const unsigned* __restrict__ keys, unsigned n, unsigned* __restrict__ out) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   const bool first = i < n && (i == 0 || keys[i] != keys[i - 1]);
-  const unsigned long long b = __ballot(first);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned)__popcll(b));
+  block_count_add(first, out);
 }
 
 __global__ __launch_bounds__(256) void k_pack4(const float* __restrict__ xyz, long long n, int stride, float4* __restrict__ out) {
@@ -221,18 +285,13 @@ __global__ __launch_bounds__(256) void k_overlap(NnGrid G, const float* __restri
       });
     }
   }
-  const unsigned long long b = __ballot(hit);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned)__popcll(b));
+  block_count_add(hit, count);
 }
 
 // ------------------------------------------------------------------------------------------------ correspondences
-__global__ __launch_bounds__(256) void k_corr_keys(const int* __restrict__ nn, const float* __restrict__ nd, int n, unsigned long long* __restrict__ keys,
-                                                   IcpState* __restrict__ st) {
+__global__ __launch_bounds__(256) void k_corr_count(const int* __restrict__ nn, int n, IcpState* __restrict__ st) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = i < n && nn[i] >= 0;
-  if (i < n && keys) keys[i] = valid ? (((unsigned long long)__float_as_uint(nd[i]) << 32) | (unsigned)i) : ~0ull;
-  const unsigned long long b = __ballot(valid);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&st->count, (unsigned)__popcll(b));
+  block_count_add(i < n && nn[i] >= 0, &st->count);
 }
 
 // CorrespondenceRejectorTrimmed::getRemainingCorrespondences: floor(overlap_ratio * float(size))
@@ -243,10 +302,93 @@ __global__ void k_icp_prep(IcpState* st) {
     if (t < nv) nv = t;
   }
   st->nv = nv;
+  st->sel_prefix[0] = 0;
+  st->sel_rank[0] = nv;
+  st->sel_done = nv >= st->count;  // nothing to trim: every valid correspondence is kept
+  st->d2star = 0xffffffffu;
+  st->istar = 0xffffffffu;
+}
+
+// ---- trimmed rejector without a sort.  The kept set is {key < K*} with key = (d2 bits, source index) and K* the key of
+// rank nv: an MSD radix select, three digit passes (11 + 11 + 10 bits) over the distance bits, then -- only when ties at
+// the threshold distance have to be split -- three over the index bits.  Every pass is one histogram kernel whose blocks
+// first derive the prefix chosen so far from the previous pass's histogram.
+constexpr int SEL_BINS = 2048;
+__device__ inline int sel_bits(int p) { return (p % 3 == 2) ? 10 : 11; }
+__device__ inline int sel_shift(int p) { return (p % 3 == 0) ? 21 : ((p % 3 == 1) ? 10 : 0); }
+
+// bin of `hist` (SEL_BINS entries) that holds rank r; *below = entries in lower bins.  Block-cooperative, 256 threads.
+__device__ inline unsigned sel_pick(const unsigned* __restrict__ hist, unsigned r, unsigned* below, int* scan_s, unsigned* pick_s) {
+  unsigned c[8], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { c[k] = hist[threadIdx.x * 8 + k]; sum += c[k]; }
+  int tot;
+  const unsigned ex = (unsigned)gh_block_excl_scan((int)sum, scan_s, &tot);
+  if (r >= ex && r < ex + sum) {
+    unsigned acc = ex;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (r >= acc && r < acc + c[k]) { pick_s[0] = threadIdx.x * 8 + k; pick_s[1] = acc; }
+      acc += c[k];
+    }
+  }
+  __syncthreads();
+  *below = pick_s[1];
+  return pick_s[0];
+}
+
+__global__ __launch_bounds__(256) void k_sel_pass(int pass, const int* __restrict__ nn, const float* __restrict__ nd, int n, IcpState* __restrict__ st,
+                                                  unsigned* __restrict__ hist) {
+  if (st->sel_done || (pass > 3 && st->istar == 0)) return;
+  __shared__ unsigned lh[SEL_BINS];
+  __shared__ int scan_s[20];
+  __shared__ unsigned pick_s[2];
+  unsigned prefix = 0, rank = st->sel_rank[0], d2star = st->d2star;
+  if (pass > 0) {
+    unsigned below;
+    const unsigned bin = sel_pick(hist + (size_t)(pass - 1) * SEL_BINS, st->sel_rank[pass - 1], &below, scan_s, pick_s);
+    prefix = (st->sel_prefix[pass - 1] << sel_bits(pass - 1)) | bin;
+    rank = st->sel_rank[pass - 1] - below;
+    if (pass == 3) {  // the distance is fixed: `rank` of its ties (lowest indices first) are kept
+      d2star = prefix;
+      prefix = 0;
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->d2star = d2star;
+        if (rank == 0) st->istar = 0;
+      }
+      if (rank == 0) return;  // K* is the first tie: no index digits needed (k_sel_final sees rank 0 too)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->sel_prefix[pass] = prefix; st->sel_rank[pass] = rank; }
+  }
+  for (int k = threadIdx.x; k < SEL_BINS; k += 256) lh[k] = 0;
+  __syncthreads();
+  const int shift = sel_shift(pass), bits = sel_bits(pass);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if (nn[i] < 0) continue;
+    const unsigned db = __float_as_uint(nd[i]);
+    unsigned v;
+    bool member;
+    if (pass < 3) { v = db; member = pass == 0 || (v >> (shift + bits)) == prefix; }
+    else { v = (unsigned)i; member = db == d2star && (pass == 3 || (v >> (shift + bits)) == prefix); }
+    if (member) atomicAdd(&lh[(v >> shift) & ((1u << bits) - 1u)], 1u);
+  }
+  __syncthreads();
+  unsigned* out = hist + (size_t)pass * SEL_BINS;
+  for (int k = threadIdx.x; k < SEL_BINS; k += 256)
+    if (lh[k]) atomicAdd(&out[k], lh[k]);
+}
+
+__global__ __launch_bounds__(256) void k_sel_final(IcpState* __restrict__ st, const unsigned* __restrict__ hist) {
+  if (st->sel_done) return;
+  __shared__ int scan_s[20];
+  __shared__ unsigned pick_s[2];
+  if (st->istar == 0) return;  // decided at pass 3
+  unsigned below;
+  const unsigned bin = sel_pick(hist + (size_t)5 * SEL_BINS, st->sel_rank[5], &below, scan_s, pick_s);
+  if (threadIdx.x == 0) st->istar = (st->sel_prefix[5] << 10) | bin;
 }
 
 struct CorrView {
-  const unsigned long long* sorted;  // trimmed: keys in ascending (d2, i) order; else NULL
   const int* nn;
   const float* nd;
   const float4* cur;
@@ -254,11 +396,12 @@ struct CorrView {
   int ns;
 };
 
-// entry e of the correspondence list -> (i, j) or i = -1
-__device__ inline int corr_at(const CorrView& V, unsigned e, int* j) {
-  const int i = V.sorted ? (int)(unsigned)V.sorted[e] : (int)e;
-  *j = V.nn[i];
-  return *j >= 0 ? i : -1;
+// source point e -> its target j if the correspondence survives the rejectors, else -1
+__device__ inline int corr_at(const CorrView& V, const IcpState* __restrict__ st, unsigned e, int* j) {
+  *j = V.nn[e];
+  if (*j < 0) return -1;
+  const unsigned db = __float_as_uint(V.nd[e]);
+  return (db < st->d2star || (db == st->d2star && e < st->istar)) ? (int)e : -1;
 }
 
 __device__ inline void store_partials(const double* v, int nv, double* red, double* __restrict__ part) {
@@ -270,11 +413,11 @@ __device__ inline void store_partials(const double* v, int nv, double* red, doub
 
 __global__ __launch_bounds__(256) void k_acc_means(CorrView V, const IcpState* __restrict__ st, double* __restrict__ part) {
   __shared__ double red[16];
-  const unsigned lim = V.sorted ? st->nv : (unsigned)V.ns;
+  const unsigned lim = (unsigned)V.ns;
   double m[7] = {0, 0, 0, 0, 0, 0, 0};
   for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < lim; e += NBLK * 256u) {
     int j;
-    const int i = corr_at(V, e, &j);
+    const int i = corr_at(V, st, e, &j);
     if (i < 0) continue;
     const float4 S = V.cur[i], D = V.tgt[j];
     m[0] += (double)S.x; m[1] += (double)S.y; m[2] += (double)S.z;
@@ -284,10 +427,19 @@ __global__ __launch_bounds__(256) void k_acc_means(CorrView V, const IcpState* _
   store_partials(m, 7, red, part);
 }
 
-__global__ void k_icp_means(IcpState* st, const double* __restrict__ part) {
-  double m[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < NBLK; b++)
-    for (int d = 0; d < 7; d++) m[d] += part[(size_t)b * NPART + d];
+// sum of component d over the NBLK block partials by one wave: lane l adds blocks l, l+64, ... then a fixed shuffle tree
+__device__ inline double wave_reduce_partials(const double* __restrict__ part, int d) {
+  double s = 0;
+  for (int b = threadIdx.x; b < NBLK; b += 64) s += part[(size_t)b * NPART + d];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+__global__ __launch_bounds__(64) void k_icp_means(IcpState* st, const double* __restrict__ part) {
+  double m[7];
+  for (int d = 0; d < 7; d++) m[d] = wave_reduce_partials(part, d);
+  if (threadIdx.x != 0) return;
   const double c = (double)st->nv;
   for (int d = 0; d < 3; d++) { st->msf[d] = (float)(m[d] / c); st->mtf[d] = (float)(m[3 + d] / c); }
   st->mse = m[6] / c;  // DefaultConvergenceCriteria::calculateMSE over the remaining correspondences
@@ -295,13 +447,13 @@ __global__ void k_icp_means(IcpState* st, const double* __restrict__ part) {
 
 __global__ __launch_bounds__(256) void k_acc_cov(CorrView V, const IcpState* __restrict__ st, double* __restrict__ part) {
   __shared__ double red[16];
-  const unsigned lim = V.sorted ? st->nv : (unsigned)V.ns;
+  const unsigned lim = (unsigned)V.ns;
   const double ms[3] = {(double)st->msf[0], (double)st->msf[1], (double)st->msf[2]};
   const double mt[3] = {(double)st->mtf[0], (double)st->mtf[1], (double)st->mtf[2]};
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < lim; e += NBLK * 256u) {
     int j;
-    const int i = corr_at(V, e, &j);
+    const int i = corr_at(V, st, e, &j);
     if (i < 0) continue;
     const float4 S = V.cur[i], D = V.tgt[j];
     const double a[3] = {(double)D.x - mt[0], (double)D.y - mt[1], (double)D.z - mt[2]};
@@ -317,13 +469,13 @@ __global__ __launch_bounds__(256) void k_acc_cov(CorrView V, const IcpState* __r
 // TransformationEstimationPointToPlaneLLS: rows [n x s ; n], rhs n.(d - s), float terms summed in f64
 __global__ __launch_bounds__(256) void k_acc_plane(CorrView V, const float* __restrict__ tnrm, const IcpState* __restrict__ st, double* __restrict__ part) {
   __shared__ double red[16];
-  const unsigned lim = V.sorted ? st->nv : (unsigned)V.ns;
+  const unsigned lim = (unsigned)V.ns;
   double acc[28];
 #pragma unroll
   for (int d = 0; d < 28; d++) acc[d] = 0;
   for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < lim; e += NBLK * 256u) {
     int j;
-    const int i = corr_at(V, e, &j);
+    const int i = corr_at(V, st, e, &j);
     if (i < 0) continue;
     const float4 S = V.cur[i], D = V.tgt[j];
     const float nx = tnrm[(size_t)j * 3], ny = tnrm[(size_t)j * 3 + 1], nz = tnrm[(size_t)j * 3 + 2];
@@ -350,18 +502,20 @@ __device__ inline void mat4_mul(const float* a, const float* b, float* out) {
 }
 
 // closed-form solve + final_transformation_ update + DefaultConvergenceCriteria::hasConverged
-__global__ void k_icp_step(IcpState* st, const double* __restrict__ part) {
+__global__ __launch_bounds__(64) void k_icp_step(IcpState* st, const double* __restrict__ part) {
   const unsigned cnt = st->nv;
+  double acc[28];
+  const int nacc = st->metric == GHICP_ICP_POINT_TO_POINT ? 9 : 28;
+  for (int d = 0; d < 28; d++) acc[d] = d < nacc ? wave_reduce_partials(part, d) : 0.0;
+  if (threadIdx.x != 0) return;
   if (cnt < 3u) {  // min_number_correspondences_
     st->converged = 0; st->reason = GHICP_ICP_NO_CORRESPONDENCES; st->count = 0;
     return;
   }
   float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   if (st->metric == GHICP_ICP_POINT_TO_POINT) {
-    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, R[9];
-    for (int b = 0; b < NBLK; b++)
-      for (int d = 0; d < 9; d++) A[d] += part[(size_t)b * NPART + d];
-    for (int d = 0; d < 9; d++) A[d] /= (double)cnt;
+    double A[9], R[9];
+    for (int d = 0; d < 9; d++) A[d] = acc[d] / (double)cnt;
     gh_quant_grid(A, 9);  // N2: umeyama's sigma is a Matrix3f
     gh_kabsch(A, R);
     float Rf[9];
@@ -372,10 +526,6 @@ __global__ void k_icp_step(IcpState* st, const double* __restrict__ part) {
                                                    (double)Rf[r * 3 + 2] * (double)st->msf[2]));
     }
   } else {
-    double acc[28];
-    for (int d = 0; d < 28; d++) acc[d] = 0;
-    for (int b = 0; b < NBLK; b++)
-      for (int d = 0; d < 28; d++) acc[d] += part[(size_t)b * NPART + d];
     st->mse = acc[27] / (double)cnt;
     double A[6][6], bb[6], x[6];
     int k = 0;
@@ -663,7 +813,7 @@ extern "C" int ghicp_icp(ghicp_ctx* ctx, const float* xyzS, int64_t ns, int stri
   float4 *cur, *tgt4, *q4 = nullptr;
   int *nn, *nn2 = nullptr;
   float *nd, *nd2 = nullptr, *tnrm = nullptr;
-  unsigned long long *keys = nullptr, *keys2 = nullptr;
+  unsigned* hist = nullptr;
   double* part;
   IcpState* st;
   GH_TRY(ctx->reserve(B_ICP_CUR, (size_t)ns + 1, &cur));
@@ -677,14 +827,7 @@ extern "C" int ghicp_icp(ghicp_ctx* ctx, const float* xyzS, int64_t ns, int stri
     GH_TRY(ctx->reserve(B_ICP_NN2, (size_t)ns + 1, &nn2));
     GH_TRY(ctx->reserve(B_ICP_ND2, (size_t)ns + 1, &nd2));
   }
-  size_t sort_bytes = 0;
-  char* sort_tmp = nullptr;
-  if (trimmed) {
-    GH_TRY(ctx->reserve(B_ICP_KEYS, (size_t)ns + 1, &keys));
-    GH_TRY(ctx->reserve(B_ICP_KEYS2, (size_t)ns + 1, &keys2));
-    GH_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys, keys2, (int)ns, 0, 64, s));
-    GH_TRY(ctx->reserve(B_ICP_SORTTMP, sort_bytes + 16, &sort_tmp));
-  }
+  if (trimmed) GH_TRY(ctx->reserve(B_ICP_KEYS, (size_t)6 * SEL_BINS, &hist));
   if (P->metric == GHICP_ICP_POINT_TO_PLANE) {  // common_reg.cpp:146-147 (only the target normals enter the LLS solve)
     GH_TRY(ctx->reserve(B_ICP_TNRM, (size_t)nt * 3 + 3, &tnrm));
     GH_TRY(gh_knn_normals_dev(ctx, dT, nt, strideT, P->covariance_k, tnrm));
@@ -706,7 +849,8 @@ extern "C" int ghicp_icp(ghicp_ctx* ctx, const float* xyzS, int64_t ns, int stri
   IcpState* pin = reinterpret_cast<IcpState*>(ctx->pinned);
   static_assert(sizeof(IcpState) <= 4096, "status record must fit the pinned scratch");
   const int gS = cdiv(ns, 256);
-  const CorrView V = {trimmed ? keys2 : nullptr, nn, nd, cur, tgt4, (int)ns};
+  const CorrView V = {nn, nd, cur, tgt4, (int)ns};
+  const int gSel = min(cdiv(ns, 2048), 512);
   for (;;) {
     GH_TRY(nn_search(ctx, XT, cur, (int)ns, nn, nd));
     if (P->use_reciprocal) {  // determineReciprocalCorrespondences
@@ -715,17 +859,21 @@ extern "C" int ghicp_icp(ghicp_ctx* ctx, const float* xyzS, int64_t ns, int stri
       GH_TRY(nn_search(ctx, XS, q4, (int)ns, nn2, nd2));
       hipLaunchKernelGGL(k_reciprocal, dim3(gS), dim3(256), 0, s, nn2, (int)ns, nn);
     }
-    hipLaunchKernelGGL(k_corr_keys, dim3(gS), dim3(256), 0, s, nn, nd, (int)ns, keys, st);
+    hipLaunchKernelGGL(k_corr_count, dim3(gS), dim3(256), 0, s, nn, (int)ns, st);
     hipLaunchKernelGGL(k_icp_prep, dim3(1), dim3(1), 0, s, st);
-    if (trimmed) GH_HIP(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys, keys2, (int)ns, 0, 64, s));
+    if (trimmed) {
+      GH_HIP(hipMemsetAsync(hist, 0, (size_t)6 * SEL_BINS * sizeof(unsigned), s));
+      for (int pass = 0; pass < 6; pass++) hipLaunchKernelGGL(k_sel_pass, dim3(gSel), dim3(256), 0, s, pass, nn, nd, (int)ns, st, hist);
+      hipLaunchKernelGGL(k_sel_final, dim3(1), dim3(256), 0, s, st, hist);
+    }
     if (P->metric == GHICP_ICP_POINT_TO_POINT) {
       hipLaunchKernelGGL(k_acc_means, dim3(NBLK), dim3(256), 0, s, V, st, part);
-      hipLaunchKernelGGL(k_icp_means, dim3(1), dim3(1), 0, s, st, part);
+      hipLaunchKernelGGL(k_icp_means, dim3(1), dim3(64), 0, s, st, part);
       hipLaunchKernelGGL(k_acc_cov, dim3(NBLK), dim3(256), 0, s, V, st, part);
     } else {
       hipLaunchKernelGGL(k_acc_plane, dim3(NBLK), dim3(256), 0, s, V, tnrm, st, part);
     }
-    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, s, st, part);
+    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(64), 0, s, st, part);
     hipLaunchKernelGGL(k_apply, dim3(gS), dim3(256), 0, s, cur, (int)ns, st);
     GH_HIP(hipMemcpyAsync(pin, st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));

@@ -105,3 +105,19 @@ def test_icp_edge_cases(ctx, api, synth):
     assert r["reason"] == 5 and r["iterations"] == 0
     with pytest.raises(api.GhicpError):
         ctx.icp(src, tgt, api.icp_params(5, metric=1, covariance_k=64))
+
+
+def test_trimmed_rejector_splits_ties_by_index(ctx, api, oracle, synth):
+    """Repeated source points give equal distances at the trimming threshold: the kept set is the lowest indices."""
+    src, tgt, _ = small_pair(synth, n=6000)
+    near = np.flatnonzero(oracle.nn1(src, tgt)[1] < 0.1 ** 2)[:2]  # two unrepeated points inside the overlap radius
+    src4 = np.vstack([np.repeat(np.delete(src, near, axis=0), 4, axis=0), src[near]])
+    for max_iter in (1, 6):
+        ro = oracle.icp(src4, tgt, oracle.icp_params(max_iter, False, True, 0, 0.2, 0.05))
+        rg = ctx.icp(src4, tgt, api.icp_params(max_iter, False, True, 0, 0.2, 0.05))
+        assert rg["overlap"] == ro["overlap"] and rg["correspondences"] == ro["correspondences"]
+        assert rg["correspondences"] % 4 == 2  # the threshold falls inside a group of four equal distances
+        assert (rg["iterations"], rg["reason"]) == (ro["iterations"], ro["reason"])
+        np.testing.assert_allclose(rg["mse"], ro["mse"], rtol=1e-9)
+        assert rot_err(rg["T"].astype(np.float64), ro["T"].astype(np.float64)) <= 5e-6
+        assert trans_err(rg["T"].astype(np.float64), ro["T"].astype(np.float64)) <= 5e-5
