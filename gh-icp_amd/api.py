@@ -52,6 +52,8 @@ EXPORTS = [
     "ghicp_register_pairs",
     "ghicp_icp_params_default", "ghicp_cal_overlap", "ghicp_icp", "ghicp_knn_normals", "ghicp_nn_search", "ghicp_inv_transform",
     "ghicp_transform_cloud_f32",
+    "ghicp_cloud_create", "ghicp_cloud_from_features", "ghicp_cloud_destroy", "ghicp_cloud_get_info", "ghicp_cloud_download",
+    "ghicp_register_clouds", "ghicp_sbf_write", "ghicp_sbf_read",
 ]
 
 _lib = None
@@ -408,6 +410,102 @@ def _register_pairs(self, cfg, pairs):
 
 
 Context.register_pairs = _register_pairs
+
+
+# ---------------------------------------------------------------- per-cloud front-end cache
+class CloudInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("k", C.c_int64), ("variants", C.c_int32), ("feature", C.c_int32),
+                ("bbx_magnitude", C.c_float), ("pad_", C.c_float), ("feature_bytes", C.c_int64)]
+
+
+class Cloud:
+    """A ghicp_cloud handle: the down-sampled points, keypoints and descriptors of one cloud, resident in HBM."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def info(self) -> CloudInfo:
+        i = CloudInfo()
+        self.ctx._check(self.ctx.lib.ghicp_cloud_get_info(self.h, C.byref(i)))
+        return i
+
+    def download(self, points=True):
+        """Returns dict(ds (m,3) f32 | None, kp (k,) i32 | None, kp_xyz (k,3) f64, feat: (V,k,56) u8 | (k,33) f32 | None) as device tensors."""
+        t, c, i = self.ctx.torch, self.ctx, self.info()
+        ds = t.empty((i.m, 3), dtype=t.float32, device=c.dev) if points and i.m > 0 else None
+        kp = t.empty((i.k,), dtype=t.int32, device=c.dev) if points and i.m > 0 else None
+        kpx = t.empty((i.k, 3), dtype=t.float64, device=c.dev)
+        feat = None
+        if i.feature == FEATURE_BSC:
+            feat = t.empty((i.variants, i.k, 56), dtype=t.uint8, device=c.dev)
+        elif i.feature == FEATURE_FPFH:
+            feat = t.empty((i.k, 33), dtype=t.float32, device=c.dev)
+        c._check(c.lib.ghicp_cloud_download(self.h, _ptr(ds), _ptr(kp), _ptr(kpx), _ptr(feat)))
+        return dict(ds=ds, kp=kp, kp_xyz=kpx, feat=feat)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.ghicp_cloud_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _cloud_create(self, cfg, xyz) -> Cloud:
+    x = self._xyz(xyz)
+    h = C.c_void_p()
+    self._check(self.lib.ghicp_cloud_create(self.h, C.byref(cfg), _ptr(x), C.c_int64(x.shape[0]), x.shape[1], C.byref(h)))
+    return Cloud(self, h)
+
+
+def _cloud_from_features(self, cfg, kp_xyz, feat, bbx_magnitude) -> Cloud:
+    t = self.torch
+    kpx = self._dev(kp_xyz, t.float64)
+    if feat is not None:
+        feat = self._dev(feat, t.uint8 if cfg.reg.feature == FEATURE_BSC else t.float32)
+    h = C.c_void_p()
+    self._check(self.lib.ghicp_cloud_from_features(self.h, C.byref(cfg), _ptr(kpx), C.c_int64(kpx.shape[0]), _ptr(feat), C.c_float(bbx_magnitude),
+                                                   C.byref(h)))
+    return Cloud(self, h)
+
+
+def _register_clouds(self, cfg, pairs):
+    """pairs: list of (Cloud S, Cloud T).  Returns list[PairStats]."""
+    n = len(pairs)
+    if n == 0:
+        return []
+    HS = (C.c_void_p * n)(*[a.h.value for a, _ in pairs])
+    HT = (C.c_void_p * n)(*[b.h.value for _, b in pairs])
+    stats = (PairStats * n)()
+    self._check(self.lib.ghicp_register_clouds(self.h, C.byref(cfg), n, HS, HT, stats))
+    return list(stats)
+
+
+Context.cloud_create = _cloud_create
+Context.cloud_from_features = _cloud_from_features
+Context.register_clouds = _register_clouds
+
+
+def sbf_write(path, feat):
+    """StereoBinaryFeature::writeFeatures format (stereo_binary_feature.cpp:107-124); feat (k,56) u8 host array."""
+    f = np.ascontiguousarray(feat, np.uint8).reshape(-1, 56)
+    rc = load().ghicp_sbf_write(str(path).encode(), f.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(f.shape[0]))
+    if rc != 0:
+        raise GhicpError("ghicp_sbf_write(%s) failed" % path)
+
+
+def sbf_read(path):
+    k = C.c_int64(0)
+    if load().ghicp_sbf_read(str(path).encode(), None, C.c_int64(0), C.byref(k)) != 0:
+        raise GhicpError("ghicp_sbf_read(%s): not a 441-bit feature dump" % path)
+    f = np.zeros((k.value, 56), np.uint8)
+    if load().ghicp_sbf_read(str(path).encode(), f.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(k.value), C.byref(k)) != 0:
+        raise GhicpError("ghicp_sbf_read(%s) failed" % path)
+    return f
 
 
 def pair_config(feature=FEATURE_BSC, corr=CORR_KM, dof=6, est_iou=0.6, voxel=0.1, neighborhood_radius=0.5, radius_nonmax=1.5,

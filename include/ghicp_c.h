@@ -236,6 +236,40 @@ void ghicp_inv_transform(const float* T16, float* inv16);
 /* CRegistration::transformcloud (common_reg.cpp:325-349): float 4x4 * (x, y, z, 1). */
 int ghicp_transform_cloud_f32(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const float* T16 /*[host]*/, float* out /*n x 3*/);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-cloud front-end cache (multi-view / all-pairs registration): down-sampling, keypoints and
+ * descriptors of one cloud (test/ghicp_main.cpp:86-127) computed once and kept in HBM; a pair then costs
+ * only calFD_* and the loop.  Results are identical to ghicp_register_pairs on the same clouds.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ghicp_cloud ghicp_cloud;
+
+typedef struct ghicp_cloud_info {
+  int64_t n, m, k;        /* raw points, down-sampled points, keypoints */
+  int32_t variants;       /* V: BSC strings per keypoint (1, 2 or 4; binary_feature_extraction.hpp:648-660) */
+  int32_t feature;        /* GHICP_FEATURE_* */
+  float bbx_magnitude;    /* of the down-sampled cloud (main:91-93) */
+  float pad_;
+  int64_t feature_bytes;  /* BSC: V*k*56, FPFH: k*33*4, None: 0 */
+} ghicp_cloud_info;
+
+int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* xyz, int64_t n, int stride, ghicp_cloud** out);
+/* rebuilds a handle from stored results: kp_xyz k x 3 f64, feat = V*k*56 BSC bytes (variant-major) or k x 33 f32 FPFH rows */
+int ghicp_cloud_from_features(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const double* kp_xyz, int64_t k, const void* feat,
+                              float bbx_magnitude, ghicp_cloud** out);
+int ghicp_cloud_destroy(ghicp_cloud* cloud);
+int ghicp_cloud_get_info(const ghicp_cloud* cloud, ghicp_cloud_info* info /*[host]*/);
+/* any destination may be NULL: ds_xyz m x 3 f32, kp_idx k, kp_xyz k x 3 f64, feat feature_bytes */
+int ghicp_cloud_download(const ghicp_cloud* cloud, float* ds_xyz, int32_t* kp_idx, double* kp_xyz, void* feat);
+/* S[i] -> T[i] for n_pairs pairs of cached clouds; cfg must describe the front end the handles were built with
+ * (cfg->reg.corr and the loop parameters may differ from call to call).  stats: n_pairs [host]. */
+int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const ghicp_cloud* const* S,
+                          const ghicp_cloud* const* T, ghicp_pair_stats* stats);
+
+/* StereoBinaryFeature::writeFeatures / readFeatures (src/stereo_binary_feature.cpp:107-148): the reference's dump
+ * format for one vector of 441-bit strings.  Host memory.  ghicp_sbf_read with feat == NULL only reports *k. */
+int ghicp_sbf_write(const char* path, const uint8_t* feat /*k x 56*/, int64_t k);
+int ghicp_sbf_read(const char* path, uint8_t* feat /*capacity x 56 or NULL*/, int64_t capacity, int64_t* k);
+
 #ifdef __cplusplus
 }
 #endif
