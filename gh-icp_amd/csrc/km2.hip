@@ -67,23 +67,21 @@ __device__ inline int first_clear(const unsigned* __restrict__ bits, int y0, int
 }
 
 
-// First unvisited background-tight column in [start, limit): groups of 4 x 64 columns, the eight LDS reads of a group
-// issued together, ballots taken in ascending column order.  (Measured alternatives, all exact, all slower on the cfg2
-// matrices: one 64-column block per round; a 16 x 64 full sweep; a monotone "first unvisited" hint.)
+// First unvisited background-tight column in [start, limit), 64 columns per round.  A lone wave issues one instruction
+// every ~4 cycles, so the scan is written for the fewest instructions on the common path (a hit in the first block, which
+// the E7 pointer makes the rule): the two LDS reads are unconditional (clamped index) and issued together, the verdict is
+// formed with bitwise operators, one ballot decides.  (Measured alternatives, all exact, all slower on the cfg2 matrices:
+// 4 x 64 columns per round with the eight reads issued together; a 16 x 64 full sweep; short-circuit evaluation.)
 __device__ inline int bg_scan(const unsigned* __restrict__ visy, const double* __restrict__ ly, double lxv, double bg, double eps, int start,
-                              int limit, int lane) {
-  for (int y0 = start; y0 < limit; y0 += 256) {
-    bool t[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int y = y0 + 64 * k + lane;
-      t[k] = (y < limit) && !((visy[y >> 5] >> (y & 31)) & 1u) && ((lxv + ly[y]) - bg) < eps;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const unsigned long long b = __ballot(t[k]);
-      if (b) return y0 + 64 * k + (int)__ffsll((long long)b) - 1;
-    }
+                              int limit, int lane, long long* groups = nullptr) {
+  for (int y0 = start; y0 < limit; y0 += 64) {
+    if (groups) ++*groups;
+    const int y = y0 + lane, yc = min(y, limit - 1);
+    const unsigned vw = visy[yc >> 5];
+    const double lv = ly[yc];
+    const unsigned t = (unsigned)(y < limit) & (unsigned)(((vw >> (yc & 31)) & 1u) == 0u) & (unsigned)(((lxv + lv) - bg) < eps);
+    const unsigned long long b = __ballot(t != 0u);
+    if (b) return y0 + (int)__ffsll((long long)b) - 1;
   }
   return INT_MAX;
 }
@@ -95,6 +93,7 @@ typedef __attribute__((address_space(1))) unsigned long long* g_u64;
 // LDS per problem: lx, ly (f64), rptr (u32), match / stack x / stack y (u16), two bitmaps = 26.25 B per row.
 // slack lives in global memory (L2): explicit entries hit it with fire-and-forget 64-bit atomic minima (d >= eps > 0,
 // so the IEEE bit pattern orders like the value), the end of a failed phase reads it with L1-bypassing loads.
+template <bool PROF>
 __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs, int flags) {
   const Km2Problem P = probs[blockIdx.x];
   if (P.n <= 0 || (P.done && *P.done)) return;
@@ -120,6 +119,9 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
   __syncthreads();
 
   long long nsteps = 0;
+  // profiling (flags & 2, GHICP_KM_STATS): step mix and cycle split of the DFS
+  constexpr bool prof = PROF;  // GHICP_KM_STATS: step mix and cycle split of the DFS (compiled out otherwise)
+  long long q_bg = 0, q_grp = 0, q_hit = 0, q_succ = 0, q_fail = 0, q_failph = 0, q_csr = 0, c_csr = 0, c_bg = 0, c_move = 0, c_relabel = 0, q_push = 0;
   int bad = 0;
   for (int root = 0; root < n && !bad; ++root) {
     for (int i = lane; i < n; i += 64) slack[i] = INF_BITS;
@@ -130,123 +132,208 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
       if (lane == 0) { stx[0] = (unsigned short)root; sty[0] = (unsigned short)NONE; visx[root >> 5] = 1u << (root & 31); }
       __syncthreads();
       int sp = 0, x = root, ystart = 0;
-      int par_sp = -1, par_x = 0, par_ys = 0;  // register copy of the frame we just descended from
       double lxmin = lx[root];
       bool ok = false;
+      double ck = __longlong_as_double(0x7ff8000000000000ll);  // E7 cache, one entry per lane: NaN never matches
+      int cp = 0, cnext = 0;
+      const long long steps0 = nsteps;
+      // E8: the first 64 explicit entries of a row live in registers (one entry per lane), for the row being scanned
+      // (r*) and for the frame below it (p*).  A push loads the child's row while the stack is being updated, a pop takes
+      // the frame below from registers and starts loading the one below that: the L2 round trip of the CSR row is no
+      // longer on the critical path of the step.
+      unsigned rb, re, pb = 0, pe = 0;
+      int rcol = 0, pcol = 0;
+      double rval = 0.0, pval = 0.0;
+      int par_sp = -1, par_x = 0, par_ys = 0;
+#define KM2_LOAD_ROW(XR, B, E, C, V)                                   \
+  do {                                                                 \
+    B = rptr[XR]; E = rptr[(XR) + 1];                                  \
+    if (E > B) { const unsigned cc_ = min(B + (unsigned)lane, E - 1u); C = cols[cc_]; V = vals[cc_]; } \
+  } while (0)
+      KM2_LOAD_ROW(x, rb, re, rcol, rval);
       for (;;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
         nsteps++;
+        const long long tq0 = prof ? (long long)__builtin_readcyclecounter() : 0;
         const double lxv = lx[x];
         lxmin = fmin(lxmin, lxv);
         int best = INT_MAX;
-        // ---- E6 (experimental, OFF by default: measured 1.5-2.5x SLOWER on the cfg2 matrices because every lane walks a
-        // whole CSR row from L2 and runs are cut short by live children): retire runs of IMMEDIATELY DEAD children,
-        // 64 columns per wave iteration.
-        // A background-tight row selects every unvisited background-tight column in ascending order (E3) and
-        // recurses into its owner c = match[y].  findpath(c) returns false at once -- having visited nothing but c --
-        // when c has no background-tight edge (E2) and none of its explicit entries is tight and still unvisited,
-        // where "visited" at that moment = visited now, or inside [u, y] (every column of that span is visited by
-        // then: this holds for all lanes below the first lane that needs the generic path).  Retiring such a child
-        // is exactly what the recursion does: visy[y], visx[c], slack minima of c's explicit entries, lx[c] into lxmin.
-        if (!(flags & 1)) {
-          if ((lxv - bg) < eps) {
-            for (;;) {
-              const int u = first_clear(visy, ystart, n, nw, lane);
-              if (u >= n) break;
-              const int y = u + lane;
-              bool unv = false, tbg = false;
-              int c = NONE;
-              if (y < n) {
-                unv = !bit_get(visy, y);
-                if (unv) { tbg = ((lxv + ly[y]) - bg) < eps; c = match[y]; }
-              }
-              bool stop = unv && !tbg;  // the generic path must look at this column (it may be explicit-tight, or skipped)
-              bool deadc = false;
-              double lxc = 0.0;
-              if (unv && tbg) {
-                if (c == NONE) stop = true;  // free column: the generic path takes it and augments
-                else {
-                  lxc = lx[c];
-                  if ((lxc - bg) < eps) stop = true;  // the child has background-tight edges of its own
-                  else {
-                    bool live = false;
-                    const unsigned re = rptr[c + 1];
-                    for (unsigned e = rptr[c]; e < re; e++) {
-                      const int col = cols[e];
-                      if (((lxc + ly[col]) - vals[e]) < eps && !bit_get(visy, col) && (col < u || col > y)) { live = true; break; }
-                    }
-                    if (live) stop = true;
-                    else deadc = true;
-                  }
-                }
-              }
-              const unsigned long long bs = __ballot(stop);
-              const int L = bs ? (int)__ffsll((long long)bs) - 1 : 64;  // lanes below L are decided
-              const bool commit = deadc && lane < L;
-              double lm = 1.0e300;
-              if (commit) {
-                atomicOr(&visy[y >> 5], 1u << (y & 31));
-                atomicOr(&visx[c >> 5], 1u << (c & 31));
-                lm = lxc;
-                const unsigned re = rptr[c + 1];
-                for (unsigned e = rptr[c]; e < re; e++) {  // km.cpp:33 for the child's non-tight entries
-                  const int col = cols[e];
-                  const double d = (lxc + ly[col]) - vals[e];
-                  if (!(d < eps)) __hip_atomic_fetch_min(&slack[col], (unsigned long long)__double_as_longlong(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-              }
-#pragma unroll
-              for (int o = 32; o > 0; o >>= 1) lm = fmin(lm, __shfl_xor(lm, o, 64));
-              lxmin = fmin(lxmin, lm);
-              __builtin_amdgcn_wave_barrier();
-              if (L < 64) { ystart = u + L; break; }
-              ystart = u + 64;
-              if (ystart >= n) break;
+        // ---- E9: marching through a chain of label-sharing rows without explicit entries, up to 64 findpath() activations
+        // per wave iteration.  Such a row x (label L, background-tight) picks the lowest unvisited column of
+        // T_L = {y : fl(fl(L + ly[y]) - bg) < eps}; if that column's owner c is again a row without explicit entries and
+        // with lx[c] == L, findpath(c) starts from column 0, finds every lower member of T_L visited and picks the NEXT
+        // unvisited member -- and so on down the chain until a column is free (augment) or its owner is a different kind
+        // of row (generic path).  The 64 lanes test a window of candidate columns and their owners at once; everything up
+        // to the first stopping candidate is retired exactly as the recursion would: visy/visx bits, one stack frame per
+        // pick.  Rows of this kind have no explicit entries, hence no slack traffic, and L is already in lxmin.
+        if (re == rb && (lxv - bg) < eps && !(flags & 1)) {
+          const unsigned long long hit = __ballot(ck == lxv);
+          int slot, p = ystart;  // everything below ystart was rejected by this row's earlier scans: a valid E7 pointer too
+          if (hit) {
+            slot = (int)__ffsll((long long)hit) - 1;
+            p = max(p, __builtin_amdgcn_readlane(cp, slot));
+          } else {
+            slot = cnext;
+            cnext = (cnext + 1) & 63;
+            if (lane == slot) ck = lxv;
+          }
+          int outcome = 0;  // 0: x has no unvisited background-tight column left (falls through to the pop below)
+          while (p < n) {
+            const int y = p + lane, yc = min(y, n - 1);
+            const unsigned vw = visy[yc >> 5];
+            const double lv = ly[yc];
+            const bool cand = (y < n) & (((vw >> (yc & 31)) & 1u) == 0u) & (((lxv + lv) - bg) < eps);
+            const unsigned long long b = __ballot(cand);
+            if (!b) { p += 64; continue; }
+            int m = NONE;
+            bool cont = false;
+            if (cand) {
+              m = match[y];
+              if (m != NONE) cont = (rptr[m + 1] == rptr[m]) & (lx[m] == lxv);
             }
+            const unsigned long long stop = __ballot(cand && !cont);
+            const int jstar = stop ? (int)__ffsll((long long)stop) - 1 : 63;
+            const unsigned long long R = b & (~0ull >> (63 - jstar));  // the picks of this window, in column order
+            const unsigned long long below = R & ((1ull << lane) - 1ull);
+            const int rank = __popcll(below);
+            const int pm = __shfl(m, below ? 63 - __clzll((long long)below) : 0, 64);
+            if ((R >> lane) & 1ull) {
+              atomicOr(&visy[y >> 5], 1u << (y & 31));
+              sty[sp + rank] = (unsigned short)y;
+              if (rank > 0) stx[sp + rank] = (unsigned short)pm;  // the row that picked this column (frame sp holds x)
+              if (m != NONE) atomicOr(&visx[m >> 5], 1u << (m & 31));
+            }
+            const int k = __popcll(R), lastlane = 63 - __clzll((long long)R);
+            const int mlast = __builtin_amdgcn_readlane(m, lastlane);
+            nsteps += k - 1;  // the activation of x itself was counted above
+            sp += k - 1;      // frame of the row that made the last pick
+            p += lastlane + 1;
+            if (mlast == NONE) { outcome = 1; break; }
+            sp++;
+            if (lane == 0) { stx[sp] = (unsigned short)mlast; sty[sp] = (unsigned short)NONE; }
+            x = mlast; ystart = 0;
+            par_sp = -1;
+            if (stop) { outcome = 2; break; }  // the owner of the last pick is not part of the chain
+            nsteps++;                          // ... it is: its activation continues the march
           }
-        }
-        // ---- explicit entries of row x (E3); non-tight ones feed slack (km.cpp:33)
-        const unsigned cb = rptr[x], ce = rptr[x + 1];
-        for (unsigned c0 = cb; c0 < ce; c0 += 64) {
-          const unsigned c = c0 + lane;
-          int col = INT_MAX;
-          bool tight = false;
-          if (c < ce) {
-            col = cols[c];
-            const double d = (lxv + ly[col]) - vals[c];
-            if (d < eps) tight = col >= ystart && !bit_get(visy, col);
-            else __hip_atomic_fetch_min(&slack[col], (unsigned long long)__double_as_longlong(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          const unsigned long long b = __ballot(tight);
-          if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); break; }
-        }
-        // ---- background entries (E1, E2)
-        if ((lxv - bg) < eps) {
-          best = min(best, bg_scan(visy, ly, lxv, bg, eps, ystart, min(n, best), lane));
-        }
-        if (best != INT_MAX) {
-          const int ystar = best;
-          const int m = match[ystar];
-          if (lane == 0) { visy[ystar >> 5] |= 1u << (ystar & 31); sty[sp] = (unsigned short)ystar; }
+          if (lane == slot) cp = p;
           __builtin_amdgcn_wave_barrier();
-          if (m == NONE) {  // augment: match[y] = x on every level of the recursion (km.cpp:26-29)
+          if (outcome == 1) {  // augment (km.cpp:26-29)
             for (int f = lane; f <= sp; f += 64) match[sty[f]] = stx[f];
             ok = true;
             break;
           }
+          if (outcome == 2) {
+            KM2_LOAD_ROW(x, rb, re, rcol, rval);
+            continue;
+          }
+          // outcome 0: fall through with best == INT_MAX -> pop (x may be a row reached by the march: its frame is sp)
+          re = rb;
+        }
+        // ---- explicit entries of row x (E3); non-tight ones feed slack (km.cpp:33).  Loads are unconditional (clamped
+        // entry index) and the verdict uses bitwise operators so that the two LDS gathers are issued together.
+        if (re > rb) {
+          if (prof) q_csr++;
+          const bool in = rb + (unsigned)lane < re;
+          const double lyc = ly[rcol];
+          const unsigned vwc = visy[rcol >> 5];
+          const double d = (lxv + lyc) - rval;
+          const bool td = d < eps;
+          const bool tight = (int)in & (int)td & (int)(rcol >= ystart) & (int)(((vwc >> (rcol & 31)) & 1u) == 0u);
+          // a resumed frame (ystart > 0) already sent this block's slack minima when it was first activated
+          if (ystart == 0 && (in & !td)) __hip_atomic_fetch_min(&slack[rcol], (unsigned long long)__double_as_longlong(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long b0 = __ballot(tight);
+          if (b0) best = __builtin_amdgcn_readlane(rcol, (int)__ffsll((long long)b0) - 1);
+          else {
+            for (unsigned c0 = rb + 64u; c0 < re; c0 += 64) {  // rows with more than 64 explicit entries
+              if (prof) q_csr++;
+              const unsigned c = c0 + lane, cc = min(c, re - 1u);
+              const int colc = cols[cc];
+              const double wv = vals[cc];
+              const double ly2 = ly[colc];
+              const unsigned vw2 = visy[colc >> 5];
+              const double d2 = (lxv + ly2) - wv;
+              const bool in2 = c < re, td2 = d2 < eps;
+              const bool tight2 = (int)in2 & (int)td2 & (int)(colc >= ystart) & (int)(((vw2 >> (colc & 31)) & 1u) == 0u);
+              if (in2 & !td2) __hip_atomic_fetch_min(&slack[colc], (unsigned long long)__double_as_longlong(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned long long b2 = __ballot(tight2);
+              if (b2) { best = __builtin_amdgcn_readlane(colc, (int)__ffsll((long long)b2) - 1); break; }
+            }
+          }
+        }
+        const long long tq1 = prof ? (long long)__builtin_readcyclecounter() : 0;
+        // ---- background entries (E1, E2).  E7: whether a column is background-tight for a row depends on the row only
+        // through the VALUE of lx, ly is fixed within a phase and visited columns stay visited, so "every column below p
+        // is visited or not background-tight for this lx" survives until the phase ends.  One such p per distinct lx
+        // value lives in a lane (key ck, pointer cp): rows that share a label -- whole chains of them do, and each one
+        // re-scans when its child returns -- resume where the last scan for that label stopped.
+        if ((lxv - bg) < eps && (re > rb || (flags & 1))) {  // rows without explicit entries were handled by the march
+          const unsigned long long hit = __ballot(ck == lxv);
+          int slot, p0 = 0;
+          if (hit) {
+            slot = (int)__ffsll((long long)hit) - 1;
+            p0 = __builtin_amdgcn_readlane(cp, slot);
+          } else {
+            slot = cnext;
+            cnext = (cnext + 1) & 63;
+            if (lane == slot) { ck = lxv; cp = 0; }
+          }
+          const int lim = min(n, best);
+          if (prof) { q_bg++; q_hit += hit ? 1 : 0; }
+          const int yb = bg_scan(visy, ly, lxv, bg, eps, max(ystart, p0), lim, lane, prof ? &q_grp : nullptr);
+          if (ystart <= p0 && lane == slot) cp = (yb != INT_MAX) ? yb : max(p0, lim);
+          best = min(best, yb);
+        }
+        const long long tq2 = prof ? (long long)__builtin_readcyclecounter() : 0;
+        if (best != INT_MAX) {
+          if (prof) q_push++;
+          const int ystar = best;
+          const int m = match[ystar];
+          if (m == NONE) {  // augment: match[y] = x on every level of the recursion (km.cpp:26-29)
+            if (lane == 0) sty[sp] = (unsigned short)ystar;
+            __builtin_amdgcn_wave_barrier();
+            for (int f = lane; f <= sp; f += 64) match[sty[f]] = stx[f];
+            ok = true;
+            break;
+          }
+          // descend: this frame moves to the p* registers, the child's row is requested before the bookkeeping
+          pb = rb; pe = re; pcol = rcol; pval = rval;
           par_sp = sp; par_x = x; par_ys = ystar + 1;
+          KM2_LOAD_ROW(m, rb, re, rcol, rval);
+          if (lane == 0) {
+            atomicOr(&visy[ystar >> 5], 1u << (ystar & 31));  // ds_or without a return value: no read-modify-write round trip
+            sty[sp] = (unsigned short)ystar;
+            stx[sp + 1] = (unsigned short)m;
+            sty[sp + 1] = (unsigned short)NONE;
+            atomicOr(&visx[m >> 5], 1u << (m & 31));
+          }
           sp++;
-          if (lane == 0) { stx[sp] = (unsigned short)m; sty[sp] = (unsigned short)NONE; visx[m >> 5] |= 1u << (m & 31); }
           x = m; ystart = 0;
         } else {
           sp--;
           if (sp < 0) break;
-          if (sp == par_sp) { x = par_x; ystart = par_ys; par_sp = -1; }
-          else { x = stx[sp]; ystart = (int)sty[sp] + 1; }
+          if (sp == par_sp) {
+            x = par_x; ystart = par_ys;
+            rb = pb; re = pe; rcol = pcol; rval = pval;
+          } else {
+            x = stx[sp]; ystart = (int)sty[sp] + 1;
+            KM2_LOAD_ROW(x, rb, re, rcol, rval);
+          }
+          par_sp = -1;
+          if (sp > 0) {  // request the frame below: if this one fails too, its data is already here
+            par_sp = sp - 1;
+            par_x = stx[sp - 1];
+            par_ys = (int)sty[sp - 1] + 1;
+            KM2_LOAD_ROW(par_x, pb, pe, pcol, pval);
+          }
         }
         __builtin_amdgcn_wave_barrier();
+        if (prof) { const long long tq3 = (long long)__builtin_readcyclecounter(); c_csr += tq1 - tq0; c_bg += tq2 - tq1; c_move += tq3 - tq2; }
       }
+#undef KM2_LOAD_ROW
       __syncthreads();
-      if (ok) break;
+      if (ok) { if (prof) q_succ += nsteps - steps0; break; }
+      if (prof) { q_fail += nsteps - steps0; q_failph++; }
+      const long long tr0 = prof ? (long long)__builtin_readcyclecounter() : 0;
       // ---- failed phase: deferred background slack (E4) + relabel (km.cpp:80-98)
       __threadfence_block();  // every slack atomic of this phase has reached L2
       double dl = KM_INF2;
@@ -271,6 +358,7 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
       }
       __threadfence_block();
       __syncthreads();
+      if (prof) c_relabel += (long long)__builtin_readcyclecounter() - tr0;
       if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
     }
   }
@@ -278,7 +366,13 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
   for (int i = lane; i < n; i += 64) P.match_out[i] = match[i] == NONE ? -1 : (int)match[i];
   if (lane == 0) {
     if (bad && P.status) *P.status = bad;
-    if (P.steps) P.steps[0] = nsteps;
+    if (P.steps) {
+      P.steps[0] = nsteps;
+      if (prof) {
+        P.steps[1] = q_succ; P.steps[2] = q_fail; P.steps[3] = q_failph; P.steps[4] = q_bg; P.steps[5] = q_grp; P.steps[6] = q_hit; P.steps[7] = q_csr;
+        P.steps[8] = c_csr; P.steps[9] = c_bg; P.steps[10] = c_move; P.steps[11] = c_relabel; P.steps[12] = q_push;
+      }
+    }
   }
 }
 
@@ -572,7 +666,8 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   static bool attr_done = false;
   if (!attr_done) {
     const size_t want = 160 * 1024;
-    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     attr_done = true;
   }
@@ -582,7 +677,8 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   const size_t lds = v3 ? gh_km3_lds_bytes(n_max) : gh_km2_lds_bytes(n_max);
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
   if (v3) hipLaunchKernelGGL(k_km3, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
-  else hipLaunchKernelGGL(k_km2, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_E6") ? 0 : 1);  // E6 (batched dead children) is exact but slower: off unless GHICP_KM_E6=1
+  else if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL(k_km2<true>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_NOMARCH") ? 1 : 0);
+  else hipLaunchKernelGGL(k_km2<false>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_NOMARCH") ? 1 : 0);  // E6 (batched dead children) is exact but slower: off unless GHICP_KM_E6=1
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
@@ -633,8 +729,12 @@ int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32
     long long h[13];
     GH_HIP(hipMemcpyAsync(h, dstats, sizeof(h), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));
-    fprintf(stderr, "[km stats] n=%d steps=%lld overflow=%lld flat=%lld failph=%lld failrows=%lld cyc_dfs=%lld cyc_fail=%lld cyc_total=%lld | A=%lld B=%lld C=%lld (list+overflow %lld) D=%lld\n", n, h[0], h[1],
-            h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[12], h[11]);
+    if (getenv("GHICP_KM_V3"))
+      fprintf(stderr, "[km stats] n=%d steps=%lld overflow=%lld flat=%lld failph=%lld failrows=%lld cyc_dfs=%lld cyc_fail=%lld cyc_total=%lld | A=%lld B=%lld C=%lld (list+overflow %lld) D=%lld\n", n, h[0], h[1],
+              h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[12], h[11]);
+    else
+      fprintf(stderr, "[km2 stats] n=%d steps=%lld (successful phases %lld, failed phases %lld in %lld phases) push=%lld | bg scans=%lld groups=%lld cache hits=%lld | csr blocks=%lld | cycles: csr=%lld bg=%lld move=%lld relabel=%lld\n",
+              n, h[0], h[1], h[2], h[3], h[12], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
   }
   return GHICP_OK;
 }
