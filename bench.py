@@ -6,8 +6,15 @@ BSC feature + KM (Kuhn-Munkres) matching, 6-DoF.  A "step" = one complete pass o
 (voxel filter -> curvature keypoints -> BSC -> feature distance -> GH-ICP loop -> 4x4) over one BATCH of
 `--pairs-per-step` independent pairs whose raw clouds are already resident in HBM.  Independent scan pairs
 are the unit of parallelism of this problem: the per-pair KM solve is a dependency chain that
-occupies one wave, so a GPU is filled by keeping many pairs in flight; the batch is split over `--streams`
-contexts so that one half's front end overlaps the other half's loop.
+occupies one wave, so a GPU is filled by keeping many pairs in flight.  Default schedule (`--pipeline 1`): `--fe-streams`
+worker contexts run the per-cloud front ends (ghicp_cloud_recompute: voxel filter, keypoints, BSC) concurrently on their
+own streams, then `--loop-groups` batched loops (ghicp_register_clouds: feature distance + GH-ICP iterations, 1792 pairs
+each = 7 Kuhn-Munkres solves per CU x 256 CUs, one wave per solve) run concurrently on their own streams, so that the
+solve slots one group frees early are taken by the next group's launch instead of idling until the slowest solve of the
+iteration ends.  Every pair's two clouds go through the full front end in the timed region (nothing is reused between
+pairs or steps).  Measured alternatives: overlapping the front ends of step k+1 with the loop of step k (`--overlap 1`) is
+slower -- a solve launch fills every CU's LDS and the small front-end kernels starve -- as are 2 or 4 loop groups.  `--pipeline 0` is the earlier schedule: the batch split over `--streams` contexts that
+each run front ends + loop for their shard.
 With N GPUs every rank registers its own batch (no data-path collective): weak scaling,
 value = pairs of all ranks / max-over-ranks time.
 
@@ -18,7 +25,7 @@ value = pairs of all ranks / max-over-ranks time.
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the kernel's own stream)
 and `cpu_baseline` (the oracle = PCL-free restatement of the reference path, 1 thread, rank 0, N=1 only).
 """
-import argparse
+import argparse  # noqa: E402
 import importlib
 import json
 import os
@@ -30,6 +37,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ROCm maps HIP streams onto 4 hardware queues by default; the front-end workers want one each (read at HIP initialisation)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KERNELS = ("pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort")
@@ -51,6 +60,10 @@ def algorithmic_bytes(st, kernel, batch):
         return (24.0 * (ks + kt) + 4.0 * ks * kt) * batch
     if kernel == "fd_bsc":
         return 56.0 * (4 * ks + kt) + 2.0 * ks * kt
+    if kernel == "nms_round":  # S2: 20 B per down-sampled point in (xyz + curvature), 4 B per keypoint out; one launch per cloud
+        return 0.5 * (20.0 * (ms + mt) + 4.0 * (ks + kt))
+    if kernel == "voxel_sort":  # S0: 16 B per raw point in + 16 B per kept point out; one launch per cloud
+        return 0.5 * (16.0 * (st.n_s + st.n_t) + 16.0 * (ms + mt))
     return float("nan")
 
 
@@ -61,8 +74,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hits", type=int, default=1_000_000, help="points per scan (cfg2 = 1M)")
     ap.add_argument("--corr", default="KM", choices=["KM", "NN", "NNR"])
-    ap.add_argument("--pairs-per-step", type=int, default=2048, help="independent pairs in flight per GPU per step")
-    ap.add_argument("--streams", type=int, default=4, help="contexts/streams the batch is split over (front end / loop overlap)")
+    ap.add_argument("--pairs-per-step", type=int, default=5376, help="independent pairs per GPU per step (3 x 1792; 1792 = 7 KM solves per CU x 256 CUs)")
+    ap.add_argument("--pipeline", type=int, default=1, help="1: front-end worker streams + one batched loop (default); 0: per-stream register_pairs")
+    ap.add_argument("--fe-streams", type=int, default=16, help="front-end worker contexts/streams (pipeline mode)")
+    ap.add_argument("--loop-groups", type=int, default=3, help="pipeline mode: the step's pairs are registered by this many concurrent batched loops")
+    ap.add_argument("--overlap", type=int, default=0, help="pipeline mode: run the front ends of step k+1 during the loop of step k")
+    ap.add_argument("--streams", type=int, default=4, help="--pipeline 0: contexts/streams the batch is split over")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic pairs generated per rank (cycled inside the batch)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU (oracle) baseline leg")
     args = ap.parse_args()
@@ -89,33 +106,89 @@ def main():
     pairs = [synth.tls_pair(args.hits, config_id=2, pair_id=rank * args.distinct + i) for i in range(args.distinct)]
     gen_s = time.time() - t0
     B = max(1, args.pairs_per_step)
-    nstream = max(1, min(args.streams, B))
-    streams = [torch.cuda.Stream() for _ in range(nstream)]
-    ctxs = [api.Context(local_rank, stream=s) for s in streams]
     dev = [(torch.from_numpy(p.source).cuda(), torch.from_numpy(p.target).cuda()) for p in pairs]
     torch.cuda.synchronize()
     corr = {"KM": api.CORR_KM, "NN": api.CORR_NN, "NNR": api.CORR_NNR}[args.corr]
     cfg = api.pair_config(api.FEATURE_BSC, corr, 6, 0.6, 0.1, 0.5, 1.5, synth.bsc_pattern_glibc(), max_iter=200)
-    shards = [[dev[(i * nstream + s) % len(dev)] for i in range((B - s + nstream - 1) // nstream)] for s in range(nstream)]
-    results = [None] * nstream
+    phase_s = {"front_end": 0.0, "loop": 0.0}
+    if args.pipeline:
+        nstream = max(1, min(args.fe_streams, B))
+        G = max(1, min(args.loop_groups, B))
+        streams = [torch.cuda.Stream() for _ in range(nstream + G)]
+        ctxs = [api.Context(local_rank, stream=s) for s in streams]
+        fe_ctxs, loop_ctxs = ctxs[:nstream], ctxs[nstream:]
+        NB = 2 if args.overlap else 1
+        pools = [[None] * B for _ in range(NB)]  # (source, target) cloud handles; two sets when steps overlap (double buffering)
+        results = [None] * G
 
-    def run_shard(s, nsteps):
-        # every stream works through its shard of each step back to back; the streams are NOT re-synchronised between
-        # steps, so one stream's front end overlaps another stream's KM-bound loop (that is the point of the split)
-        for _ in range(nsteps):
-            results[s] = ctxs[s].register_pairs(cfg, shards[s])
+        def fe_worker(w, buf):
+            pool, c = pools[buf], fe_ctxs[w]
+            for i in range(w, B, nstream):
+                S, T = dev[i % len(dev)]
+                if pool[i] is None:
+                    pool[i] = (c.cloud_create(cfg, S), c.cloud_create(cfg, T))
+                else:
+                    pool[i][0].recompute(S)
+                    pool[i][1].recompute(T)
 
-    def run_steps(nsteps):
-        if nsteps <= 0:
-            return
-        if nstream == 1:
-            run_shard(0, nsteps)
-            return
-        th = [threading.Thread(target=run_shard, args=(s, nsteps)) for s in range(nstream)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        def front_ends(buf):
+            t = time.perf_counter()
+            th = [threading.Thread(target=fe_worker, args=(w, buf)) for w in range(nstream)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            phase_s["front_end"] += time.perf_counter() - t
+
+        def loop_group(g, buf):
+            results[g] = loop_ctxs[g].register_clouds(cfg, pools[buf][g * B // G:(g + 1) * B // G])
+
+        def loop(buf):
+            t = time.perf_counter()
+            th = [threading.Thread(target=loop_group, args=(g, buf)) for g in range(G)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            phase_s["loop"] += time.perf_counter() - t
+
+        def run_steps(nsteps):
+            if nsteps <= 0:
+                return
+            front_ends(0)
+            for k in range(nsteps):
+                if args.overlap and k + 1 < nsteps:
+                    tl = threading.Thread(target=loop, args=(k % NB,))
+                    tl.start()
+                    front_ends((k + 1) % NB)
+                    tl.join()
+                else:
+                    loop(k % NB)
+                    if k + 1 < nsteps:
+                        front_ends((k + 1) % NB)
+        shard_b = B // G
+    else:
+        nstream = max(1, min(args.streams, B))
+        streams = [torch.cuda.Stream() for _ in range(nstream)]
+        ctxs = [api.Context(local_rank, stream=s) for s in streams]
+        shards = [[dev[(i * nstream + s) % len(dev)] for i in range((B - s + nstream - 1) // nstream)] for s in range(nstream)]
+        results = [None] * nstream
+
+        def run_shard(s, nsteps):
+            # every stream works through its shard of each step back to back; the streams are NOT re-synchronised between
+            # steps, so one stream's front end overlaps another stream's KM-bound loop
+            for _ in range(nsteps):
+                results[s] = ctxs[s].register_pairs(cfg, shards[s])
+
+        def run_steps(nsteps):
+            if nsteps <= 0:
+                return
+            th = [threading.Thread(target=run_shard, args=(s, nsteps)) for s in range(nstream)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        shard_b = len(shards[0])
 
     def barrier():
         torch.cuda.synchronize()
@@ -124,8 +197,11 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
+    if args.pipeline and len(pools) > 1 and pools[1][0] is None:
+        front_ends(1)  # allocate the second handle set outside the timed region
     for c in ctxs:
         c.kernel_timing(True)
+    phase_s["front_end"] = phase_s["loop"] = 0.0
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -154,7 +230,6 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     Rg = np.array(stats.Rt[:]).reshape(4, 4)
     iters = max(1, stats.iterations)
-    shard_b = len(shards[0])
 
     # ---- roofline of the dominant kernel (largest share of HIP-event kernel time over the timed region)
     dom = max(ktimes, key=lambda k: ktimes[k][0])
@@ -170,8 +245,9 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,
                 "alg_bytes_per_launch": int(b_alg),
-                "note": "km_solve is a dependency chain (exact emulation of the reference's DFS order), latency- not bandwidth-bound; "
-                        "%d solves run concurrently per launch" % shard_b,
+                "note": ("km_solve is a dependency chain (exact emulation of the reference's DFS order), latency- not bandwidth-bound; "
+                         "%d solves run concurrently per launch" % shard_b) if dom == "km_solve" else
+                        ("%s has the largest summed HIP-event time over all streams (launches of different streams overlap in wall time)" % dom),
                 "per_kernel": per_kernel}
 
     # ---- CPU baseline: the oracle (faithful PCL-free restatement of the reference path), 1 thread
@@ -208,13 +284,18 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg2: synthetic ETH-like TLS pairs, %d pts/scan, voxel 0.1 m, r_pca 0.5, R_nms 1.5, BSC + %s, 6-DoF; "
-                               "%d independent pairs in flight per GPU per step (%d distinct scenes cycled), %d streams"
-                               % (args.hits, args.corr, B, args.distinct, nstream),
+                               "%d independent pairs in flight per GPU per step (%d distinct scenes cycled), %s"
+                               % (args.hits, args.corr, B, args.distinct,
+                                  ("%d front-end streams, then %d concurrent batched loop(s)%s" % (nstream, args.loop_groups, ", front ends of step k+1 overlap the loop of step k" if args.overlap else ""))
+                                  if args.pipeline else "%d streams" % nstream),
                    "pairs_per_step": B, "n_s": int(stats.n_s), "m_s": int(stats.m_s), "m_t": int(stats.m_t), "k_s": int(stats.k_s),
                    "k_t": int(stats.k_t), "iterations": int(stats.iterations), "parallelism": "pairs sharded over ranks, no data-path collective"},
         "ms_per_iteration": round(ms_per_step / iters, 4),
         "ms_per_iteration_note": "wall time of one batched step / iterations of pair 0: every in-flight pair advances one iteration in that time",
-        "batch_ms": {"front_end_per_pair": round(stats.ms_keypoints, 3), "loop_per_pair": round(stats.ms_loop, 3)},
+        "batch_ms": ({"front_end_wall_per_step": round(1e3 * phase_s["front_end"] / max(1, args.steps), 1),
+                      "loop_wall_per_step": round(1e3 * phase_s["loop"] / max(1, args.steps), 1),
+                      "fd_per_pair": round(stats.ms_fd, 3), "loop_per_pair": round(stats.ms_loop, 3)} if args.pipeline else
+                     {"front_end_per_pair": round(stats.ms_keypoints, 3), "loop_per_pair": round(stats.ms_loop, 3)}),
         "gt_error": {"rot": round(synth.rot_err(Rg, pairs[0].gt), 6), "trans_m": round(synth.trans_err(Rg, pairs[0].gt), 5)},
         "roofline": roofline, "cpu_baseline": cpu, "parity_check": check, "gen_seconds": round(gen_s, 1),
     }

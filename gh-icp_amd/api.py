@@ -52,7 +52,7 @@ EXPORTS = [
     "ghicp_register_pairs",
     "ghicp_icp_params_default", "ghicp_cal_overlap", "ghicp_icp", "ghicp_knn_normals", "ghicp_nn_search", "ghicp_inv_transform",
     "ghicp_transform_cloud_f32",
-    "ghicp_cloud_create", "ghicp_cloud_from_features", "ghicp_cloud_destroy", "ghicp_cloud_get_info", "ghicp_cloud_download",
+    "ghicp_cloud_create", "ghicp_cloud_recompute", "ghicp_cloud_from_features", "ghicp_cloud_destroy", "ghicp_cloud_get_info", "ghicp_cloud_download",
     "ghicp_register_clouds", "ghicp_sbf_write", "ghicp_sbf_read",
 ]
 
@@ -442,6 +442,12 @@ class Cloud:
             feat = t.empty((i.k, 33), dtype=t.float32, device=c.dev)
         c._check(c.lib.ghicp_cloud_download(self.h, _ptr(ds), _ptr(kp), _ptr(kpx), _ptr(feat)))
         return dict(ds=ds, kp=kp, kp_xyz=kpx, feat=feat)
+
+    def recompute(self, xyz):
+        """Front end of another raw cloud into this handle (buffers reused)."""
+        x = self.ctx._xyz(xyz)
+        self.ctx._check(self.ctx.lib.ghicp_cloud_recompute(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1]))
+        return self
 
     def close(self):
         if self.h:

@@ -57,17 +57,13 @@ bool same_front_end(const ghicp_pair_config& a, const ghicp_pair_config& b) {
 
 }  // namespace
 
-extern "C" int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* xyz, int64_t n, int stride, ghicp_cloud** out) {
-  if (!ctx) return GHICP_ERR_ARG;
-  GH_ARG(cfg != nullptr && out != nullptr && stride >= 3 && n >= 0 && n < (1ll << 31) - 2);
-  GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
+// (re)computes the cached results of `c` for a raw cloud; buffers are grow-only, so a handle that is recomputed every
+// step of a steady-state pipeline performs no allocation.  Ends with a stream synchronisation: afterwards the handle may
+// be used from any context of the same device.
+static int cloud_fill(ghicp_ctx* ctx, ghicp_cloud* c, const float* d, long long n, int stride) {
   hipStream_t s = ctx->stream;
-  Stager sg(ctx);
-  const float* d;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
-  ghicp_cloud* c = new ghicp_cloud();
-  struct Guard { ghicp_cloud* c; ~Guard() { if (c) { c->ds.release(); c->kp.release(); c->kpx.release(); c->feat.release(); delete c; } } } guard{c};
-  c->ctx = ctx; c->cfg = *cfg; c->n = n;
+  const ghicp_pair_config* cfg = &c->cfg;
+  c->n = n; c->m = 0; c->k = 0;
   c->V = cfg->reg.dof > 4 ? 4 : (cfg->reg.dof > 0 ? 2 : 1);
   // down-sampling (main:89-90)
   if (cfg->voxel > 0.f) {
@@ -105,10 +101,34 @@ extern "C" int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, 
     GH_TRY(gh_fpfh_dev(ctx, ds, c->m, 4, nullptr, hist));
     GH_TRY(gh_gather_rows33_dev(ctx, hist, c->kp.as<int>(), c->k, c->feat.as<float>()));
   }
-  GH_HIP(hipStreamSynchronize(s));  // staged input may be released now
-  guard.c = nullptr;
+  GH_HIP(hipStreamSynchronize(s));
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* xyz, int64_t n, int stride, ghicp_cloud** out) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(cfg != nullptr && out != nullptr && stride >= 3 && n >= 0 && n < (1ll << 31) - 2);
+  GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
+  Stager sg(ctx);
+  const float* d;
+  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  ghicp_cloud* c = new ghicp_cloud();
+  c->ctx = ctx; c->cfg = *cfg;
+  const int rc = cloud_fill(ctx, c, d, n, stride);
+  if (rc != GHICP_OK) { ghicp_cloud_destroy(c); return rc; }
   *out = c;
   return GHICP_OK;
+}
+
+// Recomputes an existing handle for another raw cloud (same front-end configuration), reusing its buffers.
+extern "C" int ghicp_cloud_recompute(ghicp_cloud* c, const float* xyz, int64_t n, int stride) {
+  if (!c || !c->ctx) return GHICP_ERR_ARG;
+  ghicp_ctx* ctx = c->ctx;
+  GH_ARG(stride >= 3 && n >= 0 && n < (1ll << 31) - 2);
+  Stager sg(ctx);
+  const float* d;
+  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  return cloud_fill(ctx, c, d, n, stride);
 }
 
 extern "C" int ghicp_cloud_from_features(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const double* kp_xyz, int64_t k, const void* feat,
@@ -197,7 +217,7 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
   GH_HIP(hipEventRecord(e0, s));
   for (int i = 0; i < n_pairs; i++) {
     const ghicp_cloud *a = S[i], *b = T[i];
-    GH_ARG(a != nullptr && b != nullptr && a->ctx == ctx && b->ctx == ctx);
+    GH_ARG(a != nullptr && b != nullptr && a->ctx && b->ctx && a->ctx->device == ctx->device && b->ctx->device == ctx->device);
     if (!same_front_end(a->cfg, *cfg) || !same_front_end(b->cfg, *cfg))
       return ctx->fail(GHICP_ERR_ARG, "ghicp_register_clouds: pair %d was cached with a different front-end configuration", i);
     memset(&stats[i], 0, sizeof(stats[i]));

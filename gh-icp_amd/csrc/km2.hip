@@ -674,11 +674,17 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   // v2 and v3 solve at the same speed (the DFS is instruction-issue bound, not memory bound: profiles/r01_km_step_counters.txt);
   // v2 needs less LDS per problem, so more problems are resident per CU -> default. GHICP_KM_V3=1 selects the list kernel.
   const bool v3 = n_max <= 65534 && gh_km3_lds_bytes(n_max) <= 160 * 1024 - 256 && getenv("GHICP_KM_V3") != nullptr;
-  const size_t lds = v3 ? gh_km3_lds_bytes(n_max) : gh_km2_lds_bytes(n_max);
+  size_t lds = v3 ? gh_km3_lds_bytes(n_max) : gh_km2_lds_bytes(n_max);
+  // GHICP_KM_SLOTS=s: never more than s solves resident per CU (the request is padded to 160 KB / s), which leaves LDS and
+  // wave slots to kernels of other streams -- e.g. the front ends of the next batch -- while a solve launch fills the chip.
+  if (const char* e = getenv("GHICP_KM_SLOTS")) {
+    const int slots = atoi(e);
+    if (slots >= 1 && slots <= 32) lds = std::max(lds, (size_t)(160 * 1024) / (size_t)(slots + 1) + 1024);
+  }
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
   if (v3) hipLaunchKernelGGL(k_km3, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
   else if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL(k_km2<true>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_NOMARCH") ? 1 : 0);
-  else hipLaunchKernelGGL(k_km2<false>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_NOMARCH") ? 1 : 0);  // E6 (batched dead children) is exact but slower: off unless GHICP_KM_E6=1
+  else hipLaunchKernelGGL(k_km2<false>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_NOMARCH") ? 1 : 0);
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;

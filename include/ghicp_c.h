@@ -256,6 +256,10 @@ int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float
 /* rebuilds a handle from stored results: kp_xyz k x 3 f64, feat = V*k*56 BSC bytes (variant-major) or k x 33 f32 FPFH rows */
 int ghicp_cloud_from_features(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const double* kp_xyz, int64_t k, const void* feat,
                               float bbx_magnitude, ghicp_cloud** out);
+/* recomputes a handle for another raw cloud with the configuration it was created with, reusing its buffers (no
+ * allocation in a steady-state pipeline).  Handles are synchronised when these calls return and may then be passed to
+ * ghicp_register_clouds of ANY context on the same device. */
+int ghicp_cloud_recompute(ghicp_cloud* cloud, const float* xyz, int64_t n, int stride);
 int ghicp_cloud_destroy(ghicp_cloud* cloud);
 int ghicp_cloud_get_info(const ghicp_cloud* cloud, ghicp_cloud_info* info /*[host]*/);
 /* any destination may be NULL: ds_xyz m x 3 f32, kp_idx k, kp_xyz k x 3 f64, feat feature_bytes */
