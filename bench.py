@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, help="1: front-end worker streams + one batched loop (default); 0: per-stream register_pairs")
     ap.add_argument("--fe-streams", type=int, default=16, help="front-end worker contexts/streams (pipeline mode)")
     ap.add_argument("--loop-groups", type=int, default=3, help="pipeline mode: the step's pairs are registered by this many concurrent batched loops")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="pipeline mode: CUs (multiple of 8) kept free of loop kernels via a CU-masked loop stream")
     ap.add_argument("--overlap", type=int, default=0, help="pipeline mode: run the front ends of step k+1 during the loop of step k")
     ap.add_argument("--streams", type=int, default=4, help="--pipeline 0: contexts/streams the batch is split over")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic pairs generated per rank (cycled inside the batch)")
@@ -117,6 +118,12 @@ def main():
         streams = [torch.cuda.Stream() for _ in range(nstream + G)]
         ctxs = [api.Context(local_rank, stream=s) for s in streams]
         fe_ctxs, loop_ctxs = ctxs[:nstream], ctxs[nstream:]
+        if args.reserve_cus > 0:
+            # 4 bits at the start of every 32-CU word: no XCD loses all its CUs whichever way the mask bits map onto XCDs
+            per = max(1, args.reserve_cus // 8)
+            word = (0xFFFFFFFF << per) & 0xFFFFFFFF
+            for c in loop_ctxs:
+                c.set_cu_mask([word] * 8)
         NB = 2 if args.overlap else 1
         pools = [[None] * B for _ in range(NB)]  # (source, target) cloud handles; two sets when steps overlap (double buffering)
         results = [None] * G

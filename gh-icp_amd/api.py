@@ -44,7 +44,7 @@ class PairStats(C.Structure):
 
 
 EXPORTS = [
-    "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers",
+    "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_set_cu_mask",
     "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
@@ -146,6 +146,11 @@ class Context:
 
     def set_stream(self, stream):
         self._check(self.lib.ghicp_ctx_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def set_cu_mask(self, mask_words):
+        """Own stream restricted to the CUs whose bit is set (list of uint32 words, 32 CUs each)."""
+        m = (C.c_uint32 * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
+        self._check(self.lib.ghicp_ctx_set_cu_mask(self.h, m, len(mask_words)))
 
     def close(self):
         if getattr(self, "h", None):

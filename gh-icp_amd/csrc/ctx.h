@@ -111,6 +111,7 @@ struct ghicp_ctx {
   }
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;  // created by ghicp_ctx_set_cu_mask
   bool host_ptrs = false;
   std::string err;
   DevBuf buf[B_NUM];

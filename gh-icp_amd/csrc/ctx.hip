@@ -52,6 +52,7 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
   for (auto& b : ctx->pairbuf) b.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return GHICP_OK;
 }
@@ -61,6 +62,23 @@ extern "C" int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* s) {
   ctx->stream = reinterpret_cast<hipStream_t>(s);
   return GHICP_OK;
 }
+// Replaces the context's stream by one that may only use the compute units whose bit is set in `mask` (32 CUs per word,
+// hipExtStreamCreateWithCUMask).  Used to keep a few CUs free of Kuhn-Munkres waves -- whose LDS footprint otherwise
+// fills every CU -- so that the small front-end kernels of the next batch run next to a solve launch.
+extern "C" int ghicp_ctx_set_cu_mask(ghicp_ctx* ctx, const uint32_t* mask, int32_t n_words) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(mask != nullptr && n_words >= 1 && n_words <= 64);
+  bool any = false;
+  for (int i = 0; i < n_words; i++) any = any || mask[i] != 0u;
+  GH_ARG(any);
+  hipStream_t s = nullptr;
+  GH_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+  if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
+  ctx->own_stream = s;
+  ctx->stream = s;
+  return GHICP_OK;
+}
+
 extern "C" int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on) {
   if (!ctx) return GHICP_ERR_ARG;
   ctx->host_ptrs = on != 0;

@@ -71,6 +71,9 @@ typedef struct ghicp_iter {
 int ghicp_ctx_create(int device, ghicp_ctx** ctx);
 int ghicp_ctx_destroy(ghicp_ctx* ctx);
 int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* hip_stream);
+/* Gives the context its own stream restricted to the compute units whose bit is set (32 CUs per word); replaces any stream
+ * set before.  Lets a pipeline keep some CUs free of the LDS-filling solve waves for another context's small kernels. */
+int ghicp_ctx_set_cu_mask(ghicp_ctx* ctx, const uint32_t* mask, int32_t n_words);
 int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on);
 int ghicp_ctx_synchronize(ghicp_ctx* ctx);
 const char* ghicp_last_error(const ghicp_ctx* ctx);
