@@ -655,7 +655,9 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
                 if (hp[b].kmw) GH_TRY(gh_km_solve_dev(ctx, hp[b].kmw, hp[b].C.n, hp[b].C.km_eps, hp[b].kmmatch, &hp[b].st->done));
             }
           }
-          hipLaunchKernelGGL(k_solve<FT>, dim3(nb), dim3(1024), 0, s, dprobs);
+          // 256 threads: four waves of this kernel (108 VGPRs) fit next to the Kuhn-Munkres waves of other batches on a CU;
+          // a 1024-thread block needs a CU with no resident solve wave and stalls for a whole solve launch when batches overlap
+          hipLaunchKernelGGL(k_solve<FT>, dim3(nb), dim3(256), 0, s, dprobs);
         }
         GH_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_collect_done, dim3(cdiv(nb, 256)), dim3(256), 0, s, dprobs, nb, dflags);
