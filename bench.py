@@ -249,8 +249,18 @@ def main():
         ba = algorithmic_bytes(stats, k, shard_b)
         per_kernel[k] = {"ms_total": round(v[0], 3), "launches": v[1],
                          "GBps": round(ba / (v[0] / max(1, v[1]) * 1e-3) / 1e9, 2) if v[0] > 0 and ba == ba else None}
+    # HBM-side traffic of the dominant kernel from the committed PMC passes (counters cannot be collected inside this run)
+    traffic, traffic_note = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if dom in pmc:
+            units = shard_b if pmc[dom]["per"] in ("solve", "pair") else 1
+            traffic = int(pmc[dom]["bytes"] * units)
+            traffic_note = "%d B per %s x %d (%s)" % (pmc[dom]["bytes"], pmc[dom]["per"], units, pmc["source"])
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,
                 "alg_bytes_per_launch": int(b_alg),
                 "note": ("km_solve is a dependency chain (exact emulation of the reference's DFS order), latency- not bandwidth-bound; "
                          "%d solves run concurrently per launch" % shard_b) if dom == "km_solve" else
