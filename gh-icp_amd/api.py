@@ -47,7 +47,7 @@ EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_set_cu_mask",
     "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
-    "ghicp_nms", "ghicp_keypoints", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
+    "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
     "ghicp_register_pairs",
     "ghicp_icp_params_default", "ghicp_cal_overlap", "ghicp_icp", "ghicp_knn_normals", "ghicp_nn_search", "ghicp_inv_transform",
@@ -301,6 +301,18 @@ class Context:
         self._check(self.lib.ghicp_keypoints(self.h, _ptr(x), C.c_int64(m), x.shape[1], C.c_float(radius), C.c_float(ratio_max), min_n,
                                              C.c_float(nms_radius), _ptr(kp), C.byref(k)))
         return kp[: k.value]
+
+    def keypoints_adaptive(self, xyz, radius, nms_radius, ratio_max=0.65, min_n=20, upper=50000, lower=5000):
+        """keypointDetectionBasedOnCurvature_adaptive: returns (kp tensor, ratio_used, rounds)."""
+        t = self.torch
+        x = self._xyz(xyz)
+        m = x.shape[0]
+        kp = t.empty(max(m, 1), dtype=t.int32, device=self.dev)
+        k, ru, nr = C.c_int64(0), C.c_float(0), C.c_int32(0)
+        self._check(self.lib.ghicp_keypoints_adaptive(self.h, _ptr(x), C.c_int64(m), x.shape[1], C.c_float(radius), C.c_float(ratio_max), min_n,
+                                                      C.c_float(nms_radius), C.c_int64(upper), C.c_int64(lower), _ptr(kp), C.byref(k),
+                                                      C.byref(ru), C.byref(nr)))
+        return kp[: k.value], ru.value, nr.value
 
     def bsc_encode(self, xyz, kp, radius, dof, pattern):
         t = self.torch

@@ -331,6 +331,62 @@ int gh_keypoints_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, 
   return gh_nms_dev(ctx, xyz, stride, curv, cand, c, nms_radius, kp, k_out);
 }
 
+// CKeypointDetect::keypointDetectionBasedOnCurvature_adaptive (include/keypoint_detect.hpp:53-111): the PCA features are
+// computed once; prune + NMS are repeated with ratioMax -= 0.05 while more than `upper` keypoints come out (one step of
+// +0.025 and stop once fewer than `lower` do), never below 0.65.  float/double mixing as in the reference.
+int gh_keypoints_adaptive_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float radius, float ratio_max, int min_n, float nms_radius,
+                              long long upper, long long lower, int32_t* kp, long long* k_out, float* ratio_used, int* rounds) {
+  *k_out = 0;
+  if (ratio_used) *ratio_used = ratio_max;
+  if (rounds) *rounds = 0;
+  if (m <= 0) return GHICP_OK;
+  float* lambda;
+  double* curv;
+  int *count, *cand;
+  GH_TRY(ctx->reserve(B_FE_LAMBDA, (size_t)m * 3 + 3, &lambda));
+  GH_TRY(ctx->reserve(B_FE_CURV, (size_t)m + 1, &curv));
+  GH_TRY(ctx->reserve(B_FE_COUNT, (size_t)m + 1, &count));
+  GH_TRY(ctx->reserve(B_FE_CAND, (size_t)m + 1, &cand));
+  GH_TRY(gh_pca_dev(ctx, xyz, m, stride, radius, lambda, curv, count));
+  long long c = 0, K = 0;
+  GH_TRY(gh_prune_dev(ctx, lambda, count, m, ratio_max, min_n, cand, &c));
+  GH_TRY(gh_nms_dev(ctx, xyz, stride, curv, cand, c, nms_radius, kp, &K));
+  bool finish = false;
+  float ratioMax = ratio_max;
+  int nr = 0;
+  if (K > upper) {
+    do {
+      if (K < lower) { ratioMax += 0.025; finish = true; }
+      else ratioMax -= 0.05;
+      GH_TRY(gh_prune_dev(ctx, lambda, count, m, ratioMax, min_n, cand, &c));
+      GH_TRY(gh_nms_dev(ctx, xyz, stride, curv, cand, c, nms_radius, kp, &K));
+      nr++;
+    } while ((K < lower || K > upper) && !finish && ratioMax >= 0.65);
+  }
+  *k_out = K;
+  if (ratio_used) *ratio_used = ratioMax;
+  if (rounds) *rounds = nr;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_keypoints_adaptive(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float ratio_max, int min_n,
+                                        float nms_radius, int64_t upper, int64_t lower, int32_t* kp_idx, int64_t* k, float* ratio_used,
+                                        int32_t* rounds) {
+  if (!ctx) return GHICP_ERR_ARG;
+  GH_ARG(m >= 0 && m < (1ll << 31) - 2 && stride >= 3 && radius > 0.f && nms_radius > 0.f && k != nullptr && upper >= 0 && lower >= 0);
+  Stager sg(ctx);
+  const float* d;
+  int32_t* dk;
+  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.out(kp_idx, (size_t)m, &dk));
+  long long kk = 0;
+  int nr = 0;
+  GH_TRY(gh_keypoints_adaptive_dev(ctx, d, m, stride, radius, ratio_max, min_n, nms_radius, upper, lower, dk, &kk, ratio_used, &nr));
+  *k = kk;
+  if (rounds) *rounds = nr;
+  return sg.finish();
+}
+
 extern "C" int ghicp_nms(ghicp_ctx* ctx, const float* xyz, int stride, const double* curvature, const int32_t* cand, int64_t c, float radius,
                          int32_t* kp, int64_t* k) {
   if (!ctx) return GHICP_ERR_ARG;

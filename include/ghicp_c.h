@@ -109,6 +109,12 @@ int ghicp_nms(ghicp_ctx* ctx, const float* xyz, int stride, const double* curvat
  * PCA -> prune -> NMS.  kp_idx: capacity m; *k [host]. */
 int ghicp_keypoints(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float ratio_max, int min_n, float nms_radius,
                     int32_t* kp_idx, int64_t* k);
+/* CKeypointDetect::keypointDetectionBasedOnCurvature_adaptive (include/keypoint_detect.hpp:53-111).  The reference's
+ * constants are upper = 50000, lower = 5000; ratio_used / rounds [host] (may be NULL) report the final threshold and the
+ * number of extra prune + NMS rounds. */
+int ghicp_keypoints_adaptive(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float ratio_max, int min_n,
+                             float nms_radius, int64_t upper, int64_t lower, int32_t* kp_idx, int64_t* k, float* ratio_used,
+                             int32_t* rounds);
 
 /* BSCEncoder::extractBinaryFeatures (include/binary_feature_extraction.hpp:603-676).
  * pattern: 49 x 2 int32 [host] (the sample_pattern.txt content, bfe:63-117).

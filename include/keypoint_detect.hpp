@@ -25,6 +25,19 @@ template <typename PointT> class CKeypointDetect {
     return true;
   }
 
+  // keypoint_detect.hpp:53-111: the ratio threshold is lowered in steps of 0.05 while more than 50000 keypoints come out
+  bool keypointDetectionBasedOnCurvature_adaptive(const typename pcl::PointCloud<PointT>::Ptr& inputPointCloud, pcl::PointIndicesPtr& keypointIndices) {
+    keypointIndices = pcl::PointIndicesPtr(new pcl::PointIndices());
+    const int64_t m = (int64_t)inputPointCloud->points.size();
+    keypointIndices->indices.assign((size_t)(m > 0 ? m : 1), 0);
+    int64_t k = 0;
+    detail::check(ghicp_keypoints_adaptive(detail::ctx(), detail::xyz(*inputPointCloud), m, detail::stride<PointT>(), _neighborhood_radius,
+                                           _ratio_unstable_thre, _min_point_num_neighborhood, _curvature_non_max_radius, 50000, 5000,
+                                           keypointIndices->indices.data(), &k, nullptr, nullptr));
+    keypointIndices->indices.resize((size_t)k);
+    return true;
+  }
+
  private:
   float _neighborhood_radius, _ratio_unstable_thre;
   int _min_point_num_neighborhood;

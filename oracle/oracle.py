@@ -317,3 +317,13 @@ def icp(src, tgt, params: IcpParams, want_trace=False):
     d.update(done=int(done), T=T.reshape(4, 4), transformed=out, corr0=corr0,
              trace=None if tr is None else tr[:st.iterations].reshape(-1, 4, 4))
     return d
+
+
+def keypoints_adaptive(xyz, radius, R_nms, ratio_max=0.65, min_n=20, upper=50000, lower=5000):
+    """keypointDetectionBasedOnCurvature_adaptive (keypoint_detect.hpp:53-111). Returns (kp, ratio_used, rounds)."""
+    xyz = _f32(xyz)
+    kp = np.empty(max(1, xyz.shape[0]), np.int32)
+    ru, nr = C.c_float(0), C.c_int(0)
+    k = lib().orc_keypoints_adaptive(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], C.c_float(radius), C.c_float(ratio_max), min_n,
+                                     C.c_float(R_nms), C.c_longlong(upper), C.c_longlong(lower), _p(kp, C.c_int), C.byref(ru), C.byref(nr))
+    return kp[:k].copy(), ru.value, nr.value

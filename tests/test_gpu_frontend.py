@@ -196,3 +196,13 @@ def test_pair_pipeline_fpfh_nnr(ctx, api, oracle, synth, tls):
     Rg = np.array(stats.Rt[:]).reshape(4, 4)
     assert stats.iterations == ro["iters"]
     assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
+
+
+def test_adaptive_keypoints(ctx, oracle, ds_target):
+    """keypointDetectionBasedOnCurvature_adaptive (keypoint_detect.hpp:53-111) with the range scaled down so that the loop runs."""
+    plain, _ = oracle.keypoints(ds_target, 0.5, 0.6, 0.9)
+    for upper, lower in ((10 ** 6, 10), (plain.size - 1, plain.size // 2), (plain.size // 3, plain.size // 4), (5, 2)):
+        ko, ro, no = oracle.keypoints_adaptive(ds_target, 0.5, 0.6, 0.9, upper=upper, lower=lower)
+        kg, rg, ng = ctx.keypoints_adaptive(ds_target, 0.5, 0.6, 0.9, upper=upper, lower=lower)
+        np.testing.assert_array_equal(kg.cpu().numpy(), ko)
+        assert (rg, ng) == (ro, no)

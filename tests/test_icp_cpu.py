@@ -105,3 +105,29 @@ def test_icp_refuses_low_overlap_and_counts_iterations(oracle, synth):
     assert r["done"] == 0 and r["overlap"] < 0.01
     r = oracle.icp(src, tgt, oracle.icp_params(2, False, False, 0))
     assert r["iterations"] == 2 and r["reason"] == 1  # CONVERGENCE_CRITERIA_ITERATIONS
+
+
+def test_adaptive_keypoints_restatement(oracle, synth):
+    """keypointDetectionBasedOnCurvature_adaptive (keypoint_detect.hpp:53-111): the loop only moves the ratio threshold, so
+    its result must equal the plain detector run at the reported threshold, and the thresholds follow the reference's
+    float arithmetic (-= 0.05 per round, += 0.025 once when the count drops below the lower bound)."""
+    p = synth.tls_pair(60_000)
+    ds = p.target[oracle.voxel_filter(p.target, 0.1)]
+    plain, _ = oracle.keypoints(ds, 0.5, 0.6, 0.9)
+    assert plain.size > 120
+    # never enters the loop: same as the plain detector
+    kp, ru, nr = oracle.keypoints_adaptive(ds, 0.5, 0.6, 0.9, upper=10 ** 6, lower=10)
+    np.testing.assert_array_equal(kp, plain)
+    assert nr == 0 and ru == np.float32(0.9)
+    # enters the loop
+    kp, ru, nr = oracle.keypoints_adaptive(ds, 0.5, 0.6, 0.9, upper=plain.size - 1, lower=plain.size // 2)
+    assert nr >= 1
+    expect = np.float32(0.9)
+    path = []
+    for _ in range(nr):
+        path.append(expect)
+        expect = np.float32(np.float64(expect) - 0.05)
+    assert ru in (expect, np.float32(np.float64(path[-1]) + 0.025)) or ru == expect
+    again, _ = oracle.keypoints(ds, 0.5, 0.6, float(ru))
+    np.testing.assert_array_equal(kp, again)
+    assert kp.size <= plain.size
