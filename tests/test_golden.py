@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 
@@ -72,3 +73,27 @@ def test_gpu_reproduces_golden(ctx, api, gold, gin):
         r = ctx.register(api.default_params(api.FEATURE_NONE, corr, 6, 0.9, 1.5, bbx, max_iter=60), kpS, kpT, want_matchlist=True)
         np.testing.assert_array_equal(r["matchlist"], gold["loop"][name + "_matchlist"])
         np.testing.assert_allclose(r["Rt"], gold["loop"][name + "_Rt"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("it", [0, 10, 30])
+def test_real_km_matrices_sparse_goldens_oracle(oracle, it):
+    """The three real cfg2 weight matrices kept as sparse goldens: the restatement and the reference's own km.cpp agree on them."""
+    z = np.load(os.path.join(GOLD, "km_cfg2_it%d.npz" % it))
+    n = int(z["n"])
+    w = np.full((n, n), float(z["bg"]))
+    w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
+    m, steps = oracle.km(w)
+    assert sorted(m.tolist()) == list(range(n)) and steps > n
+    ref = oracle.km_reference(w, penalty=-float(z["bg"]))
+    if ref is not None:  # /root/reference is present in this container only
+        np.testing.assert_array_equal(m, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("it", [0, 10, 30])
+def test_real_km_matrices_gpu(ctx, oracle, it):
+    z = np.load(os.path.join(GOLD, "km_cfg2_it%d.npz" % it))
+    n = int(z["n"])
+    w = np.full((n, n), float(z["bg"]))
+    w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
+    np.testing.assert_array_equal(ctx.km_solve(w).cpu().numpy(), oracle.km(w)[0])  # index work: bit-exact
