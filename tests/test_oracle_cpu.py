@@ -280,3 +280,54 @@ def test_product_never_touches_the_oracle():
                 if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "ghicp_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_every_abi_struct_has_the_layout_the_bindings_assume(api, tmp_path):
+    """sizeof / offsetof of every struct of include/ghicp_c.h as gcc lays it out, against the ctypes mirrors in api.py and
+    the oracle's own structs (the parity tests pass the same parameter blocks to both sides)."""
+    from oracle import oracle as O
+
+    structs = {"ghicp_params": api.Params, "ghicp_iter": api.Iter, "ghicp_pair_config": api.PairConfig, "ghicp_pair_stats": api.PairStats,
+               "ghicp_icp_params": api.IcpParams, "ghicp_icp_stats": api.IcpStats, "ghicp_cloud_info": api.CloudInfo}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ghicp_c.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])  # the header is plain C
+    got = {}
+    for l in subprocess.check_output([str(exe)], text=True).splitlines():
+        s, f, v = l.split()
+        got[(s, f)] = int(v)
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    # the oracle's parameter blocks are the same bytes
+    assert ctypes.sizeof(O.Params) == ctypes.sizeof(api.Params) and ctypes.sizeof(O.Iter) == ctypes.sizeof(api.Iter)
+    assert ctypes.sizeof(O.IcpParams) == ctypes.sizeof(api.IcpParams) and ctypes.sizeof(O.IcpStats) == ctypes.sizeof(api.IcpStats)
+    for a, b in ((O.IcpParams, api.IcpParams), (O.IcpStats, api.IcpStats), (O.Params, api.Params)):
+        assert [(n, getattr(a, n).offset) for n, _ in a._fields_] == [(n, getattr(b, n).offset) for n, _ in b._fields_]
+
+
+def test_fpfh_restatement_invariants(oracle, synth):
+    """pcl::FPFHEstimation semantics the restatement must keep (SURVEY.md §8c): unit normals turned towards the viewpoint,
+    each 11-bin block rescaled to 100, |Pearson| of a histogram with itself = 1."""
+    p = synth.tls_pair(20_000)
+    ds = p.target[oracle.voxel_filter(p.target, 0.3)][:, :3]
+    nrm, hist = oracle.fpfh(ds)
+    np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
+    assert ((nrm * (-ds)).sum(1) >= -1e-6).all()  # flipNormalTowardsViewpoint, viewpoint = origin
+    blocks = hist.reshape(-1, 3, 11).sum(2)
+    ok = blocks.sum(1) > 0
+    assert ok.mean() > 0.99
+    np.testing.assert_allclose(blocks[ok], 100.0, rtol=2e-4)
+    assert (hist >= 0).all()
+    sub = hist[ok][:50]
+    FD = oracle.fd_fpfh(sub, sub)
+    np.testing.assert_allclose(np.diag(FD), 1.0, atol=1e-5)
+    assert (FD <= 1.0 + 1e-5).all()
