@@ -29,6 +29,31 @@ def inputs():
     return synth, O, tls, ds, g
 
 
+ICP_VARIANTS = (("p2p", 0, False, False), ("p2p_trim", 0, False, True), ("p2p_recip_trim", 0, True, True), ("p2plane_trim", 1, False, True))
+
+
+def icp_inputs():
+    """Source / target of the fine-registration fixture (same generator as tests/test_icp_cpu.py::small_pair)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_icp_cpu import small_pair
+
+    synth = importlib.import_module("gh-icp_amd.synth")
+    return small_pair(synth, n=5000, seed=9)
+
+
+def icp_fixture(O):
+    src, tgt, gt = icp_inputs()
+    out = {"overlap_0p2": np.float32(O.cal_overlap(src, tgt, 0.2)), "normals_k12": O.knn_normals(tgt, 12)}
+    idx, d2 = O.nn1(src, tgt)
+    out["nn_idx"], out["nn_d2"] = idx, d2
+    for name, metric, recip, trim in ICP_VARIANTS:
+        r = O.icp(src, tgt, O.icp_params(40, recip, trim, metric, 0.2, 0.1, 12))
+        out[name + "_T"] = r["T"]
+        out[name + "_meta"] = np.array([r["iterations"], r["converged"], r["reason"], r["correspondences"]], np.int64)
+        out[name + "_corr0"] = r["corr0"]
+    np.savez_compressed(os.path.join(HERE, "icp.npz"), **out)
+
+
 def main():
     synth, O, tls, ds, g = inputs()
     pat = synth.bsc_pattern_glibc()
@@ -59,6 +84,7 @@ def main():
         out[name + "_cor"] = np.array([t["cor"] for t in r["trace"]], np.int32)
         out[name + "_matchlist"] = r["matchlist"]
     np.savez_compressed(os.path.join(HERE, "loop.npz"), **out)
+    icp_fixture(O)
     print("golden fixtures written:", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

@@ -97,3 +97,37 @@ def test_real_km_matrices_gpu(ctx, oracle, it):
     w = np.full((n, n), float(z["bg"]))
     w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
     np.testing.assert_array_equal(ctx.km_solve(w).cpu().numpy(), oracle.km(w)[0])  # index work: bit-exact
+
+
+def test_oracle_reproduces_icp_golden(oracle):
+    """Fine registration (common_reg.cpp:45-199, 294-317): frozen outputs of the restatement on a seeded 5000-point pair."""
+    mg = importlib.import_module("make_golden")
+    g = np.load(os.path.join(GOLD, "icp.npz"))
+    src, tgt, _ = mg.icp_inputs()
+    assert np.float32(oracle.cal_overlap(src, tgt, 0.2)) == g["overlap_0p2"]
+    np.testing.assert_array_equal(oracle.knn_normals(tgt, 12), g["normals_k12"])
+    idx, d2 = oracle.nn1(src, tgt)
+    np.testing.assert_array_equal(idx, g["nn_idx"])
+    np.testing.assert_array_equal(d2, g["nn_d2"])
+    for name, metric, recip, trim in mg.ICP_VARIANTS:
+        r = oracle.icp(src, tgt, oracle.icp_params(40, recip, trim, metric, 0.2, 0.1, 12))
+        np.testing.assert_array_equal(r["T"], g[name + "_T"])
+        np.testing.assert_array_equal([r["iterations"], r["converged"], r["reason"], r["correspondences"]], g[name + "_meta"])
+        np.testing.assert_array_equal(r["corr0"], g[name + "_corr0"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_icp_golden(ctx, api):
+    mg = importlib.import_module("make_golden")
+    g = np.load(os.path.join(GOLD, "icp.npz"))
+    src, tgt, _ = mg.icp_inputs()
+    assert np.float32(ctx.cal_overlap(src, tgt, 0.2)) == g["overlap_0p2"]
+    assert np.abs(ctx.knn_normals(tgt, 12).cpu().numpy() - g["normals_k12"]).max() <= 1e-6
+    idx, d2 = ctx.nn_search(src, tgt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["nn_idx"])  # index work: bit-exact
+    np.testing.assert_array_equal(d2.cpu().numpy(), g["nn_d2"])
+    for name, metric, recip, trim in mg.ICP_VARIANTS:
+        r = ctx.icp(src, tgt, api.icp_params(40, recip, trim, metric, 0.2, 0.1, 12))
+        assert [r["iterations"], r["converged"], r["reason"], r["correspondences"]] == g[name + "_meta"].tolist()
+        Tg, To = r["T"].astype(np.float64), g[name + "_T"].astype(np.float64)
+        assert np.linalg.norm(Tg[:3, :3] @ To[:3, :3].T - np.eye(3)) <= 1e-4 and np.linalg.norm(Tg[:3, 3] - To[:3, 3]) <= 1e-3
