@@ -64,3 +64,27 @@ def test_sbf_dump_round_trip_and_rebuilt_handles(ctx, api, oracle, synth, scans,
         ctx.register_clouds(other, [(clouds[0], clouds[1])])
     with pytest.raises(api.GhicpError):
         api.sbf_read(tmp_path / "missing.bsc")
+
+
+def test_multiview_queue_on_one_gpu(ctx, api, synth, scans):
+    """pairqueue.run_multiview wired to the real product calls: all ordered pairs of three scans, every front end once."""
+    import importlib
+
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_NN, dof=6, voxel=0.2, pattern=synth.bsc_pattern_glibc(), max_iter=60)
+    pairs = [(i, j) for i in range(3) for j in range(3) if i != j]
+    built = []
+
+    def make_cloud(c):
+        built.append(c)
+        return ctx.cloud_create(cfg, scans[c])
+
+    def register_batch(ids, S, T):
+        return [{"Rt": np.array(st.Rt[:]), "it": st.iterations} for st in ctx.register_clouds(cfg, list(zip(S, T)))]
+
+    out = pq.run_multiview(3, pairs, make_cloud, register_batch)
+    assert built == [0, 1, 2] and len(out) == 6
+    ref = ctx.register_pairs(cfg, [(scans[i], scans[j]) for i, j in pairs])
+    for o, r in zip(out, ref):
+        assert o["it"] == r.iterations
+        np.testing.assert_array_equal(o["Rt"], np.array(r.Rt[:]))

@@ -67,3 +67,63 @@ def test_two_rank_gloo_pair_queue():
         assert [r["pair"] for r in out] == list(range(7))
         assert [r["rank"] for r in out] == [0, 1, 0, 1, 0, 1, 0]
         assert [r["value"] for r in out] == [2 * (100 + i) for i in range(7)]
+
+
+def _mv_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    n = 5
+    pairs = [(i, j) for i in range(n) for j in range(n) if i != j] if rank == 0 else []  # all ordered pairs of 5 clouds
+    built = []
+
+    def make_cloud(c):  # stands in for ctx.cloud_create
+        built.append(c)
+        return {"cloud": c, "rank": rank}
+
+    def register_batch(ids, S, T):  # stands in for ctx.register_clouds
+        assert all(h["rank"] == rank for h in S + T)
+        return [{"pair": i, "s": s["cloud"], "t": t["cloud"], "rank": rank} for i, s, t in zip(ids, S, T)]
+
+    out = pq.run_multiview(n, pairs, make_cloud, register_batch, dist)
+    q.put((rank, built, out))
+    dist.destroy_process_group()
+
+
+def test_multiview_single_process_and_validation():
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    built = []
+    pairs = [(0, 1), (2, 1), (1, 0), (0, 2), (0, 1)]
+    out = pq.run_multiview(3, pairs, lambda c: built.append(c) or ("h", c), lambda ids, S, T: [{"p": i, "s": s[1], "t": t[1]} for i, s, t in zip(ids, S, T)])
+    assert built == [0, 1, 2]  # every cloud's front end exactly once, whatever the number of pairs it takes part in
+    assert [(r["s"], r["t"]) for r in out] == pairs and [r["p"] for r in out] == list(range(5))
+    assert pq.clouds_for_pairs(pairs, [1]) == [1, 2]
+    assert pq.run_multiview(3, [], lambda c: None, lambda ids, S, T: []) == []
+    with pytest.raises(ValueError):
+        pq.run_multiview(2, [(0, 2)], lambda c: c, lambda ids, S, T: [{}])
+    with pytest.raises(RuntimeError):
+        pq.run_multiview(2, [(0, 1)], lambda c: c, lambda ids, S, T: [])
+
+
+def test_two_rank_gloo_multiview():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    pairs = [(i, j) for i in range(5) for j in range(5) if i != j]
+    for rank, built, out in got:
+        assert len(built) == len(set(built)) and set(built) <= set(range(5))  # a cloud is never built twice on a rank
+        assert [(r["s"], r["t"]) for r in out] == pairs  # every rank ends up with every record, in pair order
+        assert [r["rank"] for r in out] == [i % 2 for i in range(len(pairs))]  # pair p was registered on rank p mod 2
+    assert got[0][2] == got[1][2]
