@@ -48,7 +48,7 @@ EXPORTS = [
     "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
-    "ghicp_rigid_svd", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
+    "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
     "ghicp_register_pairs",
     "ghicp_icp_params_default", "ghicp_cal_overlap", "ghicp_icp", "ghicp_knn_normals", "ghicp_nn_search", "ghicp_inv_transform",
     "ghicp_transform_cloud_f32",
@@ -108,6 +108,18 @@ def icp_params(max_iter=50, reciprocal=False, trimmed=False, metric=ICP_POINT_TO
     p.max_iter, p.use_reciprocal, p.use_trimmed, p.metric = max_iter, int(reciprocal), int(trimmed), metric
     p.thre_dis, p.min_overlap, p.covariance_k = thre_dis, min_overlap, covariance_k
     return p
+
+
+def rigid_svd_host(src, tgt):
+    """ghicp_rigid_svd_host: float Umeyama on the host with the kernels' numerics contract (no GPU needed)."""
+    src = np.ascontiguousarray(src, np.float64)
+    tgt = np.ascontiguousarray(tgt, np.float64)
+    out = np.zeros(16)
+    rc = load().ghicp_rigid_svd_host(src.ctypes.data_as(C.POINTER(C.c_double)), tgt.ctypes.data_as(C.POINTER(C.c_double)),
+                                     C.c_int64(src.shape[0]), out.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise GhicpError("ghicp_rigid_svd_host failed with code %d" % rc)
+    return out.reshape(4, 4)
 
 
 def inv_transform(T):

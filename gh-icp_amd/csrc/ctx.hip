@@ -242,6 +242,43 @@ extern "C" int ghicp_rigid_svd(ghicp_ctx* ctx, const double* src, const double* 
   return GHICP_OK;
 }
 
+// Host-side float Umeyama with the arithmetic of k_rigid_svd (N1-N5: float means, f64 covariance rounded once onto the f32
+// grid, Kabsch via Jacobi, R and t rounded to f32) for the few-point closed-form solvers of the reference's public API
+// (CRegistration::SVD_6DOF, src/common_reg.cpp:774-888), which are not worth a kernel launch.  No context, no GPU.
+extern "C" int ghicp_rigid_svd_host(const double* src, const double* tgt, int64_t c, double* out16) {
+  if (!src || !tgt || !out16 || c < 1) return GHICP_ERR_ARG;
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t i = 0; i < c; i++)
+    for (int d = 0; d < 3; d++) { m[d] += (double)(float)src[(size_t)i * 3 + d]; m[3 + d] += (double)(float)tgt[(size_t)i * 3 + d]; }
+  float msf[3], mtf[3];
+  for (int d = 0; d < 3; d++) { msf[d] = (float)(m[d] / (double)c); mtf[d] = (float)(m[3 + d] / (double)c); }
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = 0; i < c; i++) {
+    double a[3], b[3];
+    for (int d = 0; d < 3; d++) {
+      a[d] = (double)(float)tgt[(size_t)i * 3 + d] - (double)mtf[d];
+      b[d] = (double)(float)src[(size_t)i * 3 + d] - (double)msf[d];
+    }
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++) H[r * 3 + q] += a[r] * b[q];
+  }
+  double A[9], R[9];
+  for (int d = 0; d < 9; d++) A[d] = H[d] / (double)c;
+  gh_quant_grid(A, 9);
+  gh_kabsch(A, R);
+  float Rf[9];
+  for (int d = 0; d < 9; d++) Rf[d] = (float)R[d];
+  for (int d = 0; d < 16; d++) out16[d] = 0;
+  for (int r = 0; r < 3; r++) {
+    const float t = (float)((double)mtf[r] - (((double)Rf[r * 3] * (double)msf[0] + (double)Rf[r * 3 + 1] * (double)msf[1]) +
+                                               (double)Rf[r * 3 + 2] * (double)msf[2]));
+    for (int q = 0; q < 3; q++) out16[r * 4 + q] = (double)Rf[r * 3 + q];
+    out16[r * 4 + 3] = (double)t;
+  }
+  out16[15] = 1;
+  return GHICP_OK;
+}
+
 extern "C" int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const double* Rt, float* out) {
   if (!ctx) return GHICP_ERR_ARG;
   GH_ARG(n >= 0 && stride >= 3 && Rt != nullptr);

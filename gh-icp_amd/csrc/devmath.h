@@ -1,14 +1,17 @@
-// Device-side small linear algebra and wave/block reductions for gfx950 (wave64).
+// Small linear algebra (host + device: the same source serves the kernels and the host-side entry points, so that both
+// follow one numerics contract) and device-side wave/block reductions for gfx950 (wave64).
 // Build flag contract: -ffp-contract=off (no implicit FMA), IEEE f32/f64 div & sqrt.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <cmath>
 
 #define GH_WAVE 64
 
 // ---- 3x3 symmetric eigen-decomposition, cyclic Jacobi in f64 (DESIGN.md "numerics contract" N3):
 // pivots (0,1),(0,2),(1,2), 8 sweeps, exactly-zero pivots skipped, t = sgn(th)/(|th|+sqrt(th^2+1)).
 // m = {a00,a01,a02,a11,a12,a22} in/out (diagonal ends as eigenvalues); v row-major eigenvectors in columns.
-__device__ inline void gh_jacobi3(double& a00, double& a01, double& a02, double& a11, double& a12, double& a22, double v[9]) {
+__host__ __device__ inline void gh_jacobi3(double& a00, double& a01, double& a02, double& a11, double& a12, double& a22, double v[9]) {
   v[0] = 1; v[1] = 0; v[2] = 0; v[3] = 0; v[4] = 1; v[5] = 0; v[6] = 0; v[7] = 0; v[8] = 1;
 #define GH_ROT(app, aqq, apq, arp, arq, P, Q)                  \
   if (apq != 0.0) {                                            \
@@ -39,10 +42,10 @@ __device__ inline void gh_jacobi3(double& a00, double& a01, double& a02, double&
 
 // N2: round n f64 sums onto the f32 grid of the matrix scale: nearest multiple of 2^(e-23), e = exponent of
 // the largest |entry| (ties to even).  See DESIGN.md "numerics contract".
-__device__ inline void gh_quant_grid(double* v, int n) {
+__host__ __device__ inline void gh_quant_grid(double* v, int n) {
   double mx = 0;
   for (int i = 0; i < n; i++) mx = fmax(mx, fabs(v[i]));
-  if (!(mx > 0) || !isfinite(mx)) return;
+  if (!(mx > 0) || !(mx <= 1.7976931348623157e308)) return;  // zero, infinite (or all-NaN) input: left untouched
   int e;
   frexp(mx, &e);
   const double q = ldexp(1.0, e - 1 - 23);
@@ -52,7 +55,7 @@ __device__ inline void gh_quant_grid(double* v, int n) {
 // Closest rotation to the 3x3 cross-covariance A (row-major), Kabsch via Jacobi on A^T A:
 // right singular vectors sorted by descending eigenvalue (stable), u1 = A v1/|.|, u2 = GS(A v2),
 // u3 = u1 x u2, R = [u1 u2 u3] diag(1,1,sign det V) V^T.   (N5)
-__device__ inline void gh_kabsch(const double A[9], double R[9]) {
+__host__ __device__ inline void gh_kabsch(const double A[9], double R[9]) {
   double m[6];
   {
     double ata[9];

@@ -142,6 +142,9 @@ int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double eps, int32
 /* pcl::registration::TransformationEstimationSVD as used by GHRegistration::transformestimation
  * (src/ghicp_reg.cpp:839-866): c x 3 f64 correspondences (cast to f32 like the reference), Rt 4x4 [host]. */
 int ghicp_rigid_svd(ghicp_ctx* ctx, const double* src, const double* tgt, int64_t c, double* Rt16);
+/* The same solve on the host (same numerics contract, no context, no GPU): for the few-point closed-form solvers of the
+ * reference's API (CRegistration::SVD_6DOF, src/common_reg.cpp:774-888).  src/tgt: c x 3 f64 host arrays. */
+int ghicp_rigid_svd_host(const double* src, const double* tgt, int64_t c, double* Rt16);
 
 /* GHRegistration::ghicp_reg (src/ghicp_reg.cpp:24-112): the whole iteration loop
  * (calED, calCD_*, findcorrespondence{NN,NNR,KM}, transformestimation, adjustweight).
