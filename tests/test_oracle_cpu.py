@@ -331,3 +331,63 @@ def test_fpfh_restatement_invariants(oracle, synth):
     FD = oracle.fd_fpfh(sub, sub)
     np.testing.assert_allclose(np.diag(FD), 1.0, atol=1e-5)
     assert (FD <= 1.0 + 1e-5).all()
+
+
+def test_dropin_headers_compile_and_link_without_a_gpu(tmp_path):
+    """Every drop-in header of include/ (the reference's class names over the C ABI) must compile as C++17 with nothing but
+    the standard library, and the drop-in programs must link against the built library (they only RUN on a GPU box)."""
+    inc = os.path.join(ROOT, "include")
+    hdrs = sorted(f for f in os.listdir(inc) if f.endswith((".h", ".hpp")) and f != "ghicp_c.h")
+    assert {"ghicp_reg.h", "km.h", "keypoint_detect.hpp", "binary_feature_extraction.hpp", "common_reg.h", "dataio.hpp", "utility.h",
+            "stereo_binary_feature.h"} <= set(hdrs)
+    for h in hdrs:  # each header on its own: no hidden include-order dependency
+        src = tmp_path / ("only_%s.cpp" % h.replace(".", "_"))
+        src.write_text('#include "%s"\nint main() { return 0; }\n' % h)
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", inc, str(src)])
+    libdir = os.path.join(ROOT, "gh-icp_amd")
+    for prog in ("test_dropin.cpp", "test_ctrlpts.cpp", "test_dataio.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-O0", "-I", inc, os.path.join(ROOT, "tests", "cpp", prog), "-L", libdir, "-lghicp_hip",
+                               "-Wl,-rpath," + libdir, "-o", str(tmp_path / prog[:-4])])
+    subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-x", "c", os.path.join(inc, "ghicp_c.h")])  # the ABI header is plain C
+
+
+def test_rigid_fit_equivariance_and_hamming_properties(oracle):
+    """Property checks of the restatement: the rigid fit commutes with rigid motions of both point sets up
+    to float rounding; the Hamming distance is a metric on the 441-bit strings."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    def rot(ax, ay, az):
+        cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+
+    ang = st.floats(-3.0, 3.0)
+
+    @settings(max_examples=25, deadline=None)
+    @given(seed=st.integers(0, 2 ** 31 - 1), a=ang, b=ang, c=ang, n=st.integers(4, 60))
+    def rigid(seed, a, b, c, n):
+        rng = np.random.default_rng(seed)
+        S = rng.normal(0, 10, (n, 3))
+        R0 = rot(*rng.uniform(-1, 1, 3))
+        T = S @ R0.T + rng.uniform(-3, 3, 3) + rng.normal(0, 0.01, (n, 3))
+        F = oracle.rigid_svd(S, T)
+        Q, q = rot(a, b, c), rng.uniform(-20, 20, 3)
+        G = oracle.rigid_svd(S, T @ Q.T + q)  # moving the target by (Q, q) composes on the left
+        np.testing.assert_allclose(G[:3, :3], Q @ F[:3, :3], atol=2e-5)
+        np.testing.assert_allclose(G[:3, 3], Q @ F[:3, 3] + q, atol=2e-3)
+        assert abs(np.linalg.det(F[:3, :3]) - 1) < 1e-5
+
+    rigid()
+
+    @settings(max_examples=25, deadline=None)
+    @given(seed=st.integers(0, 2 ** 31 - 1))
+    def hamming(seed):
+        rng = np.random.default_rng(seed)
+        f = rng.integers(0, 256, (3, 56), dtype=np.uint8)
+        f[:, 55] &= 0x01  # 441 bits: only bit 0 of the last byte is used
+        d = lambda x, y: int(oracle.fd_bsc(f[x][None, None, :], f[y][None, :])[0, 0])
+        assert d(0, 0) == 0 and d(0, 1) == d(1, 0) and d(0, 2) <= d(0, 1) + d(1, 2)
+        assert d(0, 1) == int(np.unpackbits(f[0] ^ f[1]).sum())
+
+    hamming()
