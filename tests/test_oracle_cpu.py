@@ -391,3 +391,25 @@ def test_rigid_fit_equivariance_and_hamming_properties(oracle):
         assert d(0, 1) == int(np.unpackbits(f[0] ^ f[1]).sum())
 
     hamming()
+
+
+def test_every_context_entry_point_rejects_a_null_context(api):
+    """No GPU needed: each ABI function that takes a context must return GHICP_ERR_ARG for a NULL one before touching
+    anything else (the drop-in classes turn that code into an exception; nothing falls back to the CPU)."""
+    lib = api.load()
+    no_ctx = {"ghicp_version", "ghicp_params_default", "ghicp_icp_params_default", "ghicp_inv_transform", "ghicp_rigid_svd_host",
+              "ghicp_sbf_write", "ghicp_sbf_read", "ghicp_last_error", "ghicp_ctx_create", "ghicp_cloud_destroy"}
+    zeros = [ctypes.c_void_p(0)] * 16
+    for name in api.EXPORTS:
+        if name in no_ctx:
+            continue
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        rc = fn(*zeros)
+        if name == "ghicp_ctx_destroy":
+            assert rc == 0  # destroying nothing is fine
+        else:
+            assert rc == 1, (name, rc)  # GHICP_ERR_ARG
+    assert lib.ghicp_last_error(None).decode() == "null context"
+    assert lib.ghicp_cloud_destroy(None) == 0
+    assert lib.ghicp_sbf_write(None, None, ctypes.c_int64(0)) == 1 and lib.ghicp_rigid_svd_host(None, None, ctypes.c_int64(3), None) == 1
