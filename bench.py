@@ -270,17 +270,18 @@ def main():
     # ---- CPU baseline: the oracle (faithful PCL-free restatement of the reference path), 1 thread
     cpu = None
     check = None
+    workload_stats = None
     if world == 1 and args.cpu_baseline:
         from oracle import oracle as O  # checker / baseline only
 
         pair = pairs[0]
         tc = time.perf_counter()
-        ds, kp, feat = {}, {}, {}
+        ds, kp, feat, kbar, mbar = {}, {}, {}, {}, {}
         for name, cloud, dof in (("T", pair.target, 0), ("S", pair.source, 6)):
             keep = O.voxel_filter(cloud, 0.1)
             ds[name] = cloud[keep]
-            kp[name], _ = O.keypoints(ds[name], 0.5, 1.5)
-            feat[name], _, _ = O.bsc(ds[name], kp[name], 1.5, dof, synth.bsc_pattern_glibc())
+            kp[name], kbar[name] = O.keypoints(ds[name], 0.5, 1.5)  # + mean neighbours in the PCA radius (k-bar of SURVEY.md §8)
+            feat[name], _, mbar[name] = O.bsc(ds[name], kp[name], 1.5, dof, synth.bsc_pattern_glibc())  # + mean points per BSC sphere (m-bar)
         FD = O.fd_bsc(feat["S"], feat["T"][0])
         t_front = time.perf_counter() - tc
         P = O.default_params(O.BSC, {"KM": O.KM, "NN": O.NN, "NNR": O.NNR}[args.corr], 6, 0.6, 1.5, O.bbx_magnitude(ds["S"]))
@@ -292,6 +293,7 @@ def main():
                "sample": "ONE complete cfg2 pair (pair 0 of the batch): front end + FD %.1f s, %d loop iterations %.1f s; oracle = PCL-free "
                          "restatement of the reference path (the reference needs PCL/Eigen/FLANN, not installable here), g++ -O2, 1 thread; "
                          "host has %d logical CPUs" % (t_front, ro["iters"], t_loop, os.cpu_count())}
+        workload_stats = {"k_bar": round(0.5 * (float(kbar["S"]) + float(kbar["T"])), 1), "m_bar": round(0.5 * (float(mbar["S"]) + float(mbar["T"])), 1)}
         check = {"iterations_match": int(stats.iterations) == int(ro["iters"]),
                  "keypoints_match": (int(stats.k_s), int(stats.k_t)) == (int(kp["S"].size), int(kp["T"].size)),
                  "rot_err_vs_oracle": round(synth.rot_err(Rg, ro["Rt"]), 9), "trans_err_vs_oracle_m": round(synth.trans_err(Rg, ro["Rt"]), 9)}
@@ -316,6 +318,8 @@ def main():
         "gt_error": {"rot": round(synth.rot_err(Rg, pairs[0].gt), 6), "trans_m": round(synth.trans_err(Rg, pairs[0].gt), 5)},
         "roofline": roofline, "cpu_baseline": cpu, "parity_check": check, "gen_seconds": round(gen_s, 1),
     }
+    if workload_stats:
+        out["config"].update(workload_stats)  # measured on the CPU leg: mean neighbours per PCA query / points per BSC sphere
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(value / cpu["value"], 2)
     print(json.dumps(out))
