@@ -1038,3 +1038,4 @@ float orc_bbx_magnitude(const float* xyz, int n, int stride) {
 }  // extern "C"
 
 #include "icp_oracle.inc"
+#include "km_model.inc"

@@ -327,3 +327,15 @@ def keypoints_adaptive(xyz, radius, R_nms, ratio_max=0.65, min_n=20, upper=50000
     k = lib().orc_keypoints_adaptive(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], C.c_float(radius), C.c_float(ratio_max), min_n,
                                      C.c_float(R_nms), C.c_longlong(upper), C.c_longlong(lower), _p(kp, C.c_int), C.byref(ru), C.byref(nr))
     return kp[:k].copy(), ru.value, nr.value
+
+
+def km_model(w, eps=0.01, march=True):
+    """Sequential model of the GPU solver's state machine (oracle/km_model.inc). Returns (match, steps, marched, failed_phases)."""
+    w = np.ascontiguousarray(w, np.float64)
+    n = w.shape[0]
+    match = np.empty(n, np.int32)
+    st = np.zeros(3, np.int64)
+    rc = lib().orc_km_model(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int), _p(st, C.c_longlong), int(march))
+    if rc != 0:
+        raise RuntimeError("km_model did not terminate (status %d)" % rc)
+    return match, int(st[0]), int(st[1]), int(st[2])

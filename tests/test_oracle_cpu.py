@@ -413,3 +413,47 @@ def test_every_context_entry_point_rejects_a_null_context(api):
     assert lib.ghicp_last_error(None).decode() == "null context"
     assert lib.ghicp_cloud_destroy(None) == 0
     assert lib.ghicp_sbf_write(None, None, ctypes.c_int64(0)) == 1 and lib.ghicp_rigid_svd_host(None, None, ctypes.c_int64(3), None) == 1
+
+
+def test_gpu_solver_state_machine_model_matches_reference_traversal(oracle):
+    """oracle/km_model.inc models the rules the GPU Kuhn-Munkres kernel relies on (background + CSR, deferred background
+    slack, per-label scan pointers E7, no re-sent slack minima on resumption E8, the 64-wide march E9).  Fuzzed here against
+    the reference traversal (orc::KM == src/km.cpp) on matrices shaped like GH-ICP's: the matching must be identical with and
+    without the march, and on the real cfg2 matrices the model's activation counts are the GPU kernel's own counters
+    (profiles/r01_km_step_counters_v2.txt)."""
+    rng = np.random.default_rng(2024)
+    marched = 0
+    for t in range(400):
+        n = int(rng.choice([3, 5, 8, 17, 40, 65, 100, 130]))
+        pen = float(rng.choice([5.0, 8.0, 20.0]))
+        cd = rng.uniform(0, 3 * pen, (n, n))
+        kind = t % 4
+        if kind == 0:
+            keep = rng.random((n, n)) < rng.choice([0.01, 0.05, 0.2])
+            keep[rng.random(n) < rng.choice([0.0, 0.3, 0.7])] = False
+        elif kind == 1:
+            keep = rng.random((n, n)) < 0.7
+        elif kind == 2:
+            cd = np.round(cd * 2) / 2
+            keep = rng.random((n, n)) < 0.3
+        else:
+            keep = rng.random((n, n)) < 0.15
+            keep[:, rng.random(n) < 0.4] = False
+        w = np.where(keep & (cd < pen), -cd, -pen)
+        ref, _ = oracle.km(w)
+        for march in (True, False):
+            m, steps, mr, _ = oracle.km_model(w, march=march)
+            np.testing.assert_array_equal(m, ref)
+            marched += mr if march else 0
+    assert marched > 1000  # the march rule was actually exercised
+    expect = {0: (299804, 727), 10: (342258, 3193), 30: (346668, 784)}  # steps / failed phases printed by k_km2<true> on the GPU
+    for it, (steps, failed) in expect.items():
+        z = np.load(os.path.join(ROOT, "tests", "golden", "km_cfg2_it%d.npz" % it))
+        n = int(z["n"])
+        w = np.full((n, n), float(z["bg"]))
+        w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
+        ref, _ = oracle.km(w)
+        for march in (True, False):
+            m, s, mr, fp = oracle.km_model(w, march=march)
+            np.testing.assert_array_equal(m, ref)
+            assert (s, fp) == (steps, failed)
