@@ -329,13 +329,16 @@ def keypoints_adaptive(xyz, radius, R_nms, ratio_max=0.65, min_n=20, upper=50000
     return kp[:k].copy(), ru.value, nr.value
 
 
-def km_model(w, eps=0.01, march=True):
-    """Sequential model of the GPU solver's state machine (oracle/km_model.inc). Returns (match, steps, marched, failed_phases)."""
+def km_model(w, eps=0.01, march=True, sweep_first=False, full=False):
+    """Sequential model of the GPU solver's state machine (oracle/km_model.inc).  Returns (match, steps, marched,
+    failed_phases); with full=True also (rows swept in failed phases, rows swept before an aborted sweep).
+    sweep_first=True enables the prototype rule 'an order-free sweep decides the fate of the phase before any DFS'."""
     w = np.ascontiguousarray(w, np.float64)
     n = w.shape[0]
     match = np.empty(n, np.int32)
-    st = np.zeros(3, np.int64)
-    rc = lib().orc_km_model(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int), _p(st, C.c_longlong), int(march))
+    st = np.zeros(5, np.int64)
+    rc = lib().orc_km_model(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int), _p(st, C.c_longlong), int(march) | (2 if sweep_first else 0))
     if rc != 0:
-        raise RuntimeError("km_model did not terminate (status %d)" % rc)
-    return match, int(st[0]), int(st[1]), int(st[2])
+        raise RuntimeError("km_model failed (status %d)" % rc)
+    out = (match, int(st[0]), int(st[1]), int(st[2]))
+    return out + (int(st[3]), int(st[4])) if full else out

@@ -441,10 +441,10 @@ def test_gpu_solver_state_machine_model_matches_reference_traversal(oracle):
             keep[:, rng.random(n) < 0.4] = False
         w = np.where(keep & (cd < pen), -cd, -pen)
         ref, _ = oracle.km(w)
-        for march in (True, False):
-            m, steps, mr, _ = oracle.km_model(w, march=march)
+        for march, sweep in ((True, False), (False, False), (True, True), (False, True)):
+            m, steps, mr, _ = oracle.km_model(w, march=march, sweep_first=sweep)  # sweep_first: rule E10 (order-free sweep decides the phase)
             np.testing.assert_array_equal(m, ref)
-            marched += mr if march else 0
+            marched += mr if (march and not sweep) else 0
     assert marched > 1000  # the march rule was actually exercised
     expect = {0: (299804, 727), 10: (342258, 3193), 30: (346668, 784)}  # steps / failed phases printed by k_km2<true> on the GPU
     for it, (steps, failed) in expect.items():
@@ -457,3 +457,6 @@ def test_gpu_solver_state_machine_model_matches_reference_traversal(oracle):
             m, s, mr, fp = oracle.km_model(w, march=march)
             np.testing.assert_array_equal(m, ref)
             assert (s, fp) == (steps, failed)
+        m, s, mr, fp, swept, aborted = oracle.km_model(w, march=True, sweep_first=True, full=True)
+        np.testing.assert_array_equal(m, ref)
+        assert fp == failed and s < steps and swept > 0  # same phases, fewer DFS activations: the failed ones are swept
