@@ -137,6 +137,74 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
       double ck = __longlong_as_double(0x7ff8000000000000ll);  // E7 cache, one entry per lane: NaN never matches
       int cp = 0, cnext = 0;
       const long long steps0 = nsteps;
+      // ---- E10 (flags & 4, GHICP_KM_SWEEP=1; prototyped and fuzzed in oracle/km_model.inc): an order-free sweep decides the
+      // fate of the phase before any DFS.  A failed findpath() visits exactly the set reachable from the root in the tight
+      // graph, in whatever order (E1); so the wave floods that set breadth-first -- 64 entries / 64 columns per iteration, the
+      // queue of rows in the (still unused) stack array -- and when no free column turns up, its visited bits, slack minima
+      // and minimum visited label ARE the failed phase: straight to the relabelling.  When a free column turns up the sweep
+      // is abandoned (its slack minima are dead: the phase augments and the next root starts from fresh slack) and the
+      // order-dependent DFS below runs as before.  On mid-run matrices 60 % of all activations belong to failed phases.
+      bool swept_failed = false;
+      if (flags & 4) {
+        int qh = 0, qt = 1;  // stx[0] == root
+        bool free_found = false;
+        double sk = __longlong_as_double(0x7ff8000000000000ll);  // labels whose background-tight set has been flooded (one per lane)
+        int snext = 0;
+        while (qh < qt && !free_found) {
+          const int xr = (int)stx[qh];
+          qh++;
+          const double lxr = lx[xr];
+          lxmin = fmin(lxmin, lxr);
+          const unsigned cb = rptr[xr], ce = rptr[xr + 1];
+          for (unsigned c0 = cb; c0 < ce && !free_found; c0 += 64) {
+            const unsigned c = c0 + lane, cc = min(c, ce - 1u);
+            const int col = cols[cc];
+            const double wv = vals[cc];
+            const double d = (lxr + ly[col]) - wv;
+            const bool in = c < ce, td = d < eps;
+            if (in & !td) __hip_atomic_fetch_min(&slack[col], (unsigned long long)__double_as_longlong(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool fresh = in & td & !bit_get(visy, col);
+            int m = NONE;
+            if (fresh) m = match[col];
+            if (__ballot(fresh && m == NONE)) { free_found = true; break; }
+            const unsigned long long fb = __ballot(fresh);
+            if (fresh) {  // a matched column is entered once, so its owner is enqueued once
+              atomicOr(&visy[col >> 5], 1u << (col & 31));
+              atomicOr(&visx[m >> 5], 1u << (m & 31));
+              stx[qt + __popcll(fb & ((1ull << lane) - 1ull))] = (unsigned short)m;
+            }
+            qt += __popcll(fb);
+            __builtin_amdgcn_wave_barrier();
+          }
+          if (!free_found && (lxr - bg) < eps && !__ballot(sk == lxr)) {  // flood T_L once per label: nothing of it is left afterwards
+            for (int y0 = 0; y0 < n && !free_found; y0 += 64) {
+              const int y = y0 + lane, yc = min(y, n - 1);
+              const bool fresh = (y < n) & !bit_get(visy, yc) & (((lxr + ly[yc]) - bg) < eps);
+              int m = NONE;
+              if (fresh) m = match[y];
+              if (__ballot(fresh && m == NONE)) { free_found = true; break; }
+              const unsigned long long fb = __ballot(fresh);
+              if (fresh) {
+                atomicOr(&visy[y >> 5], 1u << (y & 31));
+                atomicOr(&visx[m >> 5], 1u << (m & 31));
+                stx[qt + __popcll(fb & ((1ull << lane) - 1ull))] = (unsigned short)m;
+              }
+              qt += __popcll(fb);
+              __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == snext) sk = lxr;
+            snext = (snext + 1) & 63;
+          }
+        }
+        if (!free_found) swept_failed = true;
+        else {  // restore the start state of the phase for the DFS
+          for (int i = lane; i < nw; i += 64) { visx[i] = 0u; visy[i] = 0u; }
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) { stx[0] = (unsigned short)root; sty[0] = (unsigned short)NONE; visx[root >> 5] = 1u << (root & 31); }
+          __builtin_amdgcn_wave_barrier();
+          lxmin = lx[root];
+        }
+      }
       // E8: the first 64 explicit entries of a row live in registers (one entry per lane), for the row being scanned
       // (r*) and for the frame below it (p*).  A push loads the child's row while the stack is being updated, a pop takes
       // the frame below from registers and starts loading the one below that: the L2 round trip of the CSR row is no
@@ -151,7 +219,7 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
     if (E > B) { const unsigned cc_ = min(B + (unsigned)lane, E - 1u); C = cols[cc_]; V = vals[cc_]; } \
   } while (0)
       KM2_LOAD_ROW(x, rb, re, rcol, rval);
-      for (;;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
+      for (; !swept_failed;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
         nsteps++;
         const long long tq0 = prof ? (long long)__builtin_readcyclecounter() : 0;
         const double lxv = lx[x];
@@ -683,8 +751,10 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   }
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
   if (v3) hipLaunchKernelGGL(k_km3, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
-  else if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL(k_km2<true>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_NOMARCH") ? 1 : 0);
-  else hipLaunchKernelGGL(k_km2<false>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, getenv("GHICP_KM_NOMARCH") ? 1 : 0);
+  const int kflags = (getenv("GHICP_KM_NOMARCH") ? 1 : 0) | (getenv("GHICP_KM_SWEEP") ? 4 : 0);
+  if (v3) {}
+  else if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL(k_km2<true>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, kflags);
+  else hipLaunchKernelGGL(k_km2<false>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, kflags);
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
