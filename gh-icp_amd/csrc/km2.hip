@@ -93,7 +93,7 @@ typedef __attribute__((address_space(1))) unsigned long long* g_u64;
 // LDS per problem: lx, ly (f64), rptr (u32), match / stack x / stack y (u16), two bitmaps = 26.25 B per row.
 // slack lives in global memory (L2): explicit entries hit it with fire-and-forget 64-bit atomic minima (d >= eps > 0,
 // so the IEEE bit pattern orders like the value), the end of a failed phase reads it with L1-bypassing loads.
-template <bool PROF>
+template <bool PROF, bool SWEEP>
 __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs, int flags) {
   const Km2Problem P = probs[blockIdx.x];
   if (P.n <= 0 || (P.done && *P.done)) return;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
       double ck = __longlong_as_double(0x7ff8000000000000ll);  // E7 cache, one entry per lane: NaN never matches
       int cp = 0, cnext = 0;
       const long long steps0 = nsteps;
-      // ---- E10 (flags & 4, GHICP_KM_SWEEP=1; prototyped and fuzzed in oracle/km_model.inc): an order-free sweep decides the
+      // ---- E10 (template parameter SWEEP, selected by GHICP_KM_SWEEP=1; prototyped and fuzzed in oracle/km_model.inc): an order-free sweep decides the
       // fate of the phase before any DFS.  A failed findpath() visits exactly the set reachable from the root in the tight
       // graph, in whatever order (E1); so the wave floods that set breadth-first -- 64 entries / 64 columns per iteration, the
       // queue of rows in the (still unused) stack array -- and when no free column turns up, its visited bits, slack minima
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void k_km2(const Km2Problem* __restrict__ probs
       // is abandoned (its slack minima are dead: the phase augments and the next root starts from fresh slack) and the
       // order-dependent DFS below runs as before.  On mid-run matrices 60 % of all activations belong to failed phases.
       bool swept_failed = false;
-      if (flags & 4) {
+      if constexpr (SWEEP) {
         int qh = 0, qt = 1;  // stx[0] == root
         bool free_found = false;
         double sk = __longlong_as_double(0x7ff8000000000000ll);  // labels whose background-tight set has been flooded (one per lane)
@@ -734,8 +734,9 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   static bool attr_done = false;
   if (!attr_done) {
     const size_t want = 160 * 1024;
-    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
-    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     attr_done = true;
   }
@@ -751,10 +752,11 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   }
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
   if (v3) hipLaunchKernelGGL(k_km3, dim3(nprob), dim3(64), lds, ctx->stream, d_probs);
-  const int kflags = (getenv("GHICP_KM_NOMARCH") ? 1 : 0) | (getenv("GHICP_KM_SWEEP") ? 4 : 0);
+  const int kflags = getenv("GHICP_KM_NOMARCH") ? 1 : 0;
   if (v3) {}
-  else if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL(k_km2<true>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, kflags);
-  else hipLaunchKernelGGL(k_km2<false>, dim3(nprob), dim3(64), lds, ctx->stream, d_probs, kflags);
+  else if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL((k_km2<true, false>), dim3(nprob), dim3(64), lds, ctx->stream, d_probs, kflags);
+  else if (getenv("GHICP_KM_SWEEP")) hipLaunchKernelGGL((k_km2<false, true>), dim3(nprob), dim3(64), lds, ctx->stream, d_probs, kflags);  // E10, experimental
+  else hipLaunchKernelGGL((k_km2<false, false>), dim3(nprob), dim3(64), lds, ctx->stream, d_probs, kflags);
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
