@@ -329,16 +329,19 @@ def keypoints_adaptive(xyz, radius, R_nms, ratio_max=0.65, min_n=20, upper=50000
     return kp[:k].copy(), ru.value, nr.value
 
 
-def km_model(w, eps=0.01, march=True, sweep_first=False, full=False):
+def km_model(w, eps=0.01, march=True, sweep_first=False, full=False, flood_dead=False):
     """Sequential model of the GPU solver's state machine (oracle/km_model.inc).  Returns (match, steps, marched,
     failed_phases); with full=True also (rows swept in failed phases, rows swept before an aborted sweep).
-    sweep_first=True enables the prototype rule 'an order-free sweep decides the fate of the phase before any DFS'."""
+    sweep_first=True: rule E10 (an order-free sweep decides the fate of the phase before any DFS); flood_dead=True (with
+    sweep_first): prototype E12 (a dead child's reachable set is flooded instead of stepped through); full=True appends
+    (rows swept in failed phases, rows swept before an aborted sweep, rows in dead floods, rows in probes of live children)."""
     w = np.ascontiguousarray(w, np.float64)
     n = w.shape[0]
     match = np.empty(n, np.int32)
-    st = np.zeros(5, np.int64)
-    rc = lib().orc_km_model(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int), _p(st, C.c_longlong), int(march) | (2 if sweep_first else 0))
+    st = np.zeros(7, np.int64)
+    rc = lib().orc_km_model(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int), _p(st, C.c_longlong),
+                            int(march) | (2 if sweep_first else 0) | (4 if flood_dead else 0))
     if rc != 0:
         raise RuntimeError("km_model failed (status %d)" % rc)
     out = (match, int(st[0]), int(st[1]), int(st[2]))
-    return out + (int(st[3]), int(st[4])) if full else out
+    return out + (int(st[3]), int(st[4]), int(st[5]), int(st[6])) if full else out

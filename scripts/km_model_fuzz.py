@@ -30,11 +30,11 @@ for t in range(N):
     n = int(rng.choice([3, 5, 8, 17, 40, 65, 100, 130, 200]))
     w = gen(rng, n, t % 4)
     ref, _ = O.km(w)
-    for march, sweep in ((True, False), (False, False), (True, True), (False, True)):
-        m, s, mr, fp = O.km_model(w, march=march, sweep_first=sweep)
+    for march, sweep, flood in ((True, False, False), (False, False, False), (True, True, False), (False, True, False), (True, True, True), (False, True, True)):
+        m, s, mr, fp = O.km_model(w, march=march, sweep_first=sweep, flood_dead=flood)
         if not (m == ref).all():
             bad += 1
             np.save('/tmp/km_counterexample_%d.npy' % t, w)
-            print('MISMATCH t', t, 'n', n, 'kind', t % 4, 'march', march, 'sweep_first', sweep, flush=True)
+            print('MISMATCH t', t, 'n', n, 'kind', t % 4, 'march', march, 'sweep_first', sweep, 'flood_dead', flood, flush=True)
         if march and not sweep: marched += mr; steps += s
 print('matrices', N, 'mismatches', bad, 'marched share %.3f' % (marched / max(1, steps)), 'seconds %.1f' % (time.time() - t0))

@@ -441,8 +441,9 @@ def test_gpu_solver_state_machine_model_matches_reference_traversal(oracle):
             keep[:, rng.random(n) < 0.4] = False
         w = np.where(keep & (cd < pen), -cd, -pen)
         ref, _ = oracle.km(w)
-        for march, sweep in ((True, False), (False, False), (True, True), (False, True)):
-            m, steps, mr, _ = oracle.km_model(w, march=march, sweep_first=sweep)  # sweep_first: rule E10 (order-free sweep decides the phase)
+        for march, sweep, flood in ((True, False, False), (False, False, False), (True, True, False), (False, True, False), (True, True, True)):
+            # sweep_first: rule E10 (an order-free sweep decides the phase); flood_dead: prototype E12 (dead children are flooded)
+            m, steps, mr, _ = oracle.km_model(w, march=march, sweep_first=sweep, flood_dead=flood)
             np.testing.assert_array_equal(m, ref)
             marched += mr if (march and not sweep) else 0
     assert marched > 1000  # the march rule was actually exercised
@@ -457,6 +458,9 @@ def test_gpu_solver_state_machine_model_matches_reference_traversal(oracle):
             m, s, mr, fp = oracle.km_model(w, march=march)
             np.testing.assert_array_equal(m, ref)
             assert (s, fp) == (steps, failed)
-        m, s, mr, fp, swept, aborted = oracle.km_model(w, march=True, sweep_first=True, full=True)
+        m, s, mr, fp, swept, aborted, _, _ = oracle.km_model(w, march=True, sweep_first=True, full=True)
         np.testing.assert_array_equal(m, ref)
         assert fp == failed and s < steps and swept > 0  # same phases, fewer DFS activations: the failed ones are swept
+        m, s2, mr2, fp, _, _, dead_rows, probe_rows = oracle.km_model(w, march=True, sweep_first=True, flood_dead=True, full=True)
+        np.testing.assert_array_equal(m, ref)
+        assert fp == failed and s2 - mr2 < 0.6 * (s - mr) and dead_rows > 0  # E12 at least halves... the serial DFS iterations
