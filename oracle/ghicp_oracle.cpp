@@ -1039,3 +1039,4 @@ float orc_bbx_magnitude(const float* xyz, int n, int stride) {
 
 #include "icp_oracle.inc"
 #include "km_model.inc"
+#include "km4_model.inc"

@@ -41,7 +41,7 @@ def default_params(feature=NONE, corr=NN, dof=6, est_iou=0.6, radius_nonmax=1.5,
 def build(force: bool = False) -> None:
     so = os.path.join(_HERE, "libghicp_oracle.so")
     src = os.path.join(_HERE, "ghicp_oracle.cpp")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ghicp_oracle.cpp", "icp_oracle.inc", "km_model.inc", "km4_model.inc")):
         subprocess.check_call(["make", "-C", _HERE, "libghicp_oracle.so"], stdout=subprocess.DEVNULL)
     ref = os.path.join(_HERE, "_ref", "libkm_ref.so")
     if os.path.exists("/root/reference/src/km.cpp") and (force or not os.path.exists(ref)):
@@ -345,3 +345,21 @@ def km_model(w, eps=0.01, march=True, sweep_first=False, full=False, flood_dead=
         raise RuntimeError("km_model failed (status %d)" % rc)
     out = (match, int(st[0]), int(st[1]), int(st[2]))
     return out + (int(st[3]), int(st[4]), int(st[5]), int(st[6])) if full else out
+
+
+def km4_model(w, eps=0.01, cap=3, prune=True):
+    """Rule-level model of the flood-first Kuhn-Munkres kernel k_km4 (oracle/km4_model.inc).  Returns (match, stats) with
+    stats = dict(phases, failed, flood_rows, push_rows, rebuild_rows, pull_rounds, dfs_steps, dfs_pops, overflow_rows);
+    match is None when the model reports the slack hazard (rule R4) -- the kernel then falls back to its literal solver."""
+    w = np.ascontiguousarray(w, np.float64)
+    n = w.shape[0]
+    match = np.empty(n, np.int32)
+    st = np.zeros(9, np.int64)
+    rc = lib().orc_km4_model(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int), _p(st, C.c_longlong), int(cap) | (0 if prune else 0x100))
+    names = ("phases", "failed", "flood_rows", "push_rows", "rebuild_rows", "pull_rounds", "dfs_steps", "dfs_pops", "overflow_rows")
+    stats = dict(zip(names, (int(v) for v in st)))
+    if rc == 4:
+        return None, stats
+    if rc != 0:
+        raise RuntimeError("km4_model failed (status %d)" % rc)
+    return match, stats
