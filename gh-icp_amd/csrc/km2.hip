@@ -23,19 +23,7 @@
 #include <climits>
 #include <cstdlib>
 
-struct Km2Problem {
-  int n, pad_;
-  double bg, eps;
-  const unsigned* row_ptr;  // n+1
-  const int* cols;          // ascending within a row
-  const double* vals;       // explicit weights, each > bg
-  const double* lx_init;    // row maxima over the full row (km.cpp:56-62)
-  int* match_out;           // n: match[y] = x
-  int* status;              // 0 = ok
-  const int* done;          // optional early-exit flag (device)
-  long long* steps;         // optional: number of findpath() calls (profiling)
-  double* slack;            // n doubles of global scratch (k_km2)
-};
+#include "km_prob.h"
 
 size_t gh_km2_lds_bytes(int n) { return (size_t)n * 26 + 16 + 2 * (size_t)((n + 31) / 32) * 4 + 64; }
 
@@ -731,6 +719,8 @@ __global__ __launch_bounds__(1024) void k_gh_scan_rows(const unsigned* __restric
 
 // launches one k_km2 block per problem; descriptors already on device
 int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max) {
+  // default: the flood-first solver (km4.hip) whenever its state fits LDS; GHICP_KM_V2=1 keeps this file's DFS emulation
+  if (gh_km4_fits(n_max) && !getenv("GHICP_KM_V2")) return gh_km4_launch(ctx, d_probs, nprob, n_max);
   static bool attr_done = false;
   if (!attr_done) {
     const size_t want = 160 * 1024;
@@ -762,7 +752,7 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   return GHICP_OK;
 }
 
-bool gh_km2_fits(int n) { return n <= 65534 && gh_km2_lds_bytes(n) <= 160 * 1024 - 256; }
+bool gh_km2_fits(int n) { return n <= 65534 && gh_km2_lds_bytes(n) <= 160 * 1024 - 256; }  // (covers gh_km4_fits)
 
 // dense front door: background = the matrix minimum, everything above it explicit
 int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, int* status_dev) {
@@ -807,7 +797,10 @@ int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32
     long long h[13];
     GH_HIP(hipMemcpyAsync(h, dstats, sizeof(h), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));
-    if (getenv("GHICP_KM_V3"))
+    if (gh_km4_fits(n) && !getenv("GHICP_KM_V2"))
+      fprintf(stderr, "[km4 stats] n=%d activations=%lld phases=%lld failed=%lld pull_rounds=%lld dfs_iterations=%lld flood_rows(failed)=%lld rebuilt_rows=%lld | cycles: flood=%lld failed=%lld pull=%lld dfs=%lld total=%lld | hazard=%lld\n",
+              n, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]);
+    else if (getenv("GHICP_KM_V3"))
       fprintf(stderr, "[km stats] n=%d steps=%lld overflow=%lld flat=%lld failph=%lld failrows=%lld cyc_dfs=%lld cyc_fail=%lld cyc_total=%lld | A=%lld B=%lld C=%lld (list+overflow %lld) D=%lld\n", n, h[0], h[1],
               h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[12], h[11]);
     else

@@ -1,0 +1,20 @@
+// Internal: descriptor of one sparse Kuhn-Munkres problem (shared by loop.hip, km2.hip, km4.hip).  Not part of the ABI.
+#pragma once
+struct Km2Problem {
+  int n, pad_;
+  double bg, eps;
+  const unsigned* row_ptr;  // n+1
+  const int* cols;          // ascending within a row
+  const double* vals;       // explicit weights, each > bg
+  const double* lx_init;    // row maxima over the full row (km.cpp:56-62)
+  int* match_out;           // n: match[y] = x
+  int* status;              // 0 = ok
+  const int* done;          // optional early-exit flag (device)
+  long long* steps;         // optional: counters (profiling)
+  double* slack;            // n doubles of global scratch (k_km2 only)
+};
+struct ghicp_ctx;
+int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
+bool gh_km2_fits(int n);
+int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
+bool gh_km4_fits(int n);

@@ -18,21 +18,7 @@
 
 #include <cmath>
 
-struct Km2Problem {
-  int n, pad_;
-  double bg, eps;
-  const unsigned* row_ptr;
-  const int* cols;
-  const double* vals;
-  const double* lx_init;
-  int* match_out;
-  int* status;
-  const int* done;
-  long long* steps;
-  double* slack;
-};
-int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
-bool gh_km2_fits(int n);
+#include "km_prob.h"
 int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, const int* done_flag);
 
 namespace {
