@@ -788,18 +788,18 @@ int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32
   long long* dstats = nullptr;
   if (getenv("GHICP_KM_STATS")) {
     GH_TRY(ctx->reserve(B_P_PATTERN, 32, &dstats));
-    GH_HIP(hipMemsetAsync(dstats, 0, 13 * sizeof(long long), s));
+    GH_HIP(hipMemsetAsync(dstats, 0, 24 * sizeof(long long), s));
     hp.steps = dstats;
   }
   GH_HIP(hipMemcpyAsync(dp, &hp, sizeof(hp), hipMemcpyHostToDevice, s));
   GH_TRY(gh_km2_launch(ctx, dp, 1, n));
   if (dstats) {
-    long long h[13];
+    long long h[24];
     GH_HIP(hipMemcpyAsync(h, dstats, sizeof(h), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));
     if (gh_km4_fits(n) && !getenv("GHICP_KM_V2"))
-      fprintf(stderr, "[km4 stats] n=%d activations=%lld phases=%lld failed=%lld pull_rounds=%lld dfs_iterations=%lld flood_rows(failed)=%lld rebuilt_rows=%lld | cycles: flood=%lld failed=%lld pull=%lld dfs=%lld total=%lld | hazard=%lld\n",
-              n, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]);
+      fprintf(stderr, "[km4 stats] n=%d activations=%lld phases=%lld failed=%lld pull_rounds=%lld dfs_iterations=%lld flood_rows(failed)=%lld rebuilt_rows=%lld | cycles: flood=%lld failed=%lld pull=%lld dfs=%lld total=%lld | hazard=%lld | flood: levels=%lld flagged_rows=%lld cyc_rows=%lld sweeps=%lld cyc_sweeps=%lld\n",
+              n, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17]);
     else if (getenv("GHICP_KM_V3"))
       fprintf(stderr, "[km stats] n=%d steps=%lld overflow=%lld flat=%lld failph=%lld failrows=%lld cyc_dfs=%lld cyc_fail=%lld cyc_total=%lld | A=%lld B=%lld C=%lld (list+overflow %lld) D=%lld\n", n, h[0], h[1],
               h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[12], h[11]);

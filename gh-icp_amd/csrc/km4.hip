@@ -27,13 +27,16 @@
 #include "devmath.h"
 #include "km_prob.h"
 
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 
 namespace {
 
 constexpr int K4_CAP = 3;
-constexpr int K4_OVER = 255;
+constexpr int K4_OVER = 255;  // tln: 0..3 = entries in the row's own slots; 4 + blk*5 + (cnt-4) = cnt in 4..8, entries 3.. in pool block blk; 255 = flagged
+constexpr int K4_BLK = 5;     // entries per pool block
+constexpr int K4_MAXBLK = 48;
 constexpr int K4_T = 256;
 constexpr int K4_NONE = 0xFFFF;
 constexpr double K4_INF = 1000.0;  // km.cpp:42
@@ -45,10 +48,12 @@ typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
 enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NUM = 16 };
 
 struct K4 {
-  double *lx, *ly, *slack, *tlv, *red;
+  double *lx, *ly, *slack, *tlv, *red, *pval;
   unsigned *visx, *visy, *prevy, *pushed, *good, *goody, *freey, *ovf;
   int* sh;
-  unsigned short *match, *stx, *sty, *tlc;
+  unsigned short *match, *stx, *sty, *tlc, *pcol;
+  unsigned* fb;  // free pool blocks (2 words)
+  int nblk;
   unsigned char* tln;
   int n, nw;
   double bg, eps;
@@ -58,91 +63,91 @@ struct K4 {
 };
 
 __device__ inline bool k4_bit(const unsigned* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
+__device__ inline int k4_cnt(int tn) { return tn < 4 ? tn : (tn == K4_OVER ? 0 : 4 + (tn - 4) % K4_BLK); }  // listed entries (0 for flagged rows)
+__device__ inline int k4_blk(int tn) { return (tn >= 4 && tn != K4_OVER) ? (tn - 4) / K4_BLK : -1; }
 
-// R3: mark column y visited; a free column ends the flood, a matched one enqueues its owner (each row owns one column)
-__device__ inline void k4_visit(const K4& s, int y) {
-  const unsigned bit = 1u << (y & 31);
-  if (atomicOr(&s.visy[y >> 5], bit) & bit) return;
-  const int m = s.match[y];
-  if (m == K4_NONE) { s.sh[SH_FREE] = 1; return; }
-  const unsigned b2 = 1u << (m & 31);
-  if (!(atomicOr(&s.visx[m >> 5], b2) & b2)) s.stx[atomicAdd(&s.sh[SH_QT], 1)] = (unsigned short)m;
-}
-
-// One wave streams the CSR row x: REBUILD writes the row's list (R2), PUSH sends the slack minima of the non-tight entries (R4).
-// (cb, ce) = the row's CSR range, (c0col, c0val) = its first 64 entries, already requested by the caller (software pipeline).
-template <bool REBUILD, bool PUSH>
-__device__ inline void k4_scan_row(const K4& s, int x, unsigned cb, unsigned ce, int c0col, double c0val, int lane) {
-  const double lxr = s.lx[x];
-  int cnt = 0;
-  unsigned long long* sl = reinterpret_cast<unsigned long long*>(s.slack);
-  auto block = [&](unsigned c, int col, double val) {
-    const bool in = c < ce;
-    const double d = (lxr + s.ly[col]) - val;
-    const bool td = d < s.eps;
-    if (PUSH && in && !td) atomicMin(&sl[col], (unsigned long long)__double_as_longlong(d));
-    if (REBUILD) {
-      const unsigned long long tb = __ballot(in && td);
-      if (in && td) {
-        const int r = cnt + __popcll(tb & ((1ull << lane) - 1ull));
-        if (r < K4_CAP) { s.tlc[x * K4_CAP + r] = (unsigned short)col; s.tlv[x * K4_CAP + r] = val; }
-      }
-      cnt += __popcll(tb);
+// pool blocks: lock-free bitmap allocator (bit set = free)
+__device__ inline int k4_blk_alloc(const K4& s) {
+  for (int w = 0; w < 2; w++)
+    for (;;) {
+      const unsigned m = *(volatile unsigned*)&s.fb[w];
+      if (!m) break;
+      const int b = __ffs((int)m) - 1;
+      if (atomicAnd(&s.fb[w], ~(1u << b)) & (1u << b)) return w * 32 + b;
     }
-  };
-  if (ce > cb) block(cb + lane, c0col, c0val);
-  for (unsigned c0 = cb + 64u; c0 < ce; c0 += 128u) {  // two blocks per round, both requested before either is used
-    const unsigned ca = c0 + lane, cbb = c0 + 64u + lane;
-    const unsigned cca = min(ca, ce - 1u), ccb = min(cbb, ce - 1u);
-    const int col_a = s.cols[cca], col_b = s.cols[ccb];
-    const double val_a = s.vals[cca], val_b = s.vals[ccb];
-    block(ca, col_a, val_a);
-    if (c0 + 64u < ce) block(cbb, col_b, val_b);
-  }
-  if (REBUILD && lane == 0) {
-    const bool over = cnt > K4_CAP;
-    const bool was = s.tln[x] == K4_OVER;
-    s.tln[x] = (unsigned char)(over ? K4_OVER : cnt);
-    if (over != was) {
-      if (over) atomicOr(&s.ovf[x >> 5], 1u << (x & 31));
-      else atomicAnd(&s.ovf[x >> 5], ~(1u << (x & 31)));
-    }
-  }
+  return -1;
 }
+__device__ inline void k4_blk_free(const K4& s, int b) { atomicOr(&s.fb[b >> 5], 1u << (b & 31)); }
 
-// Bulk pass over rows list[0..count) (all 4 waves, a row per wave at a time); ONLY_UNPUSHED skips rows whose minima are in slack.
-// Each wave first fetches the CSR ranges of up to 64 of its rows in one go, then walks them with the next row's first block
-// in flight while the current row is processed.
+// Bulk pass over rows list[0..count), all 4 waves: REBUILD writes the rows' lists (R2), PUSH sends the slack minima of their
+// non-tight entries (R4), ONLY_UNPUSHED skips rows whose minima are already in slack.  16 lanes per row, so a wave instruction works
+// on four rows and every lane has four entries (64 per row) in flight per round: the pass is bound by the latency of the CSR
+// loads (L2), not by their volume, and 16 rows per workgroup in flight is what hides it.
 template <bool REBUILD, bool PUSH, bool ONLY_UNPUSHED>
 __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int count, int wave, int lane) {
-  for (int base = 0; base < count; base += 4 * 64) {
-    const int i = base + lane * 4 + wave;
+  const int grp = lane >> 4, lig = lane & 15;
+  unsigned long long* sl = reinterpret_cast<unsigned long long*>(s.slack);
+  for (int base = 0; base < count; base += 16) {
+    const int i = base + wave * 4 + grp;
     int x = -1;
     if (i < count) {
       x = list[i];
       if (ONLY_UNPUSHED && k4_bit(s.pushed, x)) x = -1;
     }
     unsigned cb = 0, ce = 0;
-    if (x >= 0) { cb = s.rptr[x]; ce = s.rptr[x + 1]; }
-    unsigned long long todo = __ballot(x >= 0);
-    if (!todo) continue;
-    int l = (int)__ffsll((long long)todo) - 1;
-    unsigned ncb = __builtin_amdgcn_readlane(cb, l), nce = __builtin_amdgcn_readlane(ce, l);
-    int nx = __builtin_amdgcn_readlane(x, l);
-    int ncol = 0;
-    double nval = 0.0;
-    if (nce > ncb) { const unsigned cc = min(ncb + (unsigned)lane, nce - 1u); ncol = s.cols[cc]; nval = s.vals[cc]; }
-    while (todo) {
-      todo &= todo - 1ull;
-      const int cx = nx, ccol = ncol;
-      const unsigned ccb = ncb, cce = nce;
-      const double cval = nval;
-      if (todo) {  // request the next row's first block before working on this one
-        l = (int)__ffsll((long long)todo) - 1;
-        ncb = __builtin_amdgcn_readlane(cb, l); nce = __builtin_amdgcn_readlane(ce, l); nx = __builtin_amdgcn_readlane(x, l);
-        if (nce > ncb) { const unsigned cc = min(ncb + (unsigned)lane, nce - 1u); ncol = s.cols[cc]; nval = s.vals[cc]; }
+    double lxr = 0.0;
+    if (x >= 0) { cb = s.rptr[x]; ce = s.rptr[x + 1]; lxr = s.lx[x]; }
+    int cnt = 0, blk = -1;
+    if (REBUILD && x >= 0) blk = k4_blk(s.tln[x]);  // a row that had a pool block keeps it for its new list
+    for (unsigned off = 0; __ballot(cb + off < ce); off += 64) {
+      int col[4];
+      double val[4];
+      unsigned c[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        c[j] = cb + off + 16u * j + lig;
+        const unsigned cc = ce > cb ? min(c[j], ce - 1u) : cb;
+        col[j] = s.cols[cc]; val[j] = s.vals[cc];
       }
-      k4_scan_row<REBUILD, PUSH>(s, cx, ccb, cce, ccol, cval, lane);
+      double lyv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) lyv[j] = s.ly[col[j]];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool in = c[j] < ce;
+        const double d = (lxr + lyv[j]) - val[j];
+        const bool td = d < s.eps;
+        if (PUSH && in && !td) atomicMin(&sl[col[j]], (unsigned long long)__double_as_longlong(d));
+        if (REBUILD) {
+          const unsigned gb = (unsigned)(__ballot(in && td) >> (grp * 16)) & 0xffffu;
+          const int after = cnt + __popc(gb);
+          if (after > K4_CAP && blk == -1) {  // first entry beyond the row's own slots: take a pool block (asked for once per row)
+            int b = -2;
+            if (lig == 0) b = k4_blk_alloc(s);
+            blk = __shfl(b, grp * 16, 64);
+            if (blk < 0) blk = -2;  // none free: the row ends up flagged
+          }
+          if (in && td) {
+            const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
+            if (rk < K4_CAP) { s.tlc[x * K4_CAP + rk] = (unsigned short)col[j]; s.tlv[x * K4_CAP + rk] = val[j]; }
+            else if (rk < K4_CAP + K4_BLK && blk >= 0) { s.pcol[blk * K4_BLK + rk - K4_CAP] = (unsigned short)col[j]; s.pval[blk * K4_BLK + rk - K4_CAP] = val[j]; }
+          }
+          cnt = after;
+        }
+      }
+    }
+    if (REBUILD && lig == 0 && x >= 0) {
+      int tn = cnt;
+      if (cnt > K4_CAP) {
+        if (cnt <= K4_CAP + K4_BLK && blk >= 0) tn = 4 + blk * K4_BLK + (cnt - 4);
+        else { tn = K4_OVER; if (blk >= 0) k4_blk_free(s, blk); }
+      } else if (blk >= 0) k4_blk_free(s, blk);
+      const bool over = tn == K4_OVER, was = s.tln[x] == K4_OVER;
+      s.tln[x] = (unsigned char)tn;
+      if (over != was) {
+        if (over) atomicOr(&s.ovf[x >> 5], 1u << (x & 31));
+        else atomicAnd(&s.ovf[x >> 5], ~(1u << (x & 31)));
+      }
     }
   }
 }
@@ -153,73 +158,128 @@ __device__ inline double k4_wave_min(double v) {
   return v;
 }
 
-// First unvisited good background-tight column in [start, limit) (E7 scan of km2.hip with the R5 filter)
-__device__ inline int k4_bg_scan(const K4& s, double lxv, int start, int limit, int lane) {
-  for (int y0 = start; y0 < limit; y0 += 64) {
-    const int y = y0 + lane, yc = min(y, limit - 1);
-    const unsigned vw = s.visy[yc >> 5], gw = s.goody[yc >> 5];
-    const double lv = s.ly[yc];
-    const unsigned t = (unsigned)(y < limit) & (((~vw & gw) >> (yc & 31)) & 1u) & (unsigned)(((lxv + lv) - s.bg) < s.eps);
-    const unsigned long long b = __ballot(t != 0u);
-    if (b) return y0 + (int)__ffsll((long long)b) - 1;
-  }
-  return INT_MAX;
-}
+// ---- R3: the flood (wave 0), level by level.  Returns true when a free column is reachable; the visited rows are stx[0 .. *qt_out).
+// A column is claimed by the returning ds_or on its visited bit (two rows reaching it in the same instruction are serialised by
+// the LDS); every matched row owns exactly one column, so the claim of a column is also the one enqueue of its owner, and the
+// queue tail lives in a register (ballot ranks, no LDS counter).
+#define K4_CLAIM(WANT, COL, OWNER)                                                          \
+  do {                                                                                      \
+    unsigned old_ = 0u;                                                                     \
+    const unsigned bit_ = 1u << ((COL) & 31);                                               \
+    if (WANT) old_ = atomicOr(&s.visy[(COL) >> 5], bit_);                                   \
+    const bool fresh_ = (WANT) && !(old_ & bit_);                                           \
+    free_l |= fresh_ && (OWNER) == K4_NONE;                                                 \
+    const bool enq_ = fresh_ && (OWNER) != K4_NONE;                                         \
+    const unsigned long long eb_ = __ballot(enq_);                                          \
+    if (enq_) {                                                                             \
+      s.stx[qt + __popcll(eb_ & ((1ull << lane) - 1ull))] = (unsigned short)(OWNER);        \
+      atomicOr(&s.visx[(OWNER) >> 5], 1u << ((OWNER) & 31));                                \
+    }                                                                                       \
+    qt += __popcll(eb_);                                                                    \
+  } while (0)
 
-// ---- R3: the flood (wave 0).  Returns true when a free column is reachable; the visited rows are stx[0 .. sh[SH_QT]).
-__device__ inline bool k4_flood(const K4& s, int root, int lane) {
+template <bool PROF>
+__device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, long long* pc) {
   const int n = s.n;
-  if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); s.sh[SH_QT] = 1; s.sh[SH_FREE] = 0; }
+  if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); }
   __builtin_amdgcn_wave_barrier();
   int qh = 0, qt = 1;
+  bool free_l = false;
   double lflood = INFINITY;
   while (qh < qt) {
+    const int qe = qt;
     double lcand = INFINITY;
-    for (int base = qh; base < qt; base += 64) {
+    const long long tl0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    if (PROF) pc[0]++;
+    for (int base = qh; base < qe; base += 64) {
       const int i = base + lane;
-      const bool act = i < qt;
-      int xr = 0, tn = 0;
-      double lxr = INFINITY;
-      if (act) { xr = s.stx[i]; lxr = s.lx[xr]; tn = s.tln[xr]; }
-      const bool over = act && tn == K4_OVER;
-      if (act && !over) {
-        for (int k = 0; k < K4_CAP; k++)
-          if (k < tn) {
-            const int col = s.tlc[xr * K4_CAP + k];
-            if (((lxr + s.ly[col]) - s.tlv[xr * K4_CAP + k]) < s.eps && !k4_bit(s.visy, col)) k4_visit(s, col);
-          }
+      const bool act = i < qe;
+      const int xr = s.stx[min(i, qe - 1)];
+      const double lxr = s.lx[xr];
+      const int tn = s.tln[xr];
+      int lc[K4_CAP], mc[K4_CAP];
+      double lv[K4_CAP], lyc[K4_CAP];
+      unsigned vw[K4_CAP];
+#pragma unroll
+      for (int k = 0; k < K4_CAP; k++) { lc[k] = s.tlc[xr * K4_CAP + k]; lv[k] = s.tlv[xr * K4_CAP + k]; }
+#pragma unroll
+      for (int k = 0; k < K4_CAP; k++) { lyc[k] = s.ly[lc[k]]; vw[k] = s.visy[lc[k] >> 5]; mc[k] = s.match[lc[k]]; }
+      const int cntv = act ? k4_cnt(tn) : 0, blkv = k4_blk(tn);
+      const int t = min(cntv, K4_CAP);
+#pragma unroll
+      for (int k = 0; k < K4_CAP; k++) {
+        const bool want = (int)(k < t) & (int)(((lxr + lyc[k]) - lv[k]) < s.eps) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
+        K4_CLAIM(want, lc[k], mc[k]);
+      }
+      for (int e = K4_CAP; __ballot(e < cntv); e++) {  // entries in pool blocks
+        const int pi = blkv * K4_BLK + e - K4_CAP;
+        int col = 0, m = K4_NONE;
+        bool want = false;
+        if (e < cntv) {
+          col = s.pcol[pi];
+          m = s.match[col];
+          want = (int)(((lxr + s.ly[col]) - s.pval[pi]) < s.eps) & (int)!k4_bit(s.visy, col);
+        }
+        K4_CLAIM(want, col, m);
       }
       if (act && (lxr - s.bg) < s.eps) lcand = fmin(lcand, lxr);
-      unsigned long long ob = __ballot(over);
+      unsigned long long ob = __ballot(act && tn == K4_OVER);
+      if (PROF) pc[1] += __popcll(ob);
       while (ob) {  // flagged rows: every tight entry of the CSR row
         const int l = (int)__ffsll((long long)ob) - 1;
         ob &= ob - 1ull;
         const int xo = __builtin_amdgcn_readlane(xr, l);
         const double lxo = s.lx[xo];
         const unsigned cb = s.rptr[xo], ce = s.rptr[xo + 1];
-        for (unsigned c = cb + lane; c < ce; c += 64) {
-          const int col = s.cols[c];
-          if (((lxo + s.ly[col]) - s.vals[c]) < s.eps && !k4_bit(s.visy, col)) k4_visit(s, col);
+        for (unsigned c0 = cb; c0 < ce; c0 += 64) {
+          const unsigned c = c0 + lane, cc = min(c, ce - 1u);
+          const int col = s.cols[cc];
+          const double val = s.vals[cc];
+          const int m = s.match[col];
+          const bool want = (int)(c < ce) & (int)(((lxo + s.ly[col]) - val) < s.eps) & (int)!k4_bit(s.visy, col);
+          K4_CLAIM(want, col, m);
         }
       }
     }
     lcand = k4_wave_min(lcand);
+    const long long tl1 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    if (PROF) pc[2] += tl1 - tl0;
     if (lcand < lflood) {  // T_L of the smallest label so far contains T_L of every larger one
       lflood = lcand;
-      for (int y0 = 0; y0 < n; y0 += 64) {
-        const int y = y0 + lane;
-        if (y < n && !k4_bit(s.visy, y) && ((lcand + s.ly[y]) - s.bg) < s.eps) k4_visit(s, y);
+      if (PROF) pc[3]++;
+      for (int y0 = 0; y0 < n; y0 += 256) {  // four independent windows per round
+        bool c[4];
+        int m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int y = y0 + k * 64 + lane, yc = min(y, n - 1);
+          const unsigned vw = s.visy[yc >> 5];
+          const double lv = s.ly[yc];
+          m[k] = s.match[yc];
+          c[k] = (int)(y < n) & (int)(((vw >> (yc & 31)) & 1u) == 0u) & (int)(((lcand + lv) - s.bg) < s.eps);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (y0 + k * 64 >= n) break;
+          const int y = min(y0 + k * 64 + lane, n - 1);
+          K4_CLAIM(c[k], y, m[k]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    qh = qt;
-    qt = s.sh[SH_QT];
-    if (s.sh[SH_FREE]) return true;
+    if (PROF) pc[4] += (long long)__builtin_readcyclecounter() - tl1;
+    qh = qe;
+    if (__ballot(free_l)) { *qt_out = qt; return true; }
   }
+  *qt_out = qt;
   return false;
 }
+#undef K4_CLAIM
 
 // ---- R5: the reference's DFS restricted to S (wave 0).  Returns false only on an internal error.
+// One iteration == one findpath() activation or resumption (km.cpp:13-37) and costs two dependent LDS round trips: (1) the
+// row record (label, list), (2) everything the verdict needs -- for the <= 3 listed entries and for a 64-column window of
+// background candidates at the E7 pointer of the row's label: ly, the visited / S words and the owner of every candidate.
 template <bool PROF>
 __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter, long long* q_act) {
   const int n = s.n;
@@ -229,18 +289,24 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
   int sp = 0, x = root, ystart = 0;
   double ck = __longlong_as_double(0x7ff8000000000000ll);  // E7 cache, one label per lane: NaN never matches
   int cp = 0, cnext = 0;
-  for (;;) {  // one iteration == one findpath() activation or resumption (km.cpp:13-37)
+  const int lk = min(lane, K4_CAP - 1);
+  for (;;) {
     if (PROF) { ++*q_iter; ++*q_act; }
+    // ---- round trip 1: the row record
     const double lxv = s.lx[x];
     const int tn = s.tln[x];
+    int lc = s.tlc[x * K4_CAP + lk];
+    double lv = s.tlv[x * K4_CAP + lk];
+    const int ncnt = k4_cnt(tn);
+    if (ncnt > K4_CAP && lane >= K4_CAP) {  // entries 3.. of a row with a pool block
+      const int pi = k4_blk(tn) * K4_BLK + min(lane, K4_CAP + K4_BLK - 1) - K4_CAP;
+      lc = s.pcol[pi]; lv = s.pval[pi];
+    }
     const bool bgt = (lxv - bg) < eps;
-    int best = INT_MAX;
-    bool exhausted = false;
-    if (tn == 0 && bgt) {
-      // ---- E9 march (km2.hip): a chain of rows without tight explicit entries that share the label L picks the members of
-      // T_L in column order, up to 64 activations per window; candidates are filtered by S (R5).
+    int slot = 0, p = n;
+    if (bgt) {  // E7: one scan pointer per distinct label value; everything below ystart is dead for this label as well
       const unsigned long long hit = __ballot(ck == lxv);
-      int slot, p = ystart;
+      p = ystart;
       if (hit) {
         slot = (int)__ffsll((long long)hit) - 1;
         p = max(p, __builtin_amdgcn_readlane(cp, slot));
@@ -249,95 +315,108 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
         cnext = (cnext + 1) & 63;
         if (lane == slot) ck = lxv;
       }
-      int outcome = 0;
-      while (p < n) {
-        const int y = p + lane, yc = min(y, n - 1);
-        const unsigned vw = s.visy[yc >> 5], gw = s.goody[yc >> 5];
-        const double lv = s.ly[yc];
-        const bool cand = (y < n) & ((((~vw & gw) >> (yc & 31)) & 1u) != 0u) & (((lxv + lv) - bg) < eps);
-        const unsigned long long b = __ballot(cand);
-        if (!b) { p += 64; continue; }
-        int m = K4_NONE;
-        bool cont = false;
-        if (cand) {
-          m = s.match[y];
-          if (m != K4_NONE) cont = (s.tln[m] == 0) & (s.lx[m] == lxv);
-        }
-        const unsigned long long stop = __ballot(cand && !cont);
-        const int jstar = stop ? (int)__ffsll((long long)stop) - 1 : 63;
-        const unsigned long long R = b & (~0ull >> (63 - jstar));  // the picks of this window, in column order
-        const unsigned long long below = R & ((1ull << lane) - 1ull);
-        const int rank = __popcll(below);
-        const int pm = __shfl(m, below ? 63 - __clzll((long long)below) : 0, 64);
-        if ((R >> lane) & 1ull) {
-          atomicOr(&s.visy[y >> 5], 1u << (y & 31));
-          s.sty[sp + rank] = (unsigned short)y;
-          if (rank > 0) s.stx[sp + rank] = (unsigned short)pm;  // the row that picked this column (frame sp holds x)
-        }
-        const int k = __popcll(R), lastlane = 63 - __clzll((long long)R);
-        const int mlast = __builtin_amdgcn_readlane(m, lastlane);
-        if (PROF) *q_act += k - 1;
-        sp += k - 1;  // frame of the row that made the last pick
-        p += lastlane + 1;
-        if (mlast == K4_NONE) { outcome = 1; break; }
-        sp++;
-        if (lane == 0) { s.stx[sp] = (unsigned short)mlast; s.sty[sp] = (unsigned short)K4_NONE; }
-        x = mlast; ystart = 0;
-        if (stop) { outcome = 2; break; }  // the owner of the last pick is not part of the chain
-        if (PROF) ++*q_act;                // ... it is: its activation continues the march
-      }
-      if (lane == slot) cp = p;
-      __builtin_amdgcn_wave_barrier();
-      if (outcome == 1) break;
-      if (outcome == 2) continue;
-      exhausted = true;  // x (possibly a row reached by the march: its frame is sp) has no candidate left
     }
-    if (!exhausted) {
-      if (tn == K4_OVER) {  // flagged row: lowest tight unvisited good column of the CSR row
-        const unsigned cb = s.rptr[x], ce = s.rptr[x + 1];
-        for (unsigned c0 = cb; c0 < ce; c0 += 64) {
-          const unsigned c = c0 + lane, cc = min(c, ce - 1u);
-          const int col = s.cols[cc];
-          const double val = s.vals[cc];
-          const bool t = (c < ce) & (((lxv + s.ly[col]) - val) < eps) & (col >= ystart) & !k4_bit(s.visy, col) & k4_bit(s.goody, col);
-          const unsigned long long b = __ballot(t);
-          if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); break; }
-        }
-      } else if (tn > 0) {
-        int col = 0;
-        bool t = false;
-        if (lane < tn) {
-          col = s.tlc[x * K4_CAP + lane];
-          const double val = s.tlv[x * K4_CAP + lane];
-          t = (((lxv + s.ly[col]) - val) < eps) & (col >= ystart) & !k4_bit(s.visy, col) & k4_bit(s.goody, col);
-        }
+    // ---- round trip 2: listed entries and the first window, issued together
+    const double lyL = s.ly[lc];
+    const unsigned vwL = s.visy[lc >> 5], gwL = s.goody[lc >> 5];
+    const int mL = s.match[lc];
+    int yw = p + lane, ywc = min(yw, n - 1);
+    unsigned vwW = s.visy[ywc >> 5], gwW = s.goody[ywc >> 5];
+    double lyW = s.ly[ywc];
+    int mW = s.match[ywc];
+    int best = INT_MAX, mbest = K4_NONE;
+    if (tn == K4_OVER) {  // flagged row: lowest tight unvisited good column of the CSR row
+      const unsigned cb = s.rptr[x], ce = s.rptr[x + 1];
+      for (unsigned c0 = cb; c0 < ce; c0 += 64) {
+        const unsigned c = c0 + lane, cc = min(c, ce - 1u);
+        const int col = s.cols[cc];
+        const double val = s.vals[cc];
+        const bool t = (int)(c < ce) & (int)(((lxv + s.ly[col]) - val) < eps) & (int)(col >= ystart) & (int)!k4_bit(s.visy, col) & (int)k4_bit(s.goody, col);
         const unsigned long long b = __ballot(t);
-        if (b) best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1);
+        if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); mbest = s.match[best]; break; }
       }
-      if (bgt) {  // E7: one scan pointer per distinct label value
-        const unsigned long long hit = __ballot(ck == lxv);
-        int slot, p0 = 0;
-        if (hit) {
-          slot = (int)__ffsll((long long)hit) - 1;
-          p0 = __builtin_amdgcn_readlane(cp, slot);
-        } else {
-          slot = cnext;
-          cnext = (cnext + 1) & 63;
-          if (lane == slot) { ck = lxv; cp = 0; }
-        }
-        const int lim = min(n, best);
-        const int yb = k4_bg_scan(s, lxv, max(ystart, p0), lim, lane);
-        if (ystart <= p0 && lane == slot) cp = (yb != INT_MAX) ? yb : max(p0, lim);
-        best = min(best, yb);
+    } else {
+      const bool t = (int)(lane < ncnt) & (int)(((lxv + lyL) - lv) < eps) & (int)(lc >= ystart) & (int)((((~vwL & gwL) >> (lc & 31)) & 1u) != 0u);
+      const unsigned long long b = __ballot(t);
+      if (b) {
+        const int l = (int)__ffsll((long long)b) - 1;
+        best = __builtin_amdgcn_readlane(lc, l);
+        mbest = __builtin_amdgcn_readlane(mL, l);
       }
     }
+    bool augment = false;
+    if (bgt) {
+      const int lim = min(n, best);
+      bool cand = (int)(yw < lim) & (int)((((~vwW & gwW) >> (ywc & 31)) & 1u) != 0u) & (int)(((lxv + lyW) - bg) < eps);
+      unsigned long long bw = __ballot(cand);
+      while (!bw && p + 64 < lim) {  // windows without a candidate
+        p += 64;
+        yw = p + lane; ywc = min(yw, n - 1);
+        vwW = s.visy[ywc >> 5]; gwW = s.goody[ywc >> 5]; lyW = s.ly[ywc]; mW = s.match[ywc];
+        cand = (int)(yw < lim) & (int)((((~vwW & gwW) >> (ywc & 31)) & 1u) != 0u) & (int)(((lxv + lyW) - bg) < eps);
+        bw = __ballot(cand);
+      }
+      if (tn != 0) {
+        if (bw) {
+          const int l = (int)__ffsll((long long)bw) - 1;
+          best = p + l;
+          mbest = __builtin_amdgcn_readlane(mW, l);
+          if (lane == slot) cp = best;
+        } else if (lane == slot) cp = max(p, lim);
+      } else {
+        // ---- E9 march (km2.hip): a chain of rows without tight explicit entries that share the label L picks the members of
+        // T_L in column order, up to 64 activations per window (lim == n here: the row has no listed entry)
+        int outcome = bw ? 3 : 0;
+        if (!bw) p = n;  // the skip loop above has covered every column below n
+        while (outcome == 3) {
+          bool cont = false;
+          if (cand && mW != K4_NONE) cont = (int)(s.tln[mW] == 0) & (int)(s.lx[mW] == lxv);
+          const unsigned long long stop = __ballot(cand && !cont);
+          const int jstar = stop ? (int)__ffsll((long long)stop) - 1 : 63;
+          const unsigned long long R = bw & (~0ull >> (63 - jstar));  // the picks of this window, in column order
+          const unsigned long long below = R & ((1ull << lane) - 1ull);
+          const int rank = __popcll(below);
+          const int pm = __shfl(mW, below ? 63 - __clzll((long long)below) : 0, 64);
+          if ((R >> lane) & 1ull) {
+            atomicOr(&s.visy[yw >> 5], 1u << (yw & 31));
+            s.sty[sp + rank] = (unsigned short)yw;
+            if (rank > 0) s.stx[sp + rank] = (unsigned short)pm;  // the row that picked this column (frame sp holds x)
+          }
+          const int k = __popcll(R), lastlane = 63 - __clzll((long long)R);
+          const int mlast = __builtin_amdgcn_readlane(mW, lastlane);
+          if (PROF) *q_act += k - 1;
+          sp += k - 1;  // frame of the row that made the last pick
+          p += lastlane + 1;
+          if (mlast == K4_NONE) { outcome = 1; break; }
+          sp++;
+          if (lane == 0) { s.stx[sp] = (unsigned short)mlast; s.sty[sp] = (unsigned short)K4_NONE; }
+          x = mlast; ystart = 0;
+          if (stop) { outcome = 2; break; }  // the owner of the last pick is not part of the chain
+          if (PROF) ++*q_act;                // ... it is: its activation continues the march
+          bw = 0;
+          while (!bw && p < n) {
+            yw = p + lane; ywc = min(yw, n - 1);
+            vwW = s.visy[ywc >> 5]; gwW = s.goody[ywc >> 5]; lyW = s.ly[ywc]; mW = s.match[ywc];
+            cand = (int)(yw < n) & (int)((((~vwW & gwW) >> (ywc & 31)) & 1u) != 0u) & (int)(((lxv + lyW) - bg) < eps);
+            bw = __ballot(cand);
+            if (!bw) p += 64;
+          }
+          if (!bw) outcome = 0;
+        }
+        if (lane == slot) cp = min(p, n);
+        __builtin_amdgcn_wave_barrier();
+        if (outcome == 1) { augment = true; }
+        else if (outcome == 2) continue;
+        // outcome 0: x (possibly a row reached by the march: its frame is sp) has no candidate left -> pop below
+      }
+    }
+    if (augment) break;
     if (best != INT_MAX) {
-      const int m = s.match[best];
       if (lane == 0) { atomicOr(&s.visy[best >> 5], 1u << (best & 31)); s.sty[sp] = (unsigned short)best; }
-      if (m == K4_NONE) { __builtin_amdgcn_wave_barrier(); break; }
+      if (mbest == K4_NONE) break;
       sp++;
-      if (lane == 0) { s.stx[sp] = (unsigned short)m; s.sty[sp] = (unsigned short)K4_NONE; }
-      x = m; ystart = 0;
+      if (lane == 0) { s.stx[sp] = (unsigned short)mbest; s.sty[sp] = (unsigned short)K4_NONE; }
+      x = mbest; ystart = 0;
     } else {
       sp--;
       if (sp < 0) return false;
@@ -422,7 +501,7 @@ __device__ inline int k4_literal(const K4& s, const Km2Problem& P) {
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ probs, int flags) {
+__global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ probs, int flags, int lds_bytes) {
   const Km2Problem P = probs[blockIdx.x];
   if (P.n <= 0 || (P.done && *P.done)) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -444,34 +523,36 @@ __global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ pro
   s.sty = s.stx + n + 2;
   s.tlc = s.sty + n + 2;
   s.tln = (unsigned char*)(s.tlc + (size_t)n * K4_CAP);
+  // pool blocks in whatever the launch's LDS allocation leaves beyond this problem's arrays
+  {
+    char* pend = (char*)(s.tln + n);
+    pend += (8 - ((size_t)pend & 7)) & 7;
+    const long long spare = (long long)lds_bytes - (long long)(pend - smem) - 16;
+    s.nblk = (int)max(0ll, min((long long)K4_MAXBLK, spare / (K4_BLK * 10)));
+    s.pval = (double*)pend;
+    s.pcol = (unsigned short*)(s.pval + (size_t)s.nblk * K4_BLK);
+    s.fb = (unsigned*)(s.pcol + (size_t)s.nblk * K4_BLK + (((size_t)s.nblk * K4_BLK) & 1));
+  }
   const double bg = s.bg, eps = s.eps;
 
   long long c_flood = 0, c_fail = 0, c_pull = 0, c_dfs = 0, q_phase = 0, q_fail = 0, q_rounds = 0, q_iter = 0, q_act = 0, q_frows = 0, q_prows = 0;
+  long long pcf[5] = {0, 0, 0, 0, 0};
   const long long t_begin = PROF ? (long long)__builtin_readcyclecounter() : 0;
 
   for (int i = tid; i < n; i += K4_T) { s.lx[i] = P.lx_init[i]; s.ly[i] = 0.0; s.match[i] = (unsigned short)K4_NONE; s.tln[i] = 0; }
+  for (int i = tid; i < n * K4_CAP; i += K4_T) { s.tlc[i] = 0; s.tlv[i] = 0.0; }  // list slots are read unconditionally: keep them valid
   for (int w = tid; w < nw; w += K4_T) {
     unsigned all = ~0u;
     if (w == nw - 1 && (n & 31)) all = (1u << (n & 31)) - 1u;
     s.freey[w] = all; s.ovf[w] = 0u;
   }
   if (tid < SH_NUM) s.sh[tid] = 0;
+  if (tid < 2) s.fb[tid] = s.nblk >= 32 * (tid + 1) ? ~0u : (s.nblk > 32 * tid ? (1u << (s.nblk - 32 * tid)) - 1u : 0u);
   __syncthreads();
-  // initial lists: every row once (R2)
-  for (int base = 0; base < n; base += 4 * 64) {
-    const int i = base + lane * 4 + wave;
-    unsigned cb = 0, ce = 0;
-    if (i < n) { cb = s.rptr[i]; ce = s.rptr[i + 1]; }
-    for (int l = 0; l < 64; l++) {
-      const int x = base + l * 4 + wave;
-      if (x >= n) break;
-      const unsigned rcb = __builtin_amdgcn_readlane(cb, l), rce = __builtin_amdgcn_readlane(ce, l);
-      int col = 0;
-      double val = 0.0;
-      if (rce > rcb) { const unsigned cc = min(rcb + (unsigned)lane, rce - 1u); col = s.cols[cc]; val = s.vals[cc]; }
-      k4_scan_row<true, false>(s, x, rcb, rce, col, val, lane);
-    }
-  }
+  // initial lists: every row once (R2); stx doubles as the list of all rows
+  for (int i = tid; i < n; i += K4_T) s.stx[i] = (unsigned short)i;
+  __syncthreads();
+  k4_bulk<true, false, false>(s, s.stx, n, wave, lane);
   __syncthreads();
 
   int bad = 0;
@@ -486,8 +567,9 @@ __global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ pro
       __syncthreads();
       const long long t0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
       if (wave == 0) {
-        const bool fr = k4_flood(s, root, lane);
-        if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = s.sh[SH_QT]; }
+        int fq = 0;
+        const bool fr = k4_flood<PROF>(s, root, lane, &fq, pcf);
+        if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
       }
       __syncthreads();
       const bool free_found = s.sh[SH_RES] != 0;
@@ -540,13 +622,26 @@ __global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ pro
       for (int round = 0;; round++) {
         if (PROF) q_rounds++;
         double gm = INFINITY;
-        for (int y = tid; y < n; y += K4_T) {
-          bool g = k4_bit(s.goody, y);
-          if (!g) {
-            const int m = s.match[y];
-            if (m != K4_NONE && k4_bit(s.good, m)) { atomicOr(&s.goody[y >> 5], 1u << (y & 31)); g = true; }
+        for (int base = tid; base < n; base += 4 * K4_T) {  // columns: S gains the columns whose owner is in S
+          int yy[4], mm[4];
+          unsigned gw[4];
+          double lyv[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            yy[k] = base + k * K4_T;
+            const int yc = min(yy[k], n - 1);
+            gw[k] = s.goody[yc >> 5]; mm[k] = s.match[yc]; lyv[k] = s.ly[yc];
           }
-          if (g) gm = fmin(gm, s.ly[y]);
+          unsigned ow[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) ow[k] = s.good[(mm[k] == K4_NONE ? 0 : mm[k]) >> 5];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (yy[k] >= n) continue;
+            bool g = (gw[k] >> (yy[k] & 31)) & 1u;
+            if (!g && mm[k] != K4_NONE && ((ow[k] >> (mm[k] & 31)) & 1u)) { atomicOr(&s.goody[yy[k] >> 5], 1u << (yy[k] & 31)); g = true; }
+            if (g) gm = fmin(gm, lyv[k]);
+          }
         }
         gm = k4_wave_min(gm);
         if (lane == 0) s.red[8 + wave] = gm;
@@ -554,19 +649,41 @@ __global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ pro
         if (tid == 0) s.sh[SH_CH0 + ((round + 1) & 1)] = 0;
         const double gmin = fmin(fmin(s.red[8], s.red[9]), fmin(s.red[10], s.red[11]));
         bool ch = false;
-        for (int x = tid; x < n; x += K4_T) {
-          if (k4_bit(s.good, x)) continue;
-          const double lxv = s.lx[x];
-          bool g = ((lxv - bg) < eps) & (((lxv + gmin) - bg) < eps);
-          if (!g) {
-            const int tn = s.tln[x];
-            for (int k = 0; k < K4_CAP; k++)
-              if (k < tn) {
-                const int col = s.tlc[x * K4_CAP + k];
-                g |= (((lxv + s.ly[col]) - s.tlv[x * K4_CAP + k]) < eps) & k4_bit(s.goody, col);
-              }
+        for (int base = tid; base < n; base += 4 * K4_T) {  // rows: background-tight to the best column of S, or a listed entry in S
+          int xx[4], tn[4], lc[4][K4_CAP];
+          unsigned gdw[4];
+          double lxv[4], lv[4][K4_CAP];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            xx[k] = base + k * K4_T;
+            const int xc = min(xx[k], n - 1);
+            gdw[k] = s.good[xc >> 5]; lxv[k] = s.lx[xc]; tn[k] = s.tln[xc];
+#pragma unroll
+            for (int e = 0; e < K4_CAP; e++) { lc[k][e] = s.tlc[xc * K4_CAP + e]; lv[k][e] = s.tlv[xc * K4_CAP + e]; }
           }
-          if (g) { atomicOr(&s.good[x >> 5], 1u << (x & 31)); ch = true; }
+          double lyc[4][K4_CAP];
+          unsigned gyw[4][K4_CAP];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < K4_CAP; e++) { lyc[k][e] = s.ly[lc[k][e]]; gyw[k][e] = s.goody[lc[k][e] >> 5]; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (xx[k] >= n || ((gdw[k] >> (xx[k] & 31)) & 1u)) continue;
+            bool g = (int)((lxv[k] - bg) < eps) & (int)(((lxv[k] + gmin) - bg) < eps);
+            const int cn = k4_cnt(tn[k]), t = min(cn, K4_CAP);
+#pragma unroll
+            for (int e = 0; e < K4_CAP; e++)
+              g |= (int)(e < t) & (int)(((lxv[k] + lyc[k][e]) - lv[k][e]) < eps) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);
+            if (!g && cn > K4_CAP) {
+              const int pb = k4_blk(tn[k]) * K4_BLK - K4_CAP;
+              for (int e = K4_CAP; e < cn; e++) {
+                const int col = s.pcol[pb + e];
+                g |= (int)(((lxv[k] + s.ly[col]) - s.pval[pb + e]) < eps) & (int)k4_bit(s.goody, col);
+              }
+            }
+            if (g) { atomicOr(&s.good[xx[k] >> 5], 1u << (xx[k] & 31)); ch = true; }
+          }
         }
         if (ch) s.sh[SH_CH0 + (round & 1)] = 1;
         __syncthreads();
@@ -605,6 +722,7 @@ __global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ pro
         P.steps[1] = q_phase; P.steps[2] = q_fail; P.steps[3] = q_rounds; P.steps[4] = q_iter; P.steps[5] = q_frows; P.steps[6] = q_prows;
         P.steps[7] = c_flood; P.steps[8] = c_fail; P.steps[9] = c_pull; P.steps[10] = c_dfs;
         P.steps[11] = (long long)__builtin_readcyclecounter() - t_begin; P.steps[12] = hazard ? 1 : 0;
+        for (int k = 0; k < 5; k++) P.steps[13 + k] = pcf[k];
       }
     }
   }
@@ -617,18 +735,30 @@ size_t gh_km4_lds_bytes(int n) {
   return (size_t)n * (3 + K4_CAP) * 8 + 16 * 8 + 8 * nw * 4 + SH_NUM * 4 + ((size_t)n * (1 + K4_CAP) + 2 * ((size_t)n + 2)) * 2 + (size_t)n + 64;
 }
 
+// what a launch asks for: the arrays plus, with GHICP_KM_POOL=1, as many pool blocks (rows with 4..8 tight entries) as fit without
+// lowering the number of problems per CU.  Off by default: on the cfg2 matrices the blocks cut the DFS iterations by 10-25 % but the
+// rows they hold are no longer in S from the start, S needs 5-25 % more rounds, and the solve ends up 0-8 % SLOWER (n = 840 leaves
+// room for 43 blocks only; profiles/r02_km4_stages.txt).
+static size_t k4_launch_lds(int n) {
+  if (!getenv("GHICP_KM_POOL")) return gh_km4_lds_bytes(n);
+  const size_t base = gh_km4_lds_bytes(n), cu = 160 * 1024;
+  const size_t per_cu = std::max<size_t>(1, cu / base);
+  const size_t room = cu / per_cu - 64;
+  return std::min(room, base + (size_t)K4_MAXBLK * K4_BLK * 10 + 32);
+}
+
 bool gh_km4_fits(int n) { return n <= 65534 && gh_km4_lds_bytes(n) <= 160 * 1024 - 256; }
 
 int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max) {
-  const size_t lds = gh_km4_lds_bytes(n_max);
+  const size_t lds = std::max(gh_km4_lds_bytes(n_max), k4_launch_lds(n_max));
   const size_t want = 160 * 1024;
   // per device and thread safe: the attribute is cheap to set, so it is simply set before every launch
   GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
   GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
   const int kflags = getenv("GHICP_KM_FORCE_HAZARD") ? 4 : 0;  // test hook: sends one phase through the hazard fallback
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
-  if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL((k_km4<true>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags);
-  else hipLaunchKernelGGL((k_km4<false>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags);
+  if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL((k_km4<true>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds);
+  else hipLaunchKernelGGL((k_km4<false>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds);
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;

@@ -152,3 +152,25 @@ def test_rigid_svd(ctx, oracle):
     Rg, Ro = ctx.rigid_svd(src, tgt), oracle.rigid_svd(src, tgt)
     np.testing.assert_array_equal(Rg, Ro)
     assert np.abs(Rg[:3, :3] - R).max() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "GHICP_KM_V2", "GHICP_KM_POOL", "GHICP_KM_FORCE_HAZARD"])
+def test_km_solver_paths_fuzz(ctx, oracle, mode):
+    """Every Kuhn-Munkres path of the library on the fuzz generators of scripts/km4_model_fuzz.py (ties, dense rows, empty rows,
+    ulp-perturbed lattices): the flood-first kernel (default), the DFS emulation it replaced (GHICP_KM_V2), the pool-block variant
+    and the literal fallback behind the slack-hazard check -- all bit-exact against the restatement of km.cpp:13-126."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import km4_model_fuzz as F
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 3, 5, 17, 64, 65, 130, 200] if mode == "GHICP_KM_FORCE_HAZARD" else [1, 2, 3, 5, 17, 64, 65, 130, 333, 700]
+    if mode != "default":
+        os.environ[mode] = "1"
+    try:
+        for t in range(60):
+            n = int(rng.choice(sizes))
+            w = F.gen(rng, n, t % 5)
+            np.testing.assert_array_equal(ctx.km_solve(w).cpu().numpy(), oracle.km(w)[0], err_msg="%s t=%d n=%d" % (mode, t, n))
+    finally:
+        os.environ.pop(mode, None)

@@ -1,0 +1,46 @@
+"""Rule-level model of the flood-first Kuhn-Munkres kernel (oracle/km4_model.inc) against the restatement of the reference
+traversal (oracle orc::KM, pinned to the reference's compiled km.cpp in test_oracle_cpu.py) -- CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import km4_model_fuzz as F  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("it", [0, 10, 30])
+def test_km4_model_real_matrices(oracle, it):
+    z = np.load(os.path.join(GOLD, "km_cfg2_it%d.npz" % it))
+    n = int(z["n"])
+    w = np.full((n, n), float(z["bg"]))
+    w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
+    ref, _ = oracle.km(w)
+    for cap in (1, 3):
+        m, st = oracle.km4_model(w, cap=cap)
+        assert m is not None, "hazard on a real matrix"
+        np.testing.assert_array_equal(m, ref)
+        assert st["failed"] in (727, 3193, 784) and (cap != 3 or st["dfs_steps"] < 200_000)
+
+
+def test_km4_model_fuzz(oracle):
+    rng = np.random.default_rng(20260925)
+    for t in range(400):
+        n = int(rng.choice([1, 2, 3, 5, 8, 17, 40, 65, 100, 130]))
+        w = F.gen(rng, n, t % 5)
+        ref, _ = oracle.km(w)
+        for cap, prune in ((1, True), (3, True), (3, False)):
+            m, _ = oracle.km4_model(w, cap=cap, prune=prune)
+            assert m is not None
+            np.testing.assert_array_equal(m, ref, err_msg="t=%d n=%d cap=%d prune=%s" % (t, n, cap, prune))
+
+
+def test_km4_model_kat_and_degenerate(oracle):
+    W = np.array([[-5, -2, -100], [-4, -2, -6], [-100, -1, -7]], np.float64)  # km.cpp:237-259
+    assert oracle.km4_model(W)[0].tolist() == [0, 2, 1]
+    for w in (np.full((7, 7), -3.0), np.zeros((1, 1)), -np.eye(6) * 2.0 - 1.0):
+        np.testing.assert_array_equal(oracle.km4_model(w)[0], oracle.km(w)[0])
