@@ -293,7 +293,7 @@ int gh_bsc_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, const 
 
 extern "C" int ghicp_bsc_encode(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, const int32_t* kp_idx, int64_t k, float radius, int dof,
                                 const int32_t* pattern, uint8_t* feat, float* lcs) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(m >= 0 && m < (1ll << 31) - 2 && k >= 0 && k <= m && stride >= 3 && radius > 0.f && pattern != nullptr);
   Stager sg(ctx);
   const float* d;

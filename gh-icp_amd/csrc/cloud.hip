@@ -106,7 +106,7 @@ static int cloud_fill(ghicp_ctx* ctx, ghicp_cloud* c, const float* d, long long 
 }
 
 extern "C" int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* xyz, int64_t n, int stride, ghicp_cloud** out) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(cfg != nullptr && out != nullptr && stride >= 3 && n >= 0 && n < (1ll << 31) - 2);
   GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   Stager sg(ctx);
@@ -124,6 +124,7 @@ extern "C" int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, 
 extern "C" int ghicp_cloud_recompute(ghicp_cloud* c, const float* xyz, int64_t n, int stride) {
   if (!c || !c->ctx) return GHICP_ERR_ARG;
   ghicp_ctx* ctx = c->ctx;
+  GH_ENTER(ctx);
   GH_ARG(stride >= 3 && n >= 0 && n < (1ll << 31) - 2);
   Stager sg(ctx);
   const float* d;
@@ -133,7 +134,7 @@ extern "C" int ghicp_cloud_recompute(ghicp_cloud* c, const float* xyz, int64_t n
 
 extern "C" int ghicp_cloud_from_features(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const double* kp_xyz, int64_t k, const void* feat,
                                          float bbx_magnitude, ghicp_cloud** out) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(cfg != nullptr && out != nullptr && k >= 0 && k < (1 << 24) && (k == 0 || kp_xyz != nullptr));
   GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   GH_ARG(cfg->reg.feature == GHICP_FEATURE_NONE || k == 0 || feat != nullptr);
@@ -161,6 +162,7 @@ extern "C" int ghicp_cloud_from_features(ghicp_ctx* ctx, const ghicp_pair_config
 
 extern "C" int ghicp_cloud_destroy(ghicp_cloud* c) {
   if (!c) return GHICP_OK;
+  if (c->ctx) (void)hipSetDevice(c->ctx->device);
   c->ds.release(); c->kp.release(); c->kpx.release(); c->feat.release();
   delete c;
   return GHICP_OK;
@@ -182,6 +184,7 @@ extern "C" int ghicp_cloud_get_info(const ghicp_cloud* c, ghicp_cloud_info* info
 extern "C" int ghicp_cloud_download(const ghicp_cloud* c, float* ds_xyz, int32_t* kp_idx, double* kp_xyz, void* feat) {
   if (!c) return GHICP_ERR_ARG;
   ghicp_ctx* ctx = c->ctx;
+  GH_ENTER(ctx);
   hipStream_t s = ctx->stream;
   const hipMemcpyKind kind = ctx->host_ptrs ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (ds_xyz && c->m > 0) {
@@ -203,7 +206,7 @@ extern "C" int ghicp_cloud_download(const ghicp_cloud* c, float* ds_xyz, int32_t
 // Registers n_pairs (S[i] -> T[i]) from cached front ends: feature distance per pair, then one batched GH-ICP loop.
 extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const ghicp_cloud* const* S,
                                      const ghicp_cloud* const* T, ghicp_pair_stats* stats) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(cfg != nullptr && stats != nullptr && n_pairs >= 0 && n_pairs <= 65535 && (n_pairs == 0 || (S && T)));
   if (n_pairs == 0) return GHICP_OK;
   hipStream_t s = ctx->stream;

@@ -25,6 +25,14 @@
     if (!(cond)) return ctx->fail(GHICP_ERR_ARG, "%s: bad argument (%s)", __func__, #cond); \
   } while (0)
 
+// First statement of every ABI entry that takes a context: HIP's current device is per THREAD and starts at 0, so a context
+// driven from a worker thread (bench.py, any thread pool of a caller) must select its own device before it allocates or launches.
+#define GH_ENTER(ctx)                                                                                             \
+  do {                                                                                                            \
+    if (!(ctx)) return GHICP_ERR_ARG;                                                                             \
+    if (hipSetDevice((ctx)->device) != hipSuccess) return (ctx)->fail(GHICP_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device); \
+  } while (0)
+
 // grow-only device buffer
 struct DevBuf {
   void* p = nullptr;

@@ -58,7 +58,7 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
 }
 
 extern "C" int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* s) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   ctx->stream = reinterpret_cast<hipStream_t>(s);
   return GHICP_OK;
 }
@@ -66,7 +66,7 @@ extern "C" int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* s) {
 // hipExtStreamCreateWithCUMask).  Used to keep a few CUs free of Kuhn-Munkres waves -- whose LDS footprint otherwise
 // fills every CU -- so that the small front-end kernels of the next batch run next to a solve launch.
 extern "C" int ghicp_ctx_set_cu_mask(ghicp_ctx* ctx, const uint32_t* mask, int32_t n_words) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(mask != nullptr && n_words >= 1 && n_words <= 64);
   bool any = false;
   for (int i = 0; i < n_words; i++) any = any || mask[i] != 0u;
@@ -80,17 +80,17 @@ extern "C" int ghicp_ctx_set_cu_mask(ghicp_ctx* ctx, const uint32_t* mask, int32
 }
 
 extern "C" int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   ctx->host_ptrs = on != 0;
   return GHICP_OK;
 }
 extern "C" int ghicp_ctx_synchronize(ghicp_ctx* ctx) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_HIP(hipStreamSynchronize(ctx->stream));
   return GHICP_OK;
 }
 extern "C" int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->kt_collect();
   ctx->kt_on = on != 0;
@@ -98,7 +98,7 @@ extern "C" int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on) {
   return GHICP_OK;
 }
 extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(name != nullptr);
   GH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->kt_collect();
@@ -213,7 +213,7 @@ int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float
 }
 
 extern "C" int ghicp_bbx_magnitude(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float* bbx) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(bbx != nullptr && n >= 0 && stride >= 3);
   Stager sg(ctx);
   const float* d;
@@ -227,7 +227,7 @@ extern "C" int ghicp_bbx_magnitude(ghicp_ctx* ctx, const float* xyz, int64_t n, 
 }
 
 extern "C" int ghicp_rigid_svd(ghicp_ctx* ctx, const double* src, const double* tgt, int64_t c, double* Rt16) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(c > 0 && src && tgt && Rt16);
   Stager sg(ctx);
   const double *ds, *dt;
@@ -280,7 +280,7 @@ extern "C" int ghicp_rigid_svd_host(const double* src, const double* tgt, int64_
 }
 
 extern "C" int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const double* Rt, float* out) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(n >= 0 && stride >= 3 && Rt != nullptr);
   Stager sg(ctx);
   const float* d;
@@ -298,7 +298,7 @@ extern "C" int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n
 }
 
 extern "C" int ghicp_gather_points(ghicp_ctx* ctx, const float* xyz, int stride, const int32_t* idx, int64_t m, float* out) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(m >= 0 && stride >= 3);
   if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_gather_points: device-pointer mode only");
   if (m > 0) {

@@ -100,7 +100,7 @@ int gh_fd_fpfh_dev(ghicp_ctx* ctx, const float* histS, int ks, const float* hist
 }
 
 extern "C" int ghicp_fd_bsc(ghicp_ctx* ctx, const uint8_t* featS, int64_t ks, int V, const uint8_t* featT, int64_t kt, uint16_t* FD) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(ks >= 0 && kt >= 0 && V >= 1 && V <= 4 && ks < (1 << 24) && kt < (1 << 24));
   Stager sg(ctx);
   const uint8_t *dS, *dT;
@@ -113,7 +113,7 @@ extern "C" int ghicp_fd_bsc(ghicp_ctx* ctx, const uint8_t* featS, int64_t ks, in
 }
 
 extern "C" int ghicp_fd_fpfh(ghicp_ctx* ctx, const float* histS, int64_t ks, const float* histT, int64_t kt, float* FD) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(ks >= 0 && kt >= 0 && ks < (1 << 24) && kt < (1 << 24));
   Stager sg(ctx);
   const float *dS, *dT;

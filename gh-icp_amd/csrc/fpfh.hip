@@ -302,7 +302,7 @@ int gh_gather_rows33_dev(ghicp_ctx* ctx, const float* hist, const int32_t* idx, 
 }
 
 extern "C" int ghicp_fpfh(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, int k_normal, int k_feature, float* normals, float* hist) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(m >= 0 && m < (1ll << 31) - 2 && stride >= 3 && hist != nullptr);
   if (k_normal != KNN || k_feature != KNN) return ctx->fail(GHICP_ERR_ARG, "ghicp_fpfh: k must be 20/20 as in fpfh.hpp:43,52");
   Stager sg(ctx);
@@ -316,7 +316,7 @@ extern "C" int ghicp_fpfh(ghicp_ctx* ctx, const float* xyz, int64_t m, int strid
 }
 
 extern "C" int ghicp_fpfh_keypoints(ghicp_ctx* ctx, const float* hist, const int32_t* kp_idx, int64_t k, float* out) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(k >= 0);
   if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_fpfh_keypoints: device-pointer mode only");
   return gh_gather_rows33_dev(ctx, hist, kp_idx, k, out);

@@ -2,6 +2,8 @@
 // voxel down-sampling filter.  rocPRIM/hipCUB is used for the radix sort / select primitives only.
 #include "grid.h"
 
+#include <algorithm>
+
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
@@ -54,6 +56,14 @@ int gh_grid_build(ghicp_ctx* ctx, const float* xyz, long long n, int stride, flo
   g.n = (int)n;
   float mm[6] = {0, 0, 0, 0, 0, 0};
   if (n > 0) GH_TRY(gh_bbox_dev(ctx, xyz, n, stride, mm));
+  {  // Callers pass radius * 1.0001; the float rounding of (v - mn) * inv grows with the cell coordinate (ulp(1000) = 6e-5), so beyond
+     // a few hundred cells per axis the margin is widened with the extent: two points closer than the radius never end up two
+     // cells apart.  (Below 256 cells the cell size -- and with it every enumeration order -- is what it always was.)
+    float ext = 0.f;
+    for (int d = 0; d < 3; d++) ext = std::max(ext, mm[3 + d] - mm[d]);
+    const float dims = ext / cell;
+    if (dims > 256.f) cell *= 1.0f + 4e-7f * dims;
+  }
   for (;;) {  // coarsen until the dense cell table is affordable (a larger cell is still exact: superset search)
     g.inv = 1.0f / cell;
     unsigned long long nc = 1;
@@ -175,7 +185,7 @@ int gh_voxel_filter_dev(ghicp_ctx* ctx, const float* xyz, long long n, int strid
 }
 
 extern "C" int ghicp_voxel_filter(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float voxel, int32_t* keep_idx, int64_t* m) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(n >= 0 && n < (1ll << 31) - 2 && stride >= 3 && voxel > 0.f && m != nullptr);
   Stager sg(ctx);
   const float* d;

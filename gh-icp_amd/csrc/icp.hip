@@ -708,7 +708,7 @@ extern "C" void ghicp_inv_transform(const float* T, float* inv) {
 
 extern "C" int ghicp_cal_overlap(ghicp_ctx* ctx, const float* xyz1, int64_t n1, int stride1, const float* xyz2, int64_t n2, int stride2,
                                  float thre_dis, float* ratio) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(n1 >= 0 && n2 >= 0 && n1 < (1ll << 31) - 2 && n2 < (1ll << 31) - 2 && stride1 >= 3 && stride2 >= 3 && thre_dis > 0.f && ratio != nullptr);
   Stager sg(ctx);
   const float *d1, *d2;
@@ -718,7 +718,7 @@ extern "C" int ghicp_cal_overlap(ghicp_ctx* ctx, const float* xyz1, int64_t n1, 
 }
 
 extern "C" int ghicp_transform_cloud_f32(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const float* T16, float* out) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(n >= 0 && stride >= 3 && T16 != nullptr);
   Stager sg(ctx);
   const float* d;
@@ -735,7 +735,7 @@ extern "C" int ghicp_transform_cloud_f32(ghicp_ctx* ctx, const float* xyz, int64
 }
 
 extern "C" int ghicp_knn_normals(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, int k, float* normals) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(n >= 0 && n < (1ll << 31) - 2 && stride >= 3 && normals != nullptr);
   Stager sg(ctx);
   const float* d;
@@ -748,7 +748,7 @@ extern "C" int ghicp_knn_normals(ghicp_ctx* ctx, const float* xyz, int64_t n, in
 
 extern "C" int ghicp_nn_search(ghicp_ctx* ctx, const float* query, int64_t nq, int strideQ, const float* xyzT, int64_t nt, int strideT,
                                int32_t* idx, float* d2) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(nq >= 0 && nt > 0 && nq < (1ll << 31) - 2 && nt < (1ll << 31) - 2 && strideQ >= 3 && strideT >= 3);
   Stager sg(ctx);
   const float *dq, *dt;
@@ -771,7 +771,7 @@ extern "C" int ghicp_nn_search(ghicp_ctx* ctx, const float* query, int64_t nq, i
 
 extern "C" int ghicp_icp(ghicp_ctx* ctx, const float* xyzS, int64_t ns, int strideS, const float* xyzT, int64_t nt, int strideT,
                          const ghicp_icp_params* P, float* T16, float* transformed, ghicp_icp_stats* stats) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(P != nullptr && T16 != nullptr && stats != nullptr && ns >= 0 && nt >= 0 && ns < (1ll << 31) - 2 && nt < (1ll << 31) - 2 && strideS >= 3 &&
          strideT >= 3);
   GH_ARG(P->metric == GHICP_ICP_POINT_TO_POINT || P->metric == GHICP_ICP_POINT_TO_PLANE);

@@ -213,10 +213,8 @@ int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t*
   const size_t lds_limit = 160 * 1024 - 512;
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
   if (hot <= lds_limit) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    {  // per device: set before every launch
       GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
-      attr_set = true;
     }
     hipLaunchKernelGGL(k_km_solve<true>, dim3(1), dim3(KM_THREADS), hot, s, done_flag, w, n, eps, lx, match, scratch, status);
   } else {
@@ -231,7 +229,7 @@ bool gh_km2_fits(int n);
 int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, int* status_dev);
 
 extern "C" int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double eps, int32_t* match) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(n >= 0 && n < 46000 && (n == 0 || (w != nullptr && match != nullptr)));
   Stager sg(ctx);
   const double* dw;

@@ -721,14 +721,12 @@ __global__ __launch_bounds__(1024) void k_gh_scan_rows(const unsigned* __restric
 int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max) {
   // default: the flood-first solver (km4.hip) whenever its state fits LDS; GHICP_KM_V2=1 keeps this file's DFS emulation
   if (gh_km4_fits(n_max) && !getenv("GHICP_KM_V2")) return gh_km4_launch(ctx, d_probs, nprob, n_max);
-  static bool attr_done = false;
-  if (!attr_done) {
+  {  // per device, and cheap: set before every launch instead of behind a process-wide flag
     const size_t want = 160 * 1024;
     GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
-    attr_done = true;
   }
   // v2 and v3 solve at the same speed (the DFS is instruction-issue bound, not memory bound: profiles/r01_km_step_counters.txt);
   // v2 needs less LDS per problem, so more problems are resident per CU -> default. GHICP_KM_V3=1 selects the list kernel.

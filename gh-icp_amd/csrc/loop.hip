@@ -65,6 +65,12 @@ __device__ inline double combined_distance(double ed, const void* fd, size_t idx
   return ed;                                                                                                     // ghicp_reg.cpp:224
 }
 
+template <int FT>
+__device__ inline double cd_pivot(const LoopProb& P, double wed, double wfd, double inv_k) {
+  const double dx = P.kpS[0] - P.kpT[0], dy = P.kpS[1] - P.kpT[1], dz = P.kpS[2] - P.kpT[2];
+  return combined_distance<FT>((double)P.C.scale * sqrt(dx * dx + dy * dy + dz * dz), P.FD, 0, wed, wfd, inv_k);
+}
+
 // One sweep: thread = "row" a (keypoint of set A), loop over a chunk of set B staged in LDS.
 // The feature matrix is read as [b][a] so that lanes (consecutive a) touch consecutive addresses.
 // Row arg-min semantics = ghicp_reg.cpp:715-724 / 622-650: start (9e20, 0), strict '<', ascending index.
@@ -95,13 +101,17 @@ __global__ __launch_bounds__(ROWS) void k_cd_rowmin(const LoopProb* __restrict__
   const double dscale = (double)P.C.scale;
   double best = 9e20, s = 0, s2 = 0;
   int bidx = 0;
+  // CDmean / CDstd are accumulated around a pivot (the CD of keypoint pair (0,0), the same value in every block and in
+  // k_penalty): sum^2 / n - mean^2 would cancel when the spread of CD is small against its mean (ghicp_reg.cpp:266-273 is two-pass)
+  double piv = 0;
+  if (!COLS) piv = cd_pivot<FT>(P, wed, wfd, inv_k);
   if (live) {
     for (int j = jb; j < je; j++) {
       const double dx = ax - sB[(j - jb) * 3], dy = ay - sB[(j - jb) * 3 + 1], dz = az - sB[(j - jb) * 3 + 2];
       const double ed = dscale * sqrt(dx * dx + dy * dy + dz * dz);  // ghicp_reg.cpp:122
       const double cd = combined_distance<FT>(ed, F, (size_t)j * ka + a, wed, wfd, inv_k);
       if (cd < best) { best = cd; bidx = j; }
-      if (!COLS) { s += cd; s2 += cd * cd; }
+      if (!COLS) { const double c0 = cd - piv; s += c0; s2 += c0 * c0; }
     }
     (COLS ? P.pminB : P.pminA)[(size_t)blockIdx.y * ka + a] = best;
     (COLS ? P.pidxB : P.pidxA)[(size_t)blockIdx.y * ka + a] = bidx;
@@ -131,8 +141,15 @@ __global__ __launch_bounds__(256) void k_penalty(const LoopProb* __restrict__ pr
   if (threadIdx.x == 0) {
     const int it = st->it;
     const double cnt = (double)C.ks * (double)C.kt;
-    const double mean = s / (double)C.kt / (double)C.ks;
-    double var = s2 / cnt - mean * mean;
+    double piv, wfd0 = 0, wed0 = 1;
+    if (C.feature == GHICP_FEATURE_BSC) { wfd0 = P.wfd[it]; wed0 = 1.0 - wfd0; }
+    const double inv_k0 = 1.0 / (double)(it + 1);
+    if (C.feature == GHICP_FEATURE_BSC) piv = cd_pivot<GHICP_FEATURE_BSC>(P, wed0, wfd0, inv_k0);
+    else if (C.feature == GHICP_FEATURE_FPFH) piv = cd_pivot<GHICP_FEATURE_FPFH>(P, wed0, wfd0, inv_k0);
+    else piv = cd_pivot<GHICP_FEATURE_NONE>(P, wed0, wfd0, inv_k0);
+    const double dm = s / (double)C.kt / (double)C.ks;  // mean of (CD - pivot)
+    const double mean = piv + dm;
+    double var = s2 / cnt - dm * dm;
     if (var < 0) var = 0;
     const double sd = sqrt(var);
     double pen;
@@ -283,8 +300,8 @@ __global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ pro
     for (int base = 0; base < C.n; base += nt) {
       const int y = base + tid;
       int flag = 0, x = -1;
-      if (y < C.n) {
-        x = P.kmmatch[y];
+      if (y < C.n) x = P.kmmatch[y];
+      if (y < C.n && x >= 0) {  // x < 0: the solver gave up (non-finite weights); no correspondence, status reported by the host
         double g = -penalty;
         if (P.km_rptr) {  // sparse graph: (x,y) carries a weight != -penalty iff it is an explicit entry
           unsigned lo = P.km_rptr[x], hi = P.km_rptr[x + 1];
@@ -670,6 +687,11 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
           GH_HIP(hipMemcpy(&v, hp[b].km_status, sizeof(int), hipMemcpyDeviceToHost));
           kmst |= v;
         }
+      if (any_dense && ctx->buf[B_KM_MISC].p) {  // the dense fallback reports through the context's own status word
+        int v = 0;
+        GH_HIP(hipMemcpy(&v, ctx->buf[B_KM_MISC].p, sizeof(int), hipMemcpyDeviceToHost));
+        kmst |= v;
+      }
       if (kmst) return ctx->fail(GHICP_ERR_INTERNAL, "KM solver status %d (non-finite energy?)", kmst);
     }
   }
@@ -708,7 +730,7 @@ int gh_register_dev(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, in
 
 extern "C" int ghicp_register(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int64_t ks, const double* kpT, int64_t kt,
                               const void* FD, double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(p != nullptr && ks >= 0 && kt >= 0 && ks < (1 << 24) && kt < (1 << 24));
   Stager sg(ctx);
   const double *dS, *dT;

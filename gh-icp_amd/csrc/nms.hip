@@ -11,6 +11,8 @@
 // Rank = (curvature desc, candidate order asc): stable radix sort, so ties resolve to the lower point index.
 #include "grid.h"
 
+#include <algorithm>
+
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
@@ -262,6 +264,12 @@ int gh_nms_dev(ghicp_ctx* ctx, const float* xyz, int stride, const double* curva
     GridDesc g;
     memset(&g, 0, sizeof(g));
     float cell = radius * 1.0001f;
+    {  // same extent-dependent margin as gh_grid_build
+      float ext = 0.f;
+      for (int d = 0; d < 3; d++) ext = std::max(ext, mm[3 + d] - mm[d]);
+      const float dims = ext / cell;
+      if (dims > 256.f) cell *= 1.0f + 4e-7f * dims;
+    }
     for (;;) {
       g.inv = 1.0f / cell;
       unsigned long long nc = 1;
@@ -372,7 +380,7 @@ int gh_keypoints_adaptive_dev(ghicp_ctx* ctx, const float* xyz, long long m, int
 extern "C" int ghicp_keypoints_adaptive(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float ratio_max, int min_n,
                                         float nms_radius, int64_t upper, int64_t lower, int32_t* kp_idx, int64_t* k, float* ratio_used,
                                         int32_t* rounds) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(m >= 0 && m < (1ll << 31) - 2 && stride >= 3 && radius > 0.f && nms_radius > 0.f && k != nullptr && upper >= 0 && lower >= 0);
   Stager sg(ctx);
   const float* d;
@@ -389,7 +397,7 @@ extern "C" int ghicp_keypoints_adaptive(ghicp_ctx* ctx, const float* xyz, int64_
 
 extern "C" int ghicp_nms(ghicp_ctx* ctx, const float* xyz, int stride, const double* curvature, const int32_t* cand, int64_t c, float radius,
                          int32_t* kp, int64_t* k) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(c >= 0 && c < (1ll << 31) - 2 && stride >= 3 && radius > 0.f && k != nullptr);
   if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_nms: device-pointer mode only (use ghicp_keypoints from host memory)");
   long long kk = 0;
@@ -400,7 +408,7 @@ extern "C" int ghicp_nms(ghicp_ctx* ctx, const float* xyz, int stride, const dou
 
 extern "C" int ghicp_keypoints(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float ratio_max, int min_n,
                                float nms_radius, int32_t* kp_idx, int64_t* k) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(m >= 0 && m < (1ll << 31) - 2 && stride >= 3 && radius > 0.f && nms_radius > 0.f && k != nullptr);
   Stager sg(ctx);
   const float* d;

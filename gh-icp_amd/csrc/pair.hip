@@ -146,7 +146,7 @@ static int front_end(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* 
 
 extern "C" int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg, const float* xyzS, int64_t nS, const float* xyzT, int64_t nT,
                                    int stride, ghicp_pair_stats* stats, ghicp_iter* trace) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(cfg != nullptr && stats != nullptr && stride >= 3 && nS >= 0 && nT >= 0 && nS < (1ll << 31) - 2 && nT < (1ll << 31) - 2);
   GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   hipStream_t s = ctx->stream;
@@ -188,7 +188,7 @@ extern "C" int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg,
 // stats[i].ms_* hold the batch-level timings divided by the number of pairs (ms_total = batch wall time / n).
 extern "C" int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const float* const* xyzS, const int64_t* nS,
                                     const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(cfg != nullptr && stats != nullptr && n_pairs >= 0 && n_pairs <= 65535 && stride >= 3 && xyzS && xyzT && nS && nT);
   GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_register_pairs: device-pointer mode only");

@@ -183,7 +183,7 @@ int gh_prune_dev(ghicp_ctx* ctx, const float* lambda, const int32_t* count, long
 
 extern "C" int ghicp_pca_curvature(ghicp_ctx* ctx, const float* xyz, int64_t m, int stride, float radius, float* lambda, double* curvature,
                                    int32_t* count) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(m >= 0 && m < (1ll << 31) - 2 && stride >= 3 && radius > 0.f);
   Stager sg(ctx);
   const float* d;
@@ -200,7 +200,7 @@ extern "C" int ghicp_pca_curvature(ghicp_ctx* ctx, const float* xyz, int64_t m, 
 
 extern "C" int ghicp_prune(ghicp_ctx* ctx, const float* lambda, const int32_t* count, int64_t m, float ratio_max, int min_n, int32_t* cand,
                            int64_t* c) {
-  if (!ctx) return GHICP_ERR_ARG;
+  GH_ENTER(ctx);
   GH_ARG(m >= 0 && m < (1ll << 31) - 2 && c != nullptr);
   Stager sg(ctx);
   const float* dl;
