@@ -69,7 +69,7 @@ enum BufSlot {
   // pair pipeline
   B_P_KEEP_S, B_P_KEEP_T, B_P_DS_S, B_P_DS_T, B_P_KP_S, B_P_KP_T, B_P_KPXYZ_S, B_P_KPXYZ_T, B_P_FEAT_S, B_P_FEAT_T, B_P_LCS,
   B_P_FD, B_P_MISC, B_P_PATTERN,
-  B_KM_LX, B_KM_MISC, B_KM_SLACK,
+  B_KM_LX, B_KM_MISC, B_KM_SLACK, B_KM_LSTAT, B_KM_ORDER,
   // fine registration (icp.hip): coarse target grid, source grids (reciprocal), per-point state
   B_ICP_TC_KEYS, B_ICP_TC_KEYS2, B_ICP_TC_VALS, B_ICP_TC_VALS2, B_ICP_TC_START, B_ICP_TC_PTS,
   B_ICP_SC_KEYS, B_ICP_SC_KEYS2, B_ICP_SC_VALS, B_ICP_SC_VALS2, B_ICP_SC_START, B_ICP_SC_PTS,
@@ -117,6 +117,11 @@ struct ghicp_ctx {
     }
     kt_pending.clear();
   }
+  // per-launch statistics of the Kuhn-Munkres solve launches (collected while kernel timing is on): device records of
+  // KM_LSTAT_MAX launches x 5 words, and the solve slots (resident workgroups) each launch had
+  static constexpr int KM_LSTAT_MAX = 8192;
+  long long km_launches = 0;
+  std::vector<int> km_slots;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;  // created by ghicp_ctx_set_cu_mask

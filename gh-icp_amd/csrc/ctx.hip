@@ -95,6 +95,13 @@ extern "C" int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on) {
   ctx->kt_collect();
   ctx->kt_on = on != 0;
   for (int i = 0; i < KT_NUM; i++) { ctx->kt_ms[i] = 0; ctx->kt_count[i] = 0; }
+  if (on) {  // Kuhn-Munkres launch records start over (they stay readable after timing is switched off)
+    unsigned long long* lstat;
+    GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * 5, &lstat));
+    GH_HIP(hipMemsetAsync(lstat, 0, (size_t)ghicp_ctx::KM_LSTAT_MAX * 5 * sizeof(unsigned long long), ctx->stream));
+    ctx->km_launches = 0;
+    ctx->km_slots.clear();
+  }
   return GHICP_OK;
 }
 extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {

@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <vector>
 #include <cstdlib>
 
 namespace {
@@ -501,9 +502,11 @@ __device__ inline int k4_literal(const K4& s, const Km2Problem& P) {
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ probs, int flags, int lds_bytes) {
-  const Km2Problem P = probs[blockIdx.x];
+__global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ probs, int flags, int lds_bytes, unsigned long long* __restrict__ lstat,
+                                            const int* __restrict__ order) {
+  const Km2Problem P = probs[order ? order[blockIdx.x] : (int)blockIdx.x];
   if (P.n <= 0 || (P.done && *P.done)) return;
+  const unsigned long long t_wall0 = lstat ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, common to all CUs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = P.n, nw = (n + 31) / 32, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   K4 s;
@@ -714,6 +717,14 @@ __global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ pro
     bad = s.sh[SH_BAD];
   }
   for (int i = tid; i < n; i += K4_T) P.match_out[i] = s.match[i] == K4_NONE ? -1 : (int)s.match[i];
+  if (tid == 0 && lstat) {  // launch record: first start, last end, sum and maximum of the solve times, solves
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), dt = t1 - t_wall0;
+    atomicMax(&lstat[0], (1ull << 62) - t_wall0);
+    atomicMax(&lstat[1], t1);
+    atomicAdd(&lstat[2], dt);
+    atomicMax(&lstat[3], dt);
+    atomicAdd(&lstat[4], 1ull);
+  }
   if (tid == 0) {
     if (bad && P.status) *P.status = bad;
     if (P.steps) {
@@ -749,17 +760,99 @@ static size_t k4_launch_lds(int n) {
 
 bool gh_km4_fits(int n) { return n <= 65534 && gh_km4_lds_bytes(n) <= 160 * 1024 - 256; }
 
-int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max) {
-  const size_t lds = std::max(gh_km4_lds_bytes(n_max), k4_launch_lds(n_max));
+static int k4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, size_t lds, const int* d_order) {
   const size_t want = 160 * 1024;
   // per device and thread safe: the attribute is cheap to set, so it is simply set before every launch
   GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
   GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
   const int kflags = getenv("GHICP_KM_FORCE_HAZARD") ? 4 : 0;  // test hook: sends one phase through the hazard fallback
+  unsigned long long* lstat = nullptr;
+  if (ctx->kt_on && ctx->km_launches < ghicp_ctx::KM_LSTAT_MAX) {
+    GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * 5, &lstat));
+    lstat += ctx->km_launches * 5;
+    int per_cu = 0;
+    GH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_km4<false>), K4_T, lds));
+    ctx->km_slots.push_back(per_cu * ctx->num_cu);
+    ctx->km_launches++;
+  }
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
-  if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL((k_km4<true>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds);
-  else hipLaunchKernelGGL((k_km4<false>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds);
+  if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL((k_km4<true>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds, lstat, d_order);
+  else hipLaunchKernelGGL((k_km4<false>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds, lstat, d_order);
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());
+  return GHICP_OK;
+}
+
+int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max) {
+  return k4_launch(ctx, d_probs, nprob, std::max(gh_km4_lds_bytes(n_max), k4_launch_lds(n_max)), nullptr);
+}
+
+int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan) {
+  *plan = Km4Plan();
+  std::vector<std::pair<int, int>> key((size_t)nprob);  // (problems per CU, n) per problem
+  for (int i = 0; i < nprob; i++) {
+    const int n = std::max(1, h_n[i]);
+    if (!gh_km4_fits(n)) return ctx->fail(GHICP_ERR_INTERNAL, "gh_km4_plan: n = %d does not fit", n);
+    key[i] = {(int)std::min<size_t>(8, (160 * 1024) / gh_km4_lds_bytes(n)), n};
+  }
+  std::vector<int> order((size_t)nprob);
+  for (int i = 0; i < nprob; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {  // fewest per CU (largest problems) first; within a class largest first
+    if (key[a].first != key[b].first) return key[a].first < key[b].first;
+    return key[a].second > key[b].second;
+  });
+  int nc = 0;
+  for (int i = 0; i < nprob;) {
+    int j = i;
+    while (j < nprob && key[order[j]].first == key[order[i]].first) j++;
+    if (nc == 8) { plan->count[7] += nprob - i; break; }  // cannot happen: at most 8 occupancy classes
+    plan->begin[nc] = i; plan->count[nc] = j - i;
+    const int nmax = key[order[i]].second;
+    plan->lds[nc] = std::max(gh_km4_lds_bytes(nmax), k4_launch_lds(nmax));
+    nc++;
+    i = j;
+  }
+  plan->nclass = nc;
+  GH_TRY(ctx->reserve(B_KM_ORDER, (size_t)nprob + 1, &plan->d_order));
+  GH_HIP(hipMemcpyAsync(plan->d_order, order.data(), (size_t)nprob * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  GH_HIP(hipStreamSynchronize(ctx->stream));  // `order` is a local
+  return GHICP_OK;
+}
+
+int gh_km4_launch_plan(ghicp_ctx* ctx, const Km2Problem* d_probs, const Km4Plan& plan) {
+  for (int c = 0; c < plan.nclass; c++)
+    if (plan.count[c] > 0) GH_TRY(k4_launch(ctx, d_probs, plan.count[c], plan.lds[c], plan.d_order + plan.begin[c]));
+  return GHICP_OK;
+}
+
+// Aggregates the launch records written while kernel timing was on (ghicp_ctx_kernel_timing):
+//   out[0] launches, [1] solves, [2] mean solve ms, [3] mean over launches of the LONGEST solve (ms), [4] mean launch span ms
+//   (first block start -> last block end), [5] solve slots (resident workgroups on the chip), [6] idle-slot fraction =
+//   1 - sum(solve time) / sum(min(slots, solves) x span), [7] max over launches of longest/mean solve.
+extern "C" int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8) {
+  GH_ENTER(ctx);
+  GH_ARG(out8 != nullptr);
+  for (int i = 0; i < 8; i++) out8[i] = 0.0;
+  const long long nl = ctx->km_launches;
+  if (nl <= 0 || !ctx->buf[B_KM_LSTAT].p) return GHICP_OK;
+  GH_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<unsigned long long> h((size_t)nl * 5);
+  GH_HIP(hipMemcpy(h.data(), ctx->buf[B_KM_LSTAT].p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  const double tick_ms = 1e3 / 100e6;
+  double solves = 0, sum_dt = 0, sum_max = 0, sum_span = 0, cap = 0, worst = 0, slots = 0;
+  long long used = 0;
+  for (long long l = 0; l < nl; l++) {
+    const unsigned long long* r = &h[(size_t)l * 5];
+    if (r[4] == 0) continue;
+    const double start = (double)((1ull << 62) - r[0]), span = (double)r[1] - start;
+    used++;
+    solves += (double)r[4]; sum_dt += (double)r[2]; sum_max += (double)r[3]; sum_span += span;
+    slots = (double)ctx->km_slots[(size_t)l];
+    cap += std::min(slots, (double)r[4]) * span;
+    worst = std::max(worst, (double)r[3] / ((double)r[2] / (double)r[4]));
+  }
+  if (used == 0) return GHICP_OK;
+  out8[0] = (double)used; out8[1] = solves; out8[2] = sum_dt / solves * tick_ms; out8[3] = sum_max / (double)used * tick_ms;
+  out8[4] = sum_span / (double)used * tick_ms; out8[5] = slots; out8[6] = cap > 0 ? 1.0 - sum_dt / cap : 0.0; out8[7] = worst;
   return GHICP_OK;
 }

@@ -18,3 +18,14 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
 bool gh_km2_fits(int n);
 int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
 bool gh_km4_fits(int n);
+
+// A batch of problems of different sizes: problems are grouped into classes of equal LDS occupancy (problems per CU) so that one
+// large problem does not lower the occupancy of all the others, and within a class the largest problems start first.
+struct Km4Plan {
+  int nclass = 0;
+  int begin[8] = {0}, count[8] = {0};
+  size_t lds[8] = {0};
+  int* d_order = nullptr;  // device: problem indices, class after class
+};
+int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan);
+int gh_km4_launch_plan(ghicp_ctx* ctx, const Km2Problem* d_probs, const Km4Plan& plan);

@@ -638,6 +638,15 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       int max_n_sparse = 1;
       for (int b = 0; b < nb; b++)
         if (hp[b].km_rptr) { any_sparse = true; max_n_sparse = std::max(max_n_sparse, hp[b].C.n); }
+      // the Kuhn-Munkres launches of this batch: problems grouped by LDS occupancy, largest first (km4.hip)
+      Km4Plan km_plan;
+      bool use_plan = false;
+      if (any_sparse && !any_dense && gh_km4_fits(max_n_sparse) && !getenv("GHICP_KM_V2") && !getenv("GHICP_KM_NOPLAN")) {
+        std::vector<int> hn((size_t)nb);
+        bool all_sparse = true;
+        for (int b = 0; b < nb; b++) { hn[b] = hp[b].C.n; all_sparse &= (hp[b].km_rptr != nullptr) || jobs[b].ks <= 0 || jobs[b].kt <= 0; }
+        if (all_sparse) { GH_TRY(gh_km4_plan(ctx, hn.data(), nb, &km_plan)); use_plan = true; }
+      }
       while (!all_done && launched < max_iter) {
         for (int r = 0; r < poll_every && launched < max_iter; r++, launched++) {
           hipEvent_t kev = ctx->kt_begin(KT_CD_ROWMIN);
@@ -651,7 +660,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
             hipLaunchKernelGGL(k_km_scan_desc, dim3(nb), dim3(1024), 0, s, dprobs);
             hipLaunchKernelGGL((k_km_csr<FT, 1>), dim3(cdiv(max_n, 4), nb), dim3(256), 0, s, dprobs);
             ctx->kt_end(KT_KM_WEIGHTS, kw);
-            if (any_sparse) GH_TRY(gh_km2_launch(ctx, d_descs, nb, max_n_sparse));
+            if (any_sparse) GH_TRY(use_plan ? gh_km4_launch_plan(ctx, d_descs, km_plan) : gh_km2_launch(ctx, d_descs, nb, max_n_sparse));
             if (any_dense) {  // matrices too large for the LDS-resident solver: dense fallback, one pair at a time
               hipLaunchKernelGGL(k_km_weights<FT>, dim3(cdiv(max_n, 256), max_n, nb), dim3(256), 0, s, dprobs);
               for (int b = 0; b < nb; b++)

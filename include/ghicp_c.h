@@ -82,6 +82,10 @@ const char* ghicp_last_error(const ghicp_ctx* ctx);
  * ghicp_ctx_kernel_time synchronises the stream; returns total ms and launch count since enabling. */
 int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on);
 int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches);
+/* Launch records of the Kuhn-Munkres solve kernel collected while kernel timing is on: out8 = { launches, solves, mean solve ms,
+ * mean over launches of the longest solve (ms), mean launch span (ms), solve slots resident on the chip, idle-slot fraction,
+ * worst longest/mean ratio of a launch }.  (Diagnostics for the batched loop; the reference has no counterpart.) */
+int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8);
 const char* ghicp_version(void);
 void ghicp_params_default(ghicp_params* p);
 

@@ -363,3 +363,67 @@ def km4_model(w, eps=0.01, cap=3, prune=True):
     if rc != 0:
         raise RuntimeError("km4_model failed (status %d)" % rc)
     return match, stats
+
+
+# ---------------------------------------------------------------- whole pair (the per-pair half of test/ghicp_main.cpp:86-151)
+def build_native() -> str:
+    """Compiles the same restatement with -O3 -march=native for the CPU timing legs of bench.py into
+    oracle/_native/ (git-ignored; built on the machine that runs it because of -march=native).  Returns the path."""
+    out_dir = os.path.join(_HERE, "_native")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libghicp_oracle_native.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ghicp_oracle.cpp", "icp_oracle.inc", "km_model.inc", "km4_model.inc")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-shared",
+                               "-o", so, srcs[0]])
+    return so
+
+
+def use_library(path: str) -> None:
+    """Routes every wrapper of this module through another build of the same restatement (see build_native)."""
+    global _lib
+    _lib = C.CDLL(path)
+    _lib.orc_km.restype = C.c_longlong
+    _lib.orc_bbx_magnitude.restype = C.c_float
+
+
+def register_pair(S, T, voxel, r_pca, R_nms, dof, feature, corr, est_iou, pattern=None, max_iter=200):
+    """main() of the reference for one (source, target) pair: voxel filter -> curvature keypoints -> BSC / FPFH ->
+    feature distance -> GH-ICP loop.  Returns dict(Rt, iters, m_s, m_t, k_s, k_t, k_bar, m_bar, seconds{stage: s}, trace)."""
+    import time
+    sec = {}
+    t = time.perf_counter()
+    ds = {n: c[voxel_filter(c, voxel)] for n, c in (("S", S), ("T", T))}
+    sec["voxel"] = time.perf_counter() - t
+    t = time.perf_counter()
+    kp, kbar = {}, {}
+    for n in ("T", "S"):
+        kp[n], kbar[n] = keypoints(ds[n], r_pca, R_nms)
+    sec["keypoints"] = time.perf_counter() - t
+    t = time.perf_counter()
+    mbar = 0.0
+    if feature == BSC:
+        fT, _, mT = bsc(ds["T"], kp["T"], R_nms, 0, pattern)
+        fS, _, mS = bsc(ds["S"], kp["S"], R_nms, dof, pattern)
+        mbar = 0.5 * (mT + mS)
+        sec["feature"] = time.perf_counter() - t
+        t = time.perf_counter()
+        FD = fd_bsc(fS[:(4 if dof > 4 else (2 if dof > 0 else 1))], fT[0])
+    elif feature == FPFH:
+        hT = fpfh(ds["T"])[1][kp["T"]]
+        hS = fpfh(ds["S"])[1][kp["S"]]
+        sec["feature"] = time.perf_counter() - t
+        t = time.perf_counter()
+        FD = fd_fpfh(hS, hT)
+    else:
+        sec["feature"] = 0.0
+        FD = None
+    sec["fd"] = time.perf_counter() - t
+    t = time.perf_counter()
+    P = default_params(feature, corr, dof, est_iou, R_nms, bbx_magnitude(ds["S"]), max_iter=max_iter)
+    ro = register(P, ds["S"][kp["S"]].astype(np.float64), ds["T"][kp["T"]].astype(np.float64), FD)
+    sec["loop"] = time.perf_counter() - t
+    sec["total"] = sum(sec.values())
+    return dict(Rt=ro["Rt"], iters=ro["iters"], m_s=int(ds["S"].shape[0]), m_t=int(ds["T"].shape[0]), k_s=int(kp["S"].size), k_t=int(kp["T"].size),
+                k_bar=0.5 * (kbar["S"] + kbar["T"]), m_bar=mbar, seconds=sec, km_seconds=ro["km_seconds"],
+                cor=[tr["cor"] for tr in ro["trace"]])
