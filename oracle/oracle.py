@@ -427,3 +427,72 @@ def register_pair(S, T, voxel, r_pca, R_nms, dof, feature, corr, est_iou, patter
     return dict(Rt=ro["Rt"], iters=ro["iters"], m_s=int(ds["S"].shape[0]), m_t=int(ds["T"].shape[0]), k_s=int(kp["S"].size), k_t=int(kp["T"].size),
                 k_bar=0.5 * (kbar["S"] + kbar["T"]), m_bar=mbar, seconds=sec, km_seconds=ro["km_seconds"],
                 cor=[tr["cor"] for tr in ro["trace"]])
+
+
+# ---------------------------------------------------------------- the reference's own code (oracle/_ref/libghicp_ref.so)
+_ref2 = None
+
+
+def ref2_lib():
+    """oracle/_ref/libghicp_ref.so: the reference's stereo_binary_feature.cpp, fpfh.hpp distance and the plain-C++ members of
+    ghicp_reg.cpp compiled from where they lie (oracle/ghicp_ref_shim.cpp), or None when it was not built."""
+    global _ref2
+    if _ref2 is None:
+        p = os.path.join(_HERE, "_ref", "libghicp_ref.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/src/ghicp_reg.cpp"):
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+        if os.path.exists(p):
+            _ref2 = C.CDLL(p)
+            _ref2.ref_fpfh_distance.restype = C.c_float
+    return _ref2
+
+
+def ref_iter_step(kpS, kpT, FD, feature, corr, bbx, it, RMS, FDM, FDstd, para1, para2):
+    """calED -> calCD_* -> findcorrespondence* of the reference itself.  Returns dict(penalty, CD, SP, TP, rmse, fdm, fdstd, energy)."""
+    kpS = np.ascontiguousarray(kpS, np.float64)
+    kpT = np.ascontiguousarray(kpT, np.float64)
+    ks, kt = kpS.shape[0], kpT.shape[0]
+    fdp = None
+    if FD is not None:
+        FD = np.ascontiguousarray(FD, np.float64)
+        fdp = _p(FD, C.c_double)
+    n = max(ks, kt)
+    SP, TP = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    CD = np.zeros((ks, kt))
+    pen, rmse, fdm, fdstd, en = (C.c_double(0) for _ in range(5))
+    cor = ref2_lib().ref_iter_step(_p(kpS, C.c_double), ks, _p(kpT, C.c_double), kt, fdp, int(feature), int(corr), C.c_float(bbx), int(it),
+                                   C.c_double(RMS), C.c_double(FDM), C.c_double(FDstd), C.c_double(para1), C.c_double(para2), C.byref(pen),
+                                   _p(CD, C.c_double), _p(SP, C.c_int), _p(TP, C.c_int), C.byref(rmse), C.byref(fdm), C.byref(fdstd), C.byref(en))
+    return dict(penalty=pen.value, CD=CD, SP=SP[:cor].copy(), TP=TP[:cor].copy(), rmse=rmse.value, fdm=fdm.value, fdstd=fdstd.value, energy=en.value)
+
+
+def ref_adjustweight(est_iou, iou, ratio, step, para1, para2):
+    a, b = C.c_double(para1), C.c_double(para2)
+    ref2_lib().ref_adjustweight(C.c_float(est_iou), C.c_double(iou), C.c_float(ratio), C.c_float(step), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def ref_fd_bsc(fS, fT, dof):
+    fS = np.ascontiguousarray(fS, np.uint8)
+    fT = np.ascontiguousarray(fT, np.uint8)
+    V, ks, _ = fS.shape
+    kt = fT.shape[0]
+    FD = np.zeros((ks, kt))
+    ref2_lib().ref_fd_bsc(_p(fS, C.c_ubyte), ks, V, _p(fT, C.c_ubyte), kt, int(dof), _p(FD, C.c_double))
+    return FD
+
+
+def ref_hamming(a, b, nbits=441):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(ref2_lib().ref_hamming(_p(a, C.c_ubyte), _p(b, C.c_ubyte), int(nbits)))
+
+
+def ref_fpfh_distance(h1, h2):
+    h1, h2 = _f32(h1), _f32(h2)
+    return float(ref2_lib().ref_fpfh_distance(_p(h1, C.c_float), _p(h2, C.c_float)))
+
+
+def ref_sbf_write(path, feat):
+    feat = np.ascontiguousarray(feat, np.uint8).reshape(-1, 56)
+    ref2_lib().ref_sbf_write(str(path).encode(), _p(feat, C.c_ubyte), feat.shape[0])

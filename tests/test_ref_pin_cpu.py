@@ -1,0 +1,115 @@
+"""Pins the oracle's restatement to the REFERENCE'S OWN compiled code wherever that code does not need PCL (oracle/_ref/
+libghicp_ref.so, built by oracle/Makefile from the sources where they lie): Hamming distance and calFD_BSC, the FPFH histogram
+distance, calED / calCD_{NF,BSC,FPFH} / findcorrespondence{NN,NNR,KM} / adjustweight per iteration, and the feature dump format.
+CPU only.  Skipped when /root/reference is absent and no prebuilt oracle/_ref exists (the GPU box)."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if oracle.ref2_lib() is None:
+        pytest.skip("oracle/_ref/libghicp_ref.so not built (reference sources absent)")
+    return oracle
+
+
+def test_hamming_and_calfd_bsc(ref):
+    """stereo_binary_feature.cpp:16-104 and ghicp_reg.cpp:143-200 against orc::fd_bsc (min over the V source variants)."""
+    O = ref
+    rng = np.random.default_rng(3)
+    g = np.load(os.path.join(HERE, "golden", "frontend.npz"))
+    a, b = rng.integers(0, 256, 56, dtype=np.uint8), rng.integers(0, 256, 56, dtype=np.uint8)
+    a[55] &= 1; b[55] &= 1  # 441 bits: only bit 0 of the last byte belongs to the string
+    assert O.ref_hamming(a, b) == int(np.unpackbits(a ^ b).sum()) == int(O.fd_bsc(a[None, None], b[None])[0, 0])
+    assert O.ref_hamming(a, a) == 0
+    for dof, V in ((6, 4), (4, 2)):
+        fS = rng.integers(0, 256, (4, 23, 56), dtype=np.uint8); fS[..., 55] &= 1
+        fT = rng.integers(0, 256, (17, 56), dtype=np.uint8); fT[..., 55] &= 1
+        np.testing.assert_array_equal(O.ref_fd_bsc(fS, fT, dof), O.fd_bsc(fS[:V], fT))
+        fS = g["feat"]  # golden descriptors (variants 1..3 carry the Q3 layout)
+        np.testing.assert_array_equal(O.ref_fd_bsc(fS, fS[0][:40], dof), O.fd_bsc(fS[:V], fS[0][:40]))
+
+
+def test_fpfh_distance(ref):
+    """fpfh.hpp:135-165 (|Pearson r| in f32, NaN for a constant histogram) against orc::fpfh_distance."""
+    O = ref
+    rng = np.random.default_rng(5)
+    g = np.load(os.path.join(HERE, "golden", "frontend.npz"))
+    H = np.concatenate([g["fpfh"][:40], rng.uniform(0, 100, (10, 33)).astype(np.float32), np.full((1, 33), 3.0, np.float32)])
+    FD = O.fd_fpfh(H, H)
+    for i in range(0, H.shape[0], 3):
+        for j in range(H.shape[0]):
+            r = O.ref_fpfh_distance(H[i], H[j])
+            assert (np.isnan(r) and np.isnan(FD[i, j])) or np.float32(r) == np.float32(FD[i, j]), (i, j, r, FD[i, j])
+
+
+def _apply(kp, Rt):
+    """the keypoint update of ghicp_reg.cpp:891-898 in the oracle's operation order"""
+    x, y, z = kp[:, 0].copy(), kp[:, 1].copy(), kp[:, 2].copy()
+    out = np.empty_like(kp)
+    for r in range(3):
+        out[:, r] = ((Rt[r, 0] * x + Rt[r, 1] * y) + Rt[r, 2] * z) + Rt[r, 3]
+    return out
+
+
+@pytest.mark.parametrize("feature", ["NONE", "BSC", "FPFH"])
+@pytest.mark.parametrize("corr", ["NN", "NNR", "KM"])
+def test_iteration_members(ref, feature, corr, tmp_path, monkeypatch):
+    """Every iteration of an oracle run is replayed through the reference's own calED / calCD_* / findcorrespondence* (and
+    adjustweight): penalty, correspondences, RMSE, FDM, FDstd and the adjusted weights must be IDENTICAL (f64 bit patterns)."""
+    O = ref
+    monkeypatch.chdir(tmp_path)  # findcorrespondenceKM -> Km::output writes Corres.txt into the cwd
+    rng = np.random.default_rng(11 + 7 * len(feature) + len(corr))
+    ks, kt = 46, 41
+    kpT = rng.normal(size=(kt, 3)) * np.array([10.0, 6.0, 2.0])
+    R = np.array([[0.98, -0.17, 0.03], [0.17, 0.98, 0.02], [-0.03, -0.01, 1.0]])
+    perm = rng.permutation(kt)[:min(ks, kt)]
+    kpS = (kpT[perm] - np.array([0.8, -0.5, 0.2])) @ R
+    kpS = np.concatenate([kpS, rng.normal(size=(ks - kpS.shape[0], 3)) * 8.0]) + rng.normal(size=(ks, 3)) * 0.01
+    bbx = 400.0
+    FD = None
+    if feature == "BSC":  # Hamming distances: true pairs close, the rest far
+        FD = rng.integers(150, 260, (ks, kt)).astype(np.float64)
+        FD[np.arange(perm.size), perm] = rng.integers(15, 60, perm.size)
+    elif feature == "FPFH":  # |correlation| in (0, 1], f32 values
+        FD = rng.uniform(0.05, 0.5, (ks, kt)).astype(np.float32).astype(np.float64)
+        FD[np.arange(perm.size), perm] = rng.uniform(0.8, 1.0, perm.size).astype(np.float32)
+    f, c = getattr(O, feature), getattr(O, corr)
+    P = O.default_params(f, c, 6, 0.6, 1.5, bbx, max_iter=8)
+    ro = O.register(P, kpS, kpT, FD, want_matchlist=True)
+    assert ro["iters"] >= 2, ro["iters"]
+    kp = kpS.copy()
+    RMS, FDM, FDstd, p1, p2 = 99999.0, 0.0, 0.0, P.para1, P.para2
+    for it in range(ro["iters"]):
+        tr = ro["trace"][it]
+        rr = O.ref_iter_step(kp, kpT, FD, f, c, bbx, it, RMS, FDM, FDstd, p1, p2)
+        assert rr["penalty"] == tr["penalty"], (it, rr["penalty"], tr["penalty"])
+        ml = ro["matchlist"][it]
+        assert len(rr["SP"]) == tr["cor"] == int((ml >= 0).sum())
+        assert {int(s): int(t) for s, t in zip(rr["SP"], rr["TP"])} == {int(i): int(ml[i]) for i in np.flatnonzero(ml >= 0)}
+        if tr["cor"] > 0:
+            assert rr["rmse"] == tr["rmse"]
+            if FD is not None:
+                assert rr["fdm"] == tr["fdm"] and rr["fdstd"] == tr["fdstd"]
+        if corr == "KM":
+            assert rr["energy"] == tr["energy"]
+        a1, a2 = O.ref_adjustweight(P.est_iou, tr["iou"], P.adjust_ratio, P.adjust_step, p1, p2)
+        assert (a1, a2) == (tr["para1"], tr["para2"])
+        RMS, FDM, FDstd, p1, p2 = tr["rmse"], tr["fdm"], tr["fdstd"], tr["para1"], tr["para2"]
+        kp = _apply(kp, tr["Rt"])
+
+
+def test_feature_dump_format(ref, api, tmp_path):
+    """stereo_binary_feature.cpp:107-124 written by the reference == ghicp_sbf_write of the product (host code, no GPU), and
+    the product reads the reference's file back."""
+    O = ref
+    g = np.load(os.path.join(HERE, "golden", "frontend.npz"))
+    feat = g["feat"][0]
+    O.ref_sbf_write(tmp_path / "ref.sbf", feat)
+    api.sbf_write(tmp_path / "ours.sbf", feat)
+    assert (tmp_path / "ref.sbf").read_bytes() == (tmp_path / "ours.sbf").read_bytes()
+    np.testing.assert_array_equal(api.sbf_read(tmp_path / "ref.sbf"), feat)
