@@ -54,12 +54,12 @@ template <typename PointT> class BSCEncoder : public StereoBinaryFeature {
       if (v < nvar)
         for (int64_t k = 0; k < K; k++) {
           StereoBinaryFeature f(441);
-          std::memcpy(f.feature_.data(), &feat[((size_t)v * K + k) * 56], 56);
+          std::memcpy(f.feature_, &feat[((size_t)v * K + k) * 56], 56);
           f.keypointIndex_ = (size_t)k;
           const float sx = (v == 1 || v == 3) ? -1.f : 1.f, sy = (v == 1 || v == 2) ? -1.f : 1.f, sz = (v >= 2) ? -1.f : 1.f;  // bfe:786-824
           for (int d = 0; d < 3; d++) {
-            f.localSystem_.xAxis[d] = sx * lcs[(size_t)k * 12 + d]; f.localSystem_.yAxis[d] = sy * lcs[(size_t)k * 12 + 3 + d];
-            f.localSystem_.zAxis[d] = sz * lcs[(size_t)k * 12 + 6 + d]; f.localSystem_.origin[d] = lcs[(size_t)k * 12 + 9 + d];
+            f.localSystem_.xAxis(d) = sx * lcs[(size_t)k * 12 + d]; f.localSystem_.yAxis(d) = sy * lcs[(size_t)k * 12 + 3 + d];
+            f.localSystem_.zAxis(d) = sz * lcs[(size_t)k * 12 + 6 + d]; f.localSystem_.origin(d) = lcs[(size_t)k * 12 + 9 + d];
           }
           col[(size_t)k] = f;
         }

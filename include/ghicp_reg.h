@@ -3,6 +3,7 @@
 // the GPU through ghicp_fd_bsc / ghicp_register.  No PCLVisualizer is created (ghicp_reg.cpp:28).
 #ifndef GHICP_DROPIN_GHICP_REG_H_
 #define GHICP_DROPIN_GHICP_REG_H_
+#include <cstring>
 #include <vector>
 
 #include "km.h"
@@ -10,7 +11,8 @@
 #include "utility.h"
 
 namespace ghicp {
-struct Energyfunction {  // ghicp_reg.h:15-42; the ED/FD/CD matrices are never materialised on the GPU path
+struct Energyfunction {  // ghicp_reg.h:15-42
+  std::vector<std::vector<double>> ED, FD, CD;  // declared as in the reference; the GPU path never materialises them (init() leaves them empty)
   int weight_changing_rate;
   double penalty, para1_penalty, para2_penalty, penalty_initial;
   int min_cor;
@@ -29,10 +31,10 @@ struct Keypoints {  // ghicp_reg.h:44-72
   int kps_num = 0, kpt_num = 0;
   Eigen::MatrixX3d kpSXYZ, kpTXYZ;
   doubleVectorSBF bscS, bscT;
-  std::vector<float> fpfhS, fpfhT;  // k x 33 histograms (pcl::FPFHSignature33 rows)
+  fpfhFeaturePtr fpfhS, fpfhT;
   void setCoordinate(Eigen::MatrixX3d& kps, Eigen::MatrixX3d& kpt) { kpSXYZ = kps; kpTXYZ = kpt; kps_num = (int)kpSXYZ.rows(); kpt_num = (int)kpTXYZ.rows(); }
   void setBSCfeature(const doubleVectorSBF& s, const doubleVectorSBF& t) { bscS = s; bscT = t; }
-  void setFPFHfeature(const std::vector<float>& s, const std::vector<float>& t) { fpfhS = s; fpfhT = t; }
+  void setFPFHfeature(const fpfhFeaturePtr& fpfh_S, const fpfhFeaturePtr& fpfh_T) { fpfhS = fpfh_S; fpfhT = fpfh_T; }
 };
 
 class GHRegistration {
@@ -64,22 +66,29 @@ class GHRegistration {
     if (Ft_ == BSC) {  // calFD_BSC :143-200
       const int V = P.dof == 6 ? 4 : 2;
       std::vector<uint8_t> fS((size_t)V * ks * 56), fT((size_t)kt * 56);
-      for (int v = 0; v < V; v++) for (int64_t i = 0; i < ks; i++) std::memcpy(&fS[((size_t)v * ks + i) * 56], KP.bscS[v][i].feature_.data(), 56);
-      for (int64_t j = 0; j < kt; j++) std::memcpy(&fT[(size_t)j * 56], KP.bscT[0][j].feature_.data(), 56);
+      for (int v = 0; v < V; v++) for (int64_t i = 0; i < ks; i++) std::memcpy(&fS[((size_t)v * ks + i) * 56], KP.bscS[v][i].feature_, 56);
+      for (int64_t j = 0; j < kt; j++) std::memcpy(&fT[(size_t)j * 56], KP.bscT[0][j].feature_, 56);
       fd16.resize((size_t)ks * kt);
       detail::check(ghicp_fd_bsc(c, fS.data(), ks, V, fT.data(), kt, fd16.data()));
       FD = fd16.data();
     } else if (Ft_ == FPFH) {  // calFD_FPFH :202-214
+      std::vector<float> hS((size_t)ks * 33), hT((size_t)kt * 33);  // pcl::FPFHSignature33 rows
+      for (int64_t i = 0; i < ks; i++) std::memcpy(&hS[(size_t)i * 33], KP.fpfhS->points[(size_t)i].histogram, 33 * sizeof(float));
+      for (int64_t j = 0; j < kt; j++) std::memcpy(&hT[(size_t)j * 33], KP.fpfhT->points[(size_t)j].histogram, 33 * sizeof(float));
       fd32.resize((size_t)ks * kt);
-      detail::check(ghicp_fd_fpfh(c, KP.fpfhS.data(), ks, KP.fpfhT.data(), kt, fd32.data()));
+      detail::check(ghicp_fd_fpfh(c, hS.data(), ks, hT.data(), kt, fd32.data()));
       FD = fd32.data();
     }
     std::vector<ghicp_iter> trace((size_t)P.max_iter);
     std::vector<int32_t> ml((size_t)P.max_iter * (ks > 0 ? ks : 1));
     int32_t n_iter = 0;
     double Rt[16];
-    detail::check(ghicp_register(c, &P, KP.kpSXYZ.d.data(), ks, KP.kpTXYZ.d.data(), kt, FD, Rt, trace.data(), &n_iter, ml.data()));
-    for (int i = 0; i < 16; i++) Rt_tillnow.m[i] = Rt[i];
+    // Eigen::MatrixX3d is column-major: the C ABI takes k x 3 row-major copies (the public interface only: operator())
+    std::vector<double> kS((size_t)ks * 3), kT((size_t)kt * 3);
+    for (int64_t i = 0; i < ks; i++) for (int d = 0; d < 3; d++) kS[(size_t)i * 3 + d] = KP.kpSXYZ(i, d);
+    for (int64_t j = 0; j < kt; j++) for (int d = 0; d < 3; d++) kT[(size_t)j * 3 + d] = KP.kpTXYZ(j, d);
+    detail::check(ghicp_register(c, &P, kS.data(), ks, kT.data(), kt, FD, Rt, trace.data(), &n_iter, ml.data()));
+    for (int r = 0; r < 4; r++) for (int q = 0; q < 4; q++) Rt_tillnow(r, q) = Rt[r * 4 + q];
     Rt_final = Rt_tillnow;
     matchlist.assign((size_t)ks, std::vector<int>((size_t)n_iter));
     for (int it = 0; it < n_iter; it++) {

@@ -47,7 +47,6 @@ class Km {
   }
   bool findpath(int) { return false; }  // internal to the GPU solver
   double penalty, precision, recall;
-  const std::vector<int>& match() const { return gra.match; }
 
  private:
   Graph gra;

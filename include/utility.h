@@ -10,6 +10,10 @@
 
 typedef pcl::PointCloud<pcl::PointXYZI>::Ptr pcXYZIPtr;
 typedef pcl::PointCloud<pcl::PointXYZI> pcXYZI;
+typedef pcl::PointCloud<pcl::PointXYZ>::Ptr pcXYZPtr;
+typedef pcl::PointCloud<pcl::PointXYZ> pcXYZ;
+typedef pcl::PointCloud<pcl::FPFHSignature33>::Ptr fpfhFeaturePtr;  // utility.h:45-46
+typedef pcl::PointCloud<pcl::FPFHSignature33> fpfhFeature;
 
 namespace ghicp {
 enum FeatureType { BSC, RoPS, FPFH, None };      // utility.h:51-57 (== GHICP_FEATURE_*)

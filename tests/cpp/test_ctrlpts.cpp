@@ -28,11 +28,11 @@ int main(int argc, char** argv) {
   Eigen::Matrix4d T;
   const bool okl = reg.LLS_4DOF(A, B, T, cp, theta0);
   printf("LLS %d", okl);
-  for (int i = 0; i < 16; i++) printf(" %.17g", T.m[i]);
+  for (int i = 0; i < 16; i++) printf(" %.17g", T(i / 4, i % 4));
   printf(" RMSE %.17g\n", reg.last_check_rmse);
   const bool oks = reg.SVD_6DOF(A, B, T, cp);
   printf("SVD %d", oks);
-  for (int i = 0; i < 16; i++) printf(" %.17g", T.m[i]);
+  for (int i = 0; i < 16; i++) printf(" %.17g", T(i / 4, i % 4));
   printf(" RMSE %.17g\n", reg.last_check_rmse);
   std::vector<double> tmp;
   printf("FEW %d %d %d %d\n", reg.CSTRAN_4DOF(A, B, tmp, 2), reg.CSTRAN_7DOF(A, B, tmp, 3), reg.LLS_4DOF(A, B, T, 1, 0.0), reg.SVD_6DOF(A, B, T, 1));

@@ -38,7 +38,9 @@ int main(int argc, char** argv) {
     g.GTable = {{-5, -2, -100}, {-4, -2, -6}, {-100, -1, -7}};
     Km km(g, 0.01, 1000.0);
     km.kmsolve();
-    printf("KMKAT %d %d %d energy %g\n", km.match()[0], km.match()[1], km.match()[2], km.Calenergy());
+    std::vector<int> SP, TP, SPo, TPo;  // Km::output (km.cpp:144-233): every edge differs from -penalty, so TP = 0, 1, 2
+    km.output(SP, TP, SPo, TPo);
+    printf("KMKAT %d %d %d energy %g\n", SP[0], SP[1], SP[2], km.Calenergy());
   }
   pcl::PointCloud<Point_T>::Ptr T = load(argv[1]), S = load(argv[2]);
   const char corr = argv[3][0];
@@ -67,23 +69,23 @@ int main(int argc, char** argv) {
   reg.ghicp_reg(Rt);
   printf("KP %zu %zu ITER %d\n", kS->indices.size(), kT->indices.size(), reg.iterations);
   printf("RT");
-  for (int i = 0; i < 16; i++) printf(" %.17g", Rt.m[i]);
+  for (int i = 0; i < 16; i++) printf(" %.17g", Rt(i / 4, i % 4));
   printf("\n");
   // fine registration after GH-ICP (CRegistration, common_reg.h): coarse-aligned source -> trimmed point-to-point ICP
   {
     CRegistration<Point_T> creg;
     Eigen::Matrix4f Rf, Ticp, Tinv;
-    for (int i = 0; i < 16; i++) Rf.m[i] = (float)Rt.m[i];
+    for (int i = 0; i < 16; i++) Rf(i / 4, i % 4) = (float)Rt(i / 4, i % 4);
     pcl::PointCloud<Point_T>::Ptr S1(new pcl::PointCloud<Point_T>()), S2(new pcl::PointCloud<Point_T>());
     creg.transformcloud(S, S1, Rf);
     printf("OVERLAP %.9g\n", creg.calOverlap(S1, T, 0.3f));
     const bool ok = creg.icp_reg(S1, T, S2, Ticp, 20, false, true, 0.3f, 0.1f);
     creg.invTransform(Ticp, Tinv);
     printf("ICP %d %d %d %zu", ok ? 1 : 0, creg.last_stats.iterations, creg.last_stats.reason, S2->points.size());
-    for (int i = 0; i < 16; i++) printf(" %.9g", Ticp.m[i]);
+    for (int i = 0; i < 16; i++) printf(" %.9g", Ticp(i / 4, i % 4));
     printf("\n");
     printf("INV");
-    for (int i = 0; i < 16; i++) printf(" %.9g", Tinv.m[i]);
+    for (int i = 0; i < 16; i++) printf(" %.9g", Tinv(i / 4, i % 4));
     printf("\n");
     printf("S1 %.9g %.9g %.9g\n", S1->points[7].x, S1->points[7].y, S1->points[7].z);
   }

@@ -18,11 +18,14 @@ def _dump(path, pts):
         f.write(np.ascontiguousarray(pts, np.float32).tobytes())
 
 
-@pytest.mark.parametrize("corr", ["N", "K"])
-def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr):
+@pytest.mark.parametrize("corr,types", [("N", "shim"), ("K", "shim"), ("K", "pcl-eigen-interface")])
+def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr, types):
+    """`types`: the repo's stand-in PCL / Eigen types, or -DGHICP_WITH_PCL against interface-only fakes of the real libraries
+    (column-major Eigen, 16-byte PointXYZI): the same caller code, the same results."""
     exe = tmp_path / "test_dropin"
     libdir = os.path.join(ROOT, "gh-icp_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
+    extra = [] if types == "shim" else ["-DGHICP_WITH_PCL", "-I", os.path.join(ROOT, "oracle", "ref_stubs")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include")] + extra + [os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
                            "-L", libdir, "-lghicp_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
     p = synth.tls_pair(100_000, pair_id=5)
     dsT = p.target[oracle.voxel_filter(p.target, 0.1)]

@@ -333,20 +333,24 @@ def test_fpfh_restatement_invariants(oracle, synth):
     assert (FD <= 1.0 + 1e-5).all()
 
 
-def test_dropin_headers_compile_and_link_without_a_gpu(tmp_path):
-    """Every drop-in header of include/ (the reference's class names over the C ABI) must compile as C++17 with nothing but
-    the standard library, and the drop-in programs must link against the built library (they only RUN on a GPU box)."""
+@pytest.mark.parametrize("types", ["shim", "pcl-eigen-interface"])
+def test_dropin_headers_compile_and_link_without_a_gpu(tmp_path, types):
+    """Every drop-in header of include/ (the reference's class names over the C ABI) must compile as C++17 (a) with nothing but
+    the standard library (the repo's own stand-in types) and (b) with -DGHICP_WITH_PCL against interface-only fakes of PCL and
+    Eigen that expose the real public API and nothing else (column-major Eigen storage, no .d / .m members) -- i.e. the headers
+    rely on nothing the real libraries lack.  The drop-in programs must link against the built library (they RUN on a GPU box)."""
     inc = os.path.join(ROOT, "include")
+    extra = [] if types == "shim" else ["-DGHICP_WITH_PCL", "-I", os.path.join(ROOT, "oracle", "ref_stubs")]
     hdrs = sorted(f for f in os.listdir(inc) if f.endswith((".h", ".hpp")) and f != "ghicp_c.h")
     assert {"ghicp_reg.h", "km.h", "keypoint_detect.hpp", "binary_feature_extraction.hpp", "common_reg.h", "dataio.hpp", "utility.h",
             "stereo_binary_feature.h"} <= set(hdrs)
     for h in hdrs:  # each header on its own: no hidden include-order dependency
         src = tmp_path / ("only_%s.cpp" % h.replace(".", "_"))
         src.write_text('#include "%s"\nint main() { return 0; }\n' % h)
-        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", inc, str(src)])
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", inc] + extra + [str(src)])
     libdir = os.path.join(ROOT, "gh-icp_amd")
     for prog in ("test_dropin.cpp", "test_ctrlpts.cpp", "test_dataio.cpp"):
-        subprocess.check_call(["g++", "-std=c++17", "-O0", "-I", inc, os.path.join(ROOT, "tests", "cpp", prog), "-L", libdir, "-lghicp_hip",
+        subprocess.check_call(["g++", "-std=c++17", "-O0", "-I", inc] + extra + [os.path.join(ROOT, "tests", "cpp", prog), "-L", libdir, "-lghicp_hip",
                                "-Wl,-rpath," + libdir, "-o", str(tmp_path / prog[:-4])])
     subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-x", "c", os.path.join(inc, "ghicp_c.h")])  # the ABI header is plain C
 
