@@ -120,8 +120,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic scenes per rank, cycled inside the batch (0 = the config's default)")
     ap.add_argument("--fe-streams", type=int, default=16, help="front-end worker contexts/streams")
     ap.add_argument("--loop-groups", type=int, default=3, help="the step's pairs are registered by this many concurrent batched loops (own context and stream each)")
-    ap.add_argument("--pipeline", type=int, default=0, help="1: no barrier between the steps of a run, a group's loop starts as soon as its own front ends are done "
-                    "(measured SLOWER: front-end kernels queue behind Kuhn-Munkres workgroups that hold the CUs' LDS, profiles/r02_schedules.txt)")
+    ap.add_argument("--pipeline", type=int, default=2, help="0: barrier between front ends and loops and between steps; 1: no barriers at all (measured slower: "
+                    "front-end kernels queue behind Kuhn-Munkres workgroups that hold the CUs' LDS); 2: the front ends of step k+1 start when step k is down "
+                    "to its slowly converging pairs (ghicp_ctx_loop_progress), so the long tail of a step overlaps the next step's work")
+    ap.add_argument("--tail-fraction", type=float, default=0.2, help="--pipeline 2: a group is in its tail when this fraction of its pairs is still iterating")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU (oracle) legs and the parity check")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(distinct, host CPUs))")
     args = ap.parse_args()
@@ -181,12 +183,13 @@ def main():
     nb = len(mine)  # pairs this rank registers per step
     nstream = max(1, min(args.fe_streams, max(1, nb)))
     G = max(1, min(args.loop_groups, max(1, nb)))
-    streams = [torch.cuda.Stream() for _ in range(nstream + G)]
+    LP = 2 if args.pipeline == 2 else 1  # loop contexts per group: consecutive steps of a group overlap in --pipeline 2
+    streams = [torch.cuda.Stream() for _ in range(nstream + G * LP)]
     ctxs = [api.Context(local_rank, stream=s) for s in streams]
     fe_ctxs, loop_ctxs = ctxs[:nstream], ctxs[nstream:]
     # Schedule of a step: every front end (16 worker streams), then the G batched loops concurrently.  `--pipeline 1` removes the
     # barriers (a group's loop starts when ITS front ends are done, groups of consecutive steps overlap, two sets of cloud handles).
-    NBUF = 2
+    NBUF = 2 if args.pipeline else 1
     pool_h = [[None] * nb for _ in range(NBUF)]  # (source, target) cloud handles of this rank's pairs
     bounds = [g * nb // G for g in range(G + 1)]
     group_of = np.zeros(max(1, nb), np.int64)
@@ -206,7 +209,12 @@ def main():
         ready = [[0] * G for _ in range(K)]        # front ends finished per (step, group)
         done = [[False] * G for _ in range(K)]     # loop finished per (step, group)
         res = [[None] * G for _ in range(K)]
+        started = [[False] * G for _ in range(K)]
         err = []
+
+        def tail_reached(kk, gg):
+            a, t = loop_ctxs[gg + G * (kk % LP)].loop_progress()
+            return t > 0 and a <= args.tail_fraction * t
 
         def fe_worker(w):
             try:
@@ -218,6 +226,17 @@ def main():
                         if not args.pipeline and k >= 1:  # strict schedule: the front ends of a step start when the previous step is complete
                             with cv:
                                 cv.wait_for(lambda: all(done[k - 1]) or err)
+                        elif args.pipeline == 2 and k >= 1:
+                            # tail overlap: start when every group of the previous step is done or down to its slowly converging pairs
+                            # (while most pairs still iterate, the Kuhn-Munkres workgroups hold the CUs' LDS and front-end kernels starve)
+                            while not err:
+                                with cv:
+                                    ok = all(done[k - 1][gg] or (started[k - 1][gg] and tail_reached(k - 1, gg)) for gg in range(G))
+                                    if ok and k >= NBUF:
+                                        ok = done[k - NBUF][g]
+                                if ok:
+                                    break
+                                time.sleep(0.005)
                         elif k >= NBUF:
                             with cv:
                                 cv.wait_for(lambda: done[k - NBUF][g] or err)
@@ -238,16 +257,19 @@ def main():
                     err.append(e)
                     cv.notify_all()
 
-        def loop_worker(g):
+        def loop_worker(gp):
             try:
+                g, par = gp % G, gp // G
                 n_g = bounds[g + 1] - bounds[g]
-                for k in range(K):
+                for k in range(par, K, LP):
                     with cv:  # strict schedule: the loops start when every front end of the step is done
-                        cv.wait_for(lambda: (ready[k][g] == n_g if args.pipeline else sum(ready[k]) == nb) or err)
+                        cv.wait_for(lambda: (ready[k][g] == n_g if args.pipeline == 1 else sum(ready[k]) == nb) or err)
                     if err:
                         return
+                    with cv:
+                        started[k][g] = True
                     t = time.perf_counter()
-                    r = loop_ctxs[g].register_clouds(cfg, pool_h[k % NBUF][bounds[g]:bounds[g + 1]]) if n_g else []
+                    r = loop_ctxs[gp].register_clouds(cfg, pool_h[k % NBUF][bounds[g]:bounds[g + 1]]) if n_g else []
                     dt = time.perf_counter() - t
                     with cv:
                         thread_busy["loop"] += dt
@@ -259,7 +281,7 @@ def main():
                     err.append(e)
                     cv.notify_all()
 
-        th = [threading.Thread(target=fe_worker, args=(w,)) for w in range(nstream)] + [threading.Thread(target=loop_worker, args=(g,)) for g in range(G)]
+        th = [threading.Thread(target=fe_worker, args=(w,)) for w in range(nstream)] + [threading.Thread(target=loop_worker, args=(gp,)) for gp in range(G * LP)]
         for x in th:
             x.start()
         for k in range(K):  # the pair queue's only data exchange: ONE all-gather of the step's result records, as soon as the step is complete
@@ -338,7 +360,7 @@ def main():
     # ---- single pair on an idle GPU: latency and the true per-pair ms/iteration
     sid0 = manifest[mine[0]]
     lat, lat_loop, lat_it = [], [], 1
-    for _ in range(3):
+    for _ in range(1 if hits > 2_000_000 else 3):
         torch.cuda.synchronize()
         tl = time.perf_counter()
         st1, _ = loop_ctxs[0].register_pair(cfg, dev[sid0][0], dev[sid0][1], want_trace=False)
@@ -460,6 +482,8 @@ def main():
                      "front_end_ms_per_cloud_on_its_stream": round(1e3 * thread_busy["front_end"] / max(1, args.steps) / max(1, 2 * nb), 4),
                      "note": "thread seconds are summed over the worker threads; --pipeline %d" % args.pipeline},
         "km_launch_stats": km_stats,
+        "scenes": [{"pair_id": int(sid), "k_s": int(st.k_s), "k_t": int(st.k_t), "m_s": int(st.m_s), "m_t": int(st.m_t), "iterations": int(st.iterations),
+                    "converged": int(st.converged), "Rt": [float(v) for v in st.Rt[:]]} for sid, st in sorted(by_scene.items())][:(64 if args.config == 2 else 256)],
         "rank_wall_s": {"per_rank": [round(b, 3) for b in busy_all], "imbalance_max_over_mean": round(max(busy_all) / max(1e-9, float(np.mean(busy_all))), 4)},
         "gt_error": {"max_rot": round(max(gts), 6) if gts else None, "max_trans_m": round(max(gtt), 5) if gtt else None},
         "roofline": roofline, "cpu_baseline": cpu, "parity_check": check, "gen_seconds": round(gen_s, 1),

@@ -207,6 +207,7 @@ extern "C" int ghicp_cloud_download(const ghicp_cloud* c, float* ds_xyz, int32_t
 extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const ghicp_cloud* const* S,
                                      const ghicp_cloud* const* T, ghicp_pair_stats* stats) {
   GH_ENTER(ctx);
+  if (n_pairs > 0) { ctx->loop_total.store(n_pairs, std::memory_order_relaxed); ctx->loop_active.store(n_pairs, std::memory_order_relaxed); }  // progress: nothing done yet
   GH_ARG(cfg != nullptr && stats != nullptr && n_pairs >= 0 && n_pairs <= 65535 && (n_pairs == 0 || (S && T)));
   if (n_pairs == 0) return GHICP_OK;
   hipStream_t s = ctx->stream;

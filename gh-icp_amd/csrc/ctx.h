@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -122,6 +123,9 @@ struct ghicp_ctx {
   static constexpr int KM_LSTAT_MAX = 8192;
   long long km_launches = 0;
   std::vector<int> km_slots;
+  // progress of the batched loop that is running on this context (pairs still iterating / pairs of the batch), readable from
+  // other threads while ghicp_register_pairs / ghicp_register_clouds is in flight (ghicp_ctx_loop_progress)
+  std::atomic<long long> loop_active{0}, loop_total{0};
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;  // created by ghicp_ctx_set_cu_mask

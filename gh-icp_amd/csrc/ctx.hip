@@ -104,6 +104,12 @@ extern "C" int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on) {
   }
   return GHICP_OK;
 }
+extern "C" int ghicp_ctx_loop_progress(const ghicp_ctx* ctx, int64_t* active, int64_t* total) {  // no device work: callable from any thread
+  if (!ctx || !active || !total) return GHICP_ERR_ARG;
+  *active = ctx->loop_active.load(std::memory_order_relaxed);
+  *total = ctx->loop_total.load(std::memory_order_relaxed);
+  return GHICP_OK;
+}
 extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {
   GH_ENTER(ctx);
   GH_ARG(name != nullptr);

@@ -8,6 +8,12 @@
 
 #include <cmath>
 
+// Radix sort of the voxel / cell keys (22-30 significant bits, 0.25-10 M pairs): rocPRIM's default dispatch picks its merge sort below
+// 1 M items -- ~17 launches of ~5 us each per sort, half of all the front end's launches (profiles/r01_kernel_stats_bench_default.txt),
+// and the front end is bound by the host's launch rate.  With the limit at 4096 items the Onesweep path runs instead: one histogram
+// + scan launch and one launch per 8-bit digit place.  Both are stable, so the order (lowest input index first) is unchanged.
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096> GhSortConfig;
+
 namespace {
 
 __global__ __launch_bounds__(256) void k_cell_keys(const float* __restrict__ xyz, long long n, int stride, GridDesc g, unsigned* __restrict__ keys,
@@ -88,10 +94,10 @@ int gh_grid_build(ghicp_ctx* ctx, const float* xyz, long long n, int stride, flo
     hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, n, stride, g, keys, vals);
     size_t tb = 0;
     const int eb = bits_for(g.ncell);
-    GH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));
+    GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));
     char* tmp;
     GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
-    GH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));
+    GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));
     hipLaunchKernelGGL(k_gather_sorted, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, stride, vals2, n, pts);
   }
   hipLaunchKernelGGL(k_cell_start, dim3(cdiv((long long)g.ncell + 1, 256)), dim3(256), 0, s, keys2, (unsigned)n, g.ncell, start);
@@ -167,12 +173,12 @@ int gh_voxel_filter_dev(ghicp_ctx* ctx, const float* xyz, long long n, int strid
   const unsigned long long maxkey = (maxv[0] - 1) * v.mul_x + (maxv[1] - 1) * v.mul_y + (maxv[2] - 1);
   const int eb = bits_for(maxkey);
   size_t tb = 0, tb2 = 0;
-  GH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));
+  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));
   GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));
   char* tmp;
   GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
   hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
-  GH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, vals, vals2, (int)n, 0, eb, s));  // stable: lowest input index leads its voxel
+  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));  // stable: lowest input index leads its voxel
   ctx->kt_end(KT_VOXEL_SORT, kev);
   hipLaunchKernelGGL(k_voxel_flags, dim3(cdiv(n, 256)), dim3(256), 0, s, keys2, n, flags);
   hipLaunchKernelGGL(k_set_first, dim3(1), dim3(1), 0, s, keep);

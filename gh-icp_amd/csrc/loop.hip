@@ -628,6 +628,8 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       GH_HIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)nb * sizeof(LoopProb), hipMemcpyHostToDevice, s));
 
       // ---- iterate
+      ctx->loop_total.store(nb, std::memory_order_relaxed);
+      ctx->loop_active.store(nb, std::memory_order_relaxed);
       std::vector<int> hflags((size_t)nb * 2, 0);
       const int poll_every = 2;
       int launched = 0;
@@ -676,8 +678,11 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         GH_HIP(hipMemcpyAsync(hflags.data(), dflags, hflags.size() * sizeof(int), hipMemcpyDeviceToHost, s));
         GH_HIP(hipStreamSynchronize(s));
         all_done = true;
-        for (int b = 0; b < nb; b++) all_done &= (hflags[(size_t)b * 2 + 1] != 0);
+        long long still = 0;
+        for (int b = 0; b < nb; b++) { all_done &= (hflags[(size_t)b * 2 + 1] != 0); still += hflags[(size_t)b * 2 + 1] == 0; }
+        ctx->loop_active.store(still, std::memory_order_relaxed);
       }
+      ctx->loop_active.store(0, std::memory_order_relaxed);
       // ---- results
       for (int b = 0; b < nb; b++) GH_HIP(hipMemcpyAsync(&hst[b], hp[b].st, sizeof(LoopState), hipMemcpyDeviceToHost, s));
       GH_HIP(hipStreamSynchronize(s));

@@ -86,6 +86,10 @@ int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, in
  * mean over launches of the longest solve (ms), mean launch span (ms), solve slots resident on the chip, idle-slot fraction,
  * worst longest/mean ratio of a launch }.  (Diagnostics for the batched loop; the reference has no counterpart.) */
 int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8);
+/* Progress of the batched loop (ghicp_register_pairs / ghicp_register_clouds) currently running on this context: pairs that are still
+ * iterating and pairs of the batch.  No device work; may be called from another thread while the loop runs (a scheduler can start the
+ * next batch's front ends when only the slowly converging pairs are left). */
+int ghicp_ctx_loop_progress(const ghicp_ctx* ctx, int64_t* active, int64_t* total);
 const char* ghicp_version(void);
 void ghicp_params_default(ghicp_params* p);
 
