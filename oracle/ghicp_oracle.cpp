@@ -5,12 +5,14 @@
 //  SURVEY.md §8 names.  Only tests/, __graft_entry__.smoke() and bench.py's
 //  `cpu_baseline` leg may load this library; the product (gh-icp_amd/) never does.
 //
-//  PARITY STATUS: "parity unpinned" for every stage that goes through PCL/Eigen/FLANN
-//  (the reference ships no tests/goldens and its dependencies are not installable here,
-//  SURVEY.md §4/§8c).  Pinned pieces: Km::kmsolve/findpath/output are checked against the
-//  reference's own km.cpp compiled into oracle/_ref (see oracle/Makefile) and against the
-//  commented 3x3 known-answer vector in src/km.cpp:237-259; SBF::hammingDistance is checked
-//  against popcount.  All other stages restate upstream PCL semantics as documented below.
+//  PARITY STATUS.  Pinned bit for bit to the reference's OWN code, compiled from where it lies into oracle/_ref (oracle/Makefile,
+//  ghicp_ref_shim.cpp, km_ref_shim.cpp): Km::kmsolve / findpath / output / Calenergy (src/km.cpp), StereoBinaryFeature::hammingDistance
+//  and the dump format (src/stereo_binary_feature.cpp), compute_fpfh_distance (include/fpfh.hpp:135-165), calED, calFD_BSC, calFD_FPFH,
+//  calCD_NF/BSC/FPFH, findcorrespondenceKM/NN/NNR, adjustweight (src/ghicp_reg.cpp:114-341, 343-789) -- tests/test_ref_pin_cpu.py,
+//  test_oracle_cpu.py, test_golden.py; plus the commented 3x3 known-answer vector of src/km.cpp:237-259.
+//  "parity unpinned" for every stage that goes through PCL / Eigen / FLANN (voxel representative, radius search + pcl::PCA, the BSC
+//  encoder's Eigen calls, normals + FPFH, TransformationEstimationSVD, PCL's ICP): the reference ships no tests or goldens and its
+//  dependencies are not installable here; those stages restate upstream semantics as documented below.
 //
 //  Numerics convention (DESIGN.md "numerics contract"): values the reference STORES in f32
 //  are f32 here; where the reference accumulates in f32 in an implementation-defined order
