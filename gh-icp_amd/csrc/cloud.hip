@@ -82,7 +82,12 @@ static int cloud_fill(ghicp_ctx* ctx, ghicp_cloud* c, const float* d, long long 
     float mm[6] = {0, 0, 0, 0, 0, 0};
     if (c->m > 0) GH_TRY(gh_bbox_dev(ctx, ds, c->m, 4, mm));
     c->bbx = (float)((double)mm[3] - (double)mm[0] + (double)mm[4] - (double)mm[1] + (double)mm[5] - (double)mm[2]);
+    if (c->m > 0) {  // the grids of the keypoint detector and of the BSC encoder are built over the same cloud
+      ctx->bbox_valid = true; ctx->bbox_ptr = ds; ctx->bbox_n = c->m; ctx->bbox_stride = 4;
+      memcpy(ctx->bbox_mm, mm, sizeof(mm));
+    }
   }
+  struct BoxScope { ghicp_ctx* c; ~BoxScope() { c->bbox_valid = false; } } box_scope{ctx};
   // keypoints (main:96-100) and their coordinates as f64 (dataio.hpp:609-627)
   GH_HIP(c->kp.reserve(((size_t)c->m + 1) * sizeof(int)));
   GH_TRY(gh_keypoints_dev(ctx, ds, c->m, 4, cfg->neighborhood_radius, cfg->ratio_max, cfg->min_neighbors, cfg->reg.radius_nonmax, c->kp.as<int>(), &c->k));

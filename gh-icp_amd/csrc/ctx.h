@@ -126,6 +126,12 @@ struct ghicp_ctx {
   // progress of the batched loop that is running on this context (pairs still iterating / pairs of the batch), readable from
   // other threads while ghicp_register_pairs / ghicp_register_clouds is in flight (ghicp_ctx_loop_progress)
   std::atomic<long long> loop_active{0}, loop_total{0};
+  // bounding box of the cloud a front end is working on (set and cleared by cloud_fill; see gh_bbox_dev)
+  bool bbox_valid = false;
+  const float* bbox_ptr = nullptr;
+  long long bbox_n = 0;
+  int bbox_stride = 0;
+  float bbox_mm[6] = {0, 0, 0, 0, 0, 0};
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;  // created by ghicp_ctx_set_cu_mask

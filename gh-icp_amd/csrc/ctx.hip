@@ -209,14 +209,24 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, lon
 
 }  // namespace
 
+__global__ void k_bbox_init(int* mm) {  // enc(+FLT_MAX) x 3, enc(-FLT_MAX) x 3
+  if (threadIdx.x < 6) mm[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffff : (int)0x80800000;
+}
+
+// Bounding box of a device cloud on the host.  Small transfers go through the context's PINNED scratch: a pageable hipMemcpyAsync is
+// staged and serialised inside the runtime (the front end did 12 of them per cloud from 16 threads).  The box of the cloud a front end
+// is working on is computed once and remembered (ctx->bbox_*): the PCA grid, the BSC grid and the bbx magnitude all ask for it.
 int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float* mm_host6) {
+  if (ctx->bbox_valid && ctx->bbox_ptr == xyz && ctx->bbox_n == n && ctx->bbox_stride == stride) {
+    memcpy(mm_host6, ctx->bbox_mm, 6 * sizeof(float));
+    return GHICP_OK;
+  }
   int* d;
   GH_TRY(ctx->reserve(B_GRID_MISC, 64, &d));
-  const int init[6] = {0x7f7fffff, 0x7f7fffff, 0x7f7fffff, (int)0x80800000, (int)0x80800000, (int)0x80800000};  // enc(+FLT_MAX), enc(-FLT_MAX)
-  GH_HIP(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, ctx->stream, d);
   if (n > 0) hipLaunchKernelGGL(k_bbox, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, ctx->stream, xyz, n, stride, reinterpret_cast<float*>(d));
-  int h[6];
-  GH_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  int* h = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->pinned) + 256);
+  GH_HIP(hipMemcpyAsync(h, d, 6 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < 6; k++) {
     int i = h[k] >= 0 ? h[k] : h[k] ^ 0x7fffffff;

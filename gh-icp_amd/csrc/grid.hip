@@ -183,10 +183,10 @@ int gh_voxel_filter_dev(ghicp_ctx* ctx, const float* xyz, long long n, int strid
   hipLaunchKernelGGL(k_voxel_flags, dim3(cdiv(n, 256)), dim3(256), 0, s, keys2, n, flags);
   hipLaunchKernelGGL(k_set_first, dim3(1), dim3(1), 0, s, keep);
   GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));
-  int hc = 0;
-  GH_HIP(hipMemcpyAsync(&hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+  int* hc = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->pinned) + 320);  // pinned: see gh_bbox_dev
+  GH_HIP(hipMemcpyAsync(hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
   GH_HIP(hipStreamSynchronize(s));
-  *m_out = (long long)hc + 1;
+  *m_out = (long long)*hc + 1;
   return GHICP_OK;
 }
 

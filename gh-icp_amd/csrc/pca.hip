@@ -174,10 +174,10 @@ int gh_prune_dev(ghicp_ctx* ctx, const float* lambda, const int32_t* count, long
   char* tmp;
   GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb, iota, flags, cand, dcount, (int)m, s));
-  int hc = 0;
-  GH_HIP(hipMemcpyAsync(&hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+  int* hc = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->pinned) + 320);  // pinned: see gh_bbox_dev
+  GH_HIP(hipMemcpyAsync(hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
   GH_HIP(hipStreamSynchronize(s));
-  *c_out = hc;
+  *c_out = *hc;
   return GHICP_OK;
 }
 
