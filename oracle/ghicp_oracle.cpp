@@ -9,7 +9,9 @@
 //  ghicp_ref_shim.cpp, km_ref_shim.cpp): Km::kmsolve / findpath / output / Calenergy (src/km.cpp), StereoBinaryFeature::hammingDistance
 //  and the dump format (src/stereo_binary_feature.cpp), compute_fpfh_distance (include/fpfh.hpp:135-165), calED, calFD_BSC, calFD_FPFH,
 //  calCD_NF/BSC/FPFH, findcorrespondenceKM/NN/NNR, adjustweight (src/ghicp_reg.cpp:114-341, 343-789) -- tests/test_ref_pin_cpu.py,
-//  test_oracle_cpu.py, test_golden.py; plus the commented 3x3 known-answer vector of src/km.cpp:237-259.
+//  test_oracle_cpu.py, test_golden.py; plus the commented 3x3 known-answer vector of src/km.cpp:237-259; the BSC binarisation, flip
+//  variants and sample pattern (binary_feature_extraction.hpp:62-117, 463-565, 678-758), CFilter::voxelfilter (filter.hpp:18-88),
+//  pruneUnstablePoints and the logic of nonMaximaSuppression (keypoint_detect.hpp:119-191) through oracle/frontend_ref_shim.cpp.
 //  "parity unpinned" for every stage that goes through PCL / Eigen / FLANN (voxel representative, radius search + pcl::PCA, the BSC
 //  encoder's Eigen calls, normals + FPFH, TransformationEstimationSVD, PCL's ICP): the reference ships no tests or goldens and its
 //  dependencies are not installable here; those stages restate upstream semantics as documented below.
@@ -360,6 +362,32 @@ static void bsc_binarize(const float* weight /*>=147 (+zeros)*/, const float* de
   }
 }
 
+// The strings of one keypoint from its 147 cells: variant 0, and for dof > 0 / dof > 4 the flip variants exactly as
+// extractBinaryFeatureOfKeypoint builds them (bfe:782-828: `vector<GridVoxel> grid_k(147)` THEN ReArrangeGrid appends -> 294 cells, Q3).
+// out: 4 x 56 bytes, unused variants zero.  Pinned against the reference's own members by tests/test_ref_pin_cpu.py.
+static void bsc_strings(const float* weight147, const float* depth147, int dof, const int* pattern, uint8_t* out) {
+  std::memset(out, 0, 4 * 56);
+  bsc_binarize(weight147, depth147, 147, pattern, out);
+  const int nvar = (dof > 4) ? 4 : (dof > 0 ? 2 : 1);
+  static const int TR[4][3] = {{0, 0, 0}, {1, 2, 2}, {3, 2, 1}, {2, 1, 3}};  // bfe:795,808,817
+  for (int vv = 1; vv < nvar; vv++) {
+    float w2[294], d2v[294];
+    for (int i = 0; i < 147; i++) w2[i] = d2v[i] = 0.f;
+    for (int pl = 0; pl < 3; pl++)
+      for (int k = 0; k < 49; k++) {
+        int src;
+        switch (TR[vv][pl]) {
+          case 1: src = 48 - k; break;                      // bfe:700-708
+          case 2: src = (6 - k / 7) * 7 + k % 7; break;     // bfe:711-723
+          default: src = (k / 7) * 7 + 6 - k % 7; break;    // bfe:726-738
+        }
+        w2[147 + 49 * pl + k] = weight147[49 * pl + src];
+        d2v[147 + 49 * pl + k] = depth147[49 * pl + src];
+      }
+    bsc_binarize(w2, d2v, 294, pattern, &out[vv * 56]);
+  }
+}
+
 static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K, float R, int dof, const int* pattern,
                        uint8_t* feat, float* lcs, double* mean_nb) {
   const double r_search = std::sqrt(3.0) * (double)R;  // bfe:641
@@ -480,25 +508,10 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
       depth[i] = avg;
     }
     // ---- a8: binarise (+ flip variants with quirk Q3: [147 zero cells | re-arranged cells])
-    bsc_binarize(weight, depth, 147, pattern, &feat[((size_t)0 * K + kk) * 56]);
+    uint8_t four[4 * 56];
+    bsc_strings(weight, depth, dof, pattern, four);
     const int nvar = (dof > 4) ? 4 : (dof > 0 ? 2 : 1);
-    static const int TR[4][3] = {{0, 0, 0}, {1, 2, 2}, {3, 2, 1}, {2, 1, 3}};  // bfe:795,808,817
-    for (int vv = 1; vv < nvar; vv++) {
-      float w2[294], d2v[294];
-      for (int i = 0; i < 147; i++) w2[i] = d2v[i] = 0.f;
-      for (int pl = 0; pl < 3; pl++)
-        for (int k = 0; k < 49; k++) {
-          int src;
-          switch (TR[vv][pl]) {
-            case 1: src = 48 - k; break;                      // bfe:700-708
-            case 2: src = (6 - k / 7) * 7 + k % 7; break;     // bfe:711-723
-            default: src = (k / 7) * 7 + 6 - k % 7; break;    // bfe:726-738
-          }
-          w2[147 + 49 * pl + k] = weight[49 * pl + src];
-          d2v[147 + 49 * pl + k] = depth[49 * pl + src];
-        }
-      bsc_binarize(w2, d2v, 294, pattern, &feat[((size_t)vv * K + kk) * 56]);
-    }
+    for (int vv = 0; vv < nvar; vv++) std::memcpy(&feat[((size_t)vv * K + kk) * 56], &four[vv * 56], 56);
   }
   if (mean_nb) *mean_nb = K ? nb_sum / K : 0;
 }
@@ -786,6 +799,9 @@ int orc_keypoints(const float* xyz, int m, int stride, float radius, float ratio
 void orc_bsc(const float* xyz, int m, int stride, const int* kp, int K, float R, int dof, const int* pattern, uint8_t* feat, float* lcs,
              double* mean_nb) {
   orc::bsc_encode(xyz, m, stride, kp, K, R, dof, pattern, feat, lcs, mean_nb);
+}
+void orc_bsc_strings(const float* weight147, const float* depth147, int dof, const int* pattern, uint8_t* out4x56) {
+  orc::bsc_strings(weight147, depth147, dof, pattern, out4x56);
 }
 void orc_bsc_binarize(const float* weight, const float* depth, int ncell, const int* pattern, uint8_t* out56) {
   std::memset(out56, 0, 56);

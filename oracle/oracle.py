@@ -496,3 +496,68 @@ def ref_fpfh_distance(h1, h2):
 def ref_sbf_write(path, feat):
     feat = np.ascontiguousarray(feat, np.uint8).reshape(-1, 56)
     ref2_lib().ref_sbf_write(str(path).encode(), _p(feat, C.c_ubyte), feat.shape[0])
+
+
+_ref3 = None
+
+
+def ref3_lib():
+    """oracle/_ref/libfrontend_ref.so: plain-C++ members of the reference's front end (BSC binarisation / re-arrangement / sample
+    pattern, CFilter::voxelfilter, pruneUnstablePoints) compiled from where they lie (oracle/frontend_ref_shim.cpp), or None."""
+    global _ref3
+    if _ref3 is None:
+        p = os.path.join(_HERE, "_ref", "libfrontend_ref.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/include/filter.hpp"):
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+        if os.path.exists(p):
+            _ref3 = C.CDLL(p)
+    return _ref3
+
+
+def bsc_strings(weight147, depth147, dof, pattern):
+    """The oracle's strings of one keypoint from its 147 cells -> (4, 56) u8 (orc::bsc_strings, the tail of the BSC encoder)."""
+    w, d = _f32(weight147), _f32(depth147)
+    pattern = np.ascontiguousarray(pattern, np.int32)
+    out = np.zeros((4, 56), np.uint8)
+    lib().orc_bsc_strings(_p(w, C.c_float), _p(d, C.c_float), int(dof), _p(pattern, C.c_int), _p(out, C.c_ubyte))
+    return out
+
+
+def ref_bsc_strings(weight147, depth147, dof, pattern):
+    w, d = _f32(weight147), _f32(depth147)
+    pattern = np.ascontiguousarray(pattern, np.int32)
+    out = np.zeros((4, 56), np.uint8)
+    ref3_lib().ref_bsc_strings(_p(w, C.c_float), _p(d, C.c_float), int(dof), _p(pattern, C.c_int), _p(out, C.c_ubyte))
+    return out
+
+
+def ref_bsc_pattern():
+    out = np.zeros(98, np.int32)
+    ref3_lib().ref_bsc_pattern(_p(out, C.c_int))
+    return out.reshape(49, 2)
+
+
+def ref_voxelfilter(xyz, voxel):
+    xyz = _f32(xyz)
+    out = np.zeros((xyz.shape[0] + 1, 3), np.float32)
+    m = ref3_lib().ref_voxelfilter(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], C.c_float(voxel), _p(out, C.c_float))
+    return out[:m].copy()
+
+
+def ref_prune(lam, cnt, ratio_max=0.65, min_n=20):
+    lam = _f32(lam)
+    cnt = np.ascontiguousarray(cnt, np.int32)
+    out = np.zeros(max(1, lam.shape[0]), np.int32)
+    k = ref3_lib().ref_prune(_p(lam, C.c_float), _p(cnt, C.c_int), lam.shape[0], C.c_float(ratio_max), int(min_n), _p(out, C.c_int))
+    return out[:k].copy()
+
+
+def ref_nms(xyz, curv, cand, R):
+    """The reference's own nonMaximaSuppression over the candidates `cand` of cloud `xyz` -> kept point ids in its output order."""
+    xyz = _f32(xyz)
+    cand = np.ascontiguousarray(cand, np.int32)
+    pts = np.ascontiguousarray(xyz[cand][:, :3], np.float32)
+    cv = np.ascontiguousarray(np.asarray(curv, np.float64)[cand])
+    out = np.zeros(max(1, cand.size), np.int32)
+    k = ref3_lib().ref_nms(_p(pts, C.c_float), _p(cv, C.c_double), _p(cand, C.c_int), cand.size, C.c_float(R), _p(out, C.c_int))
+    return out[:k].copy()

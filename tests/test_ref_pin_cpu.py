@@ -113,3 +113,102 @@ def test_feature_dump_format(ref, api, tmp_path):
     api.sbf_write(tmp_path / "ours.sbf", feat)
     assert (tmp_path / "ref.sbf").read_bytes() == (tmp_path / "ours.sbf").read_bytes()
     np.testing.assert_array_equal(api.sbf_read(tmp_path / "ref.sbf"), feat)
+
+
+@pytest.fixture(scope="module")
+def ref3(oracle):
+    if oracle.ref3_lib() is None:
+        pytest.skip("oracle/_ref/libfrontend_ref.so not built (reference sources absent)")
+    return oracle
+
+
+def test_bsc_binarisation_and_flip_variants(ref3, synth):
+    """binary_feature_extraction.hpp:463-565 (occupancy + depth / density comparison bits, Q4) and 678-758 (ReArrangeGrid, Q3: the
+    294-cell grids of the flip variants) run on the same 147 cells as the oracle's restatement: identical 441-bit strings for all
+    variants, with the glibc rand() pattern, the shipped all-zero pattern and random patterns."""
+    O = ref3
+    rng = np.random.default_rng(9)
+    pats = [synth.bsc_pattern_glibc(), synth.bsc_pattern_zero(), rng.integers(0, 49, (49, 2))]
+    for t in range(60):
+        w = np.where(rng.random(147) < 0.35, 0.0, rng.gamma(1.5, 0.4, 147)).astype(np.float32)  # empty cells and cells around the 0.1 threshold
+        w[rng.integers(0, 147, 5)] = np.float32(0.1)
+        d = (rng.uniform(0.0, 3.0, 147) * (w > 0)).astype(np.float32)
+        for dof in (0, 4, 6):
+            pat = pats[t % 3]
+            np.testing.assert_array_equal(O.ref_bsc_strings(w, d, dof, pat), O.bsc_strings(w, d, dof, pat), err_msg="t=%d dof=%d" % (t, dof))
+
+
+def test_bsc_sample_pattern_of_a_fresh_process(ref3, synth, tmp_path, monkeypatch):
+    """BSCEncoder(R, 7, build_sample_pattern = true) (bfe:62-117, contain2DPair 855-872) after srand(1) -- rand() of a fresh
+    process -- draws exactly the 49 pairs SURVEY.md Q2 lists and the bench / tests use; it writes sample_pattern.txt like the reference."""
+    monkeypatch.chdir(tmp_path)
+    pat = ref3.ref_bsc_pattern()
+    np.testing.assert_array_equal(pat, np.asarray(synth.bsc_pattern_glibc()).reshape(49, 2))
+    np.testing.assert_array_equal(np.loadtxt(tmp_path / "sample_pattern.txt", dtype=np.int32), pat)
+
+
+def test_voxelfilter_and_prune(ref3, synth):
+    """CFilter::voxelfilter (filter.hpp:28-88: Q1 phantom entries, voxel-key order) and pruneUnstablePoints
+    (keypoint_detect.hpp:132-147) of the reference itself against the restatement."""
+    O = ref3
+    rng = np.random.default_rng(21)
+    # (a) at most one point per voxel (input point 0 anchors the lattice at the origin): the kept points and their order are fully
+    # determined -> identical sequences; point 0 shares the min-corner voxel with the N phantom entries (Q1), so it leads the output
+    cells = rng.choice(np.arange(1, 40 * 40 * 10), 3000, replace=False)
+    pts = (np.stack([cells // 400, (cells // 10) % 40, cells % 10], 1) + rng.uniform(0.25, 0.75, (3000, 3))).astype(np.float32) * np.float32(0.5)
+    pts = np.concatenate([np.zeros((1, 3), np.float32), pts])
+    keep = O.voxel_filter(pts, 0.5)
+    out = O.ref_voxelfilter(pts, 0.5)
+    assert keep[0] == 0 and out.shape[0] == keep.size == 3001
+    np.testing.assert_array_equal(out, pts[keep])
+    # the same cloud without the anchor: the min corner voxel is empty, the phantom entries add ONE extra copy of input point 0 in front
+    keep = O.voxel_filter(pts[1:], 0.5)
+    out = O.ref_voxelfilter(pts[1:], 0.5)
+    assert keep[0] == 0 and out.shape[0] == keep.size
+    assert np.array_equal(out[0], pts[1]) and np.array_equal(pts[1:][keep[0]], pts[1])
+    # (b) a real scan (many points per voxel): std::sort is not stable, so only the NUMBER of voxels and the voxel sequence are
+    # defined by the reference; the restatement keeps the lowest input index of every voxel (documented deviation, SURVEY Q1)
+    scan = synth.tls_pair(60_000, pair_id=3).target
+    keep = O.voxel_filter(scan, 0.1)
+    out = O.ref_voxelfilter(scan, 0.1)
+    assert out.shape[0] == keep.size
+    mn = scan[:, :3].min(0)
+    vox = lambda p: np.floor((p[:, :3] - mn) * np.float32(1.0 / np.float32(0.1))).astype(np.int64)
+    np.testing.assert_array_equal(vox(out)[1:], vox(scan[keep])[1:])
+    # prune: float ratios, NaN (< 3 neighbours: zero eigenvalues) rejected, ptNum > min
+    lam = np.abs(rng.normal(size=(5000, 3))).astype(np.float32)
+    lam.sort(axis=1)
+    lam = lam[:, ::-1].copy()
+    lam[::17] = 0.0
+    cnt = rng.integers(0, 60, 5000).astype(np.int32)
+    np.testing.assert_array_equal(O.ref_prune(lam, cnt, 0.65, 20), O.prune(lam, cnt, 0.65, 20))
+
+
+def test_non_maxima_suppression_logic(ref3, synth):
+    """keypoint_detect.hpp:149-191 itself (std::sort by curvature, std::set of unvisited ranks, erase within the radius).  (The radius
+    search under it is the stand-in KdTreeFLANN of oracle/ref_stubs -- exact, strict d^2 < r^2 -- so what is pinned is the suppression
+    logic, not FLANN.)
+    (1) distinct curvatures: the same keypoints in the same order as the restatement.
+    (2) candidates of real scans: neighbouring points with identical neighbourhoods have EQUAL curvature (a few dozen exact ties per
+        cloud); std::sort is not stable, so which of two tied points the reference keeps is decided by libstdc++'s introsort, while the
+        restatement (and the GPU) break ties by the lower index.  Pinned here: the curvature sequence of the kept points
+        is identical, and every position where the point differs is such a tie."""
+    O = ref3
+    rng = np.random.default_rng(33)
+    pts = (rng.uniform(0, 30, (6000, 3)) * np.array([1, 1, 0.2])).astype(np.float32)
+    curv = rng.permutation(6000) / 6000.0
+    cand = np.sort(rng.choice(6000, 4000, replace=False)).astype(np.int32)
+    np.testing.assert_array_equal(O.ref_nms(pts, curv, cand, 1.5), O.nms(pts, curv, cand, 1.5))
+    ties = 0
+    for pid, hits in ((1, 120_000), (4, 80_000)):
+        scan = synth.tls_pair(hits, pair_id=pid).source
+        ds = scan[O.voxel_filter(scan, 0.1)]
+        lam, cv, cnt = O.pca(ds, 0.5)
+        cand = O.prune(lam, cnt)
+        assert cand.size > 500
+        a, b = O.ref_nms(ds, cv, cand, 1.5), O.nms(ds, cv, cand, 1.5)
+        assert a.size == b.size
+        np.testing.assert_array_equal(cv[a], cv[b])
+        ties += int((a != b).sum())
+    assert ties <= 6  # one tied pair on this data
+    assert O.ref_nms(np.zeros((3, 3), np.float32), np.zeros(3), np.zeros(0, np.int32), 1.5).size == 0
