@@ -1000,7 +1000,8 @@ int orc_register(const orc_params* P, const double* kpS_in, int ks, const double
     double after = 0;
     for (int c = 0; c < cor; c++) {
       apply(&Sp[(size_t)c * 3]);
-      for (int d = 0; d < 3; d++) after += (Sp[(size_t)c * 3 + d] - Tp[(size_t)c * 3 + d]) * (Sp[(size_t)c * 3 + d] - Tp[(size_t)c * 3 + d]);
+      const double ex = Sp[(size_t)c * 3] - Tp[(size_t)c * 3], ey = Sp[(size_t)c * 3 + 1] - Tp[(size_t)c * 3 + 1], ez = Sp[(size_t)c * 3 + 2] - Tp[(size_t)c * 3 + 2];
+      after += ex * ex + ey * ey + ez * ez;  // ghicp_reg.cpp:901: the three squares are summed first, then added (pinned by test_ref_pin_cpu.py)
     }
     after = std::sqrt(after / cor);
     rec.rmse_after = after;

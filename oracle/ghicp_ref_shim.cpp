@@ -14,12 +14,25 @@
 #include <sstream>
 #define private public  // the pinned functions are private members; the shim sets and reads the state they work on
 #define protected public
+// one extra member is DECLARED in the reference's class so that the scalar tail of transformestimation (below) can be compiled in member
+// scope: the declaration rides on the class's own `bool adjustweight();`
+#define adjustweight() adjustweight(); bool transformestimation_scalar_tail(const Eigen::Matrix3d &R, const Eigen::Vector3d &t)
 #include "ghicp_reg.h"
+#undef adjustweight
 #undef private
 #undef protected
 
 namespace ghicp {
 #include "ghicp_reg_members.inc"
+
+// The plain-C++ statements of GHRegistration::transformestimation (src/ghicp_reg.cpp:791-927) around its PCL call: min_cor / IoU
+// (795-799), translation + Euler angles in degrees with pi = 3.1415926 (870-882), RMSE after the update (890, 899-907) and the convergence
+// test (909-914), extracted by the Makefile.  R, t stand for what lines 860-864 take out of PCL's float 4x4; Spoint must already hold the
+// transformed correspondences (lines 893-898 are Eigen expressions and stay with the restatement).
+bool GHRegistration::transformestimation_scalar_tail(const Eigen::Matrix3d &R, const Eigen::Vector3d &t) {
+#include "ghicp_reg_te_tail.inc"
+  return converge;
+}
 }  // namespace ghicp
 
 namespace {
@@ -127,6 +140,37 @@ float ref_fpfh_distance(const float* h1, const float* h2) {
   std::memcpy(b, h2, sizeof(b));
   ghicp::FPFHfeature<pcl::PointXYZ> f(1.0);
   return f.compute_fpfh_distance(a, b);
+}
+
+// See transformestimation_scalar_tail above.  Rt16: the iteration's 4x4 (row-major, f32 values); SpA: correspondences AFTER the update,
+// Tp: their targets (c x 3).  Returns converge; out3 = {IoU, RMSE after, converge}.
+int ref_te_tail(const double* Rt16, const double* SpA, const double* Tp, int c, int ks, int kt, int min_cor, float conv_t, float conv_r, double* out3) {
+  Quiet q;
+  std::vector<double> a((size_t)ks * 3, 0.0), b((size_t)kt * 3, 0.0);
+  ghicp::GHRegistration reg = make(a.data(), ks, b.data(), kt, 1.f, ghicp::None, ghicp::NN, 6, 0.6f, 1.1f, 0.1f);
+  reg.EF.min_cor = min_cor;
+  reg.converge_t_ = conv_t; reg.converge_r_ = conv_r;
+  reg.Spoint.resize(c, 3); reg.Tpoint.resize(c, 3);
+  for (int i = 0; i < c; i++) for (int d = 0; d < 3; d++) { reg.Spoint(i, d) = SpA[(size_t)i * 3 + d]; reg.Tpoint(i, d) = Tp[(size_t)i * 3 + d]; }
+  Eigen::Matrix3d R;
+  Eigen::Vector3d t;
+  for (int r = 0; r < 3; r++) { for (int q2 = 0; q2 < 3; q2++) R(r, q2) = Rt16[r * 4 + q2]; t(r) = Rt16[r * 4 + 3]; }
+  const bool cv = reg.transformestimation_scalar_tail(R, t);
+  out3[0] = reg.IoU; out3[1] = reg.rmseafter.back(); out3[2] = cv ? 1.0 : 0.0;
+  return cv ? 1 : 0;
+}
+
+// CloudUtility::getCloudBound (utility.h:153-183) and the bbx magnitude of test/ghicp_main.cpp:93 (that one line is extracted by the
+// Makefile into _ref/main_bbx.inc): the scale of the Euclidean term, 0.005 * bbx (ghicp_reg.h:40).
+float ref_bbx_magnitude(const float* xyz, int n, int stride) {
+  pcl::PointCloud<pcl::PointXYZ> cloud;
+  cloud.points.resize(n);
+  for (int i = 0; i < n; i++) { cloud.points[i].x = xyz[(size_t)i * stride]; cloud.points[i].y = xyz[(size_t)i * stride + 1]; cloud.points[i].z = xyz[(size_t)i * stride + 2]; }
+  ghicp::CloudUtility<pcl::PointXYZ> cu;
+  ghicp::Bounds s_cloud_bbx;
+  cu.getCloudBound(cloud, s_cloud_bbx);
+#include "main_bbx.inc"
+  return bbx_magnitude;
 }
 
 // StereoBinaryFeature::writeFeatures / readFeatures (stereo_binary_feature.cpp:107-148): the on-disk dump format

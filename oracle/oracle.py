@@ -444,6 +444,7 @@ def ref2_lib():
         if os.path.exists(p):
             _ref2 = C.CDLL(p)
             _ref2.ref_fpfh_distance.restype = C.c_float
+            _ref2.ref_bbx_magnitude.restype = C.c_float
     return _ref2
 
 
@@ -561,3 +562,19 @@ def ref_nms(xyz, curv, cand, R):
     out = np.zeros(max(1, cand.size), np.int32)
     k = ref3_lib().ref_nms(_p(pts, C.c_float), _p(cv, C.c_double), _p(cand, C.c_int), cand.size, C.c_float(R), _p(out, C.c_int))
     return out[:k].copy()
+
+
+def ref_bbx_magnitude(xyz):
+    xyz = _f32(xyz)
+    return float(ref2_lib().ref_bbx_magnitude(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1]))
+
+
+def ref_te_tail(Rt, SpA, Tp, ks, kt, min_cor=10, conv_t=0.02, conv_r=0.02):
+    """Scalar tail of the reference's transformestimation: returns (IoU, RMSE after, converged)."""
+    Rt = np.ascontiguousarray(Rt, np.float64).reshape(16)
+    SpA = np.ascontiguousarray(SpA, np.float64).reshape(-1, 3)
+    Tp = np.ascontiguousarray(Tp, np.float64).reshape(-1, 3)
+    out = np.zeros(3)
+    ref2_lib().ref_te_tail(_p(Rt, C.c_double), _p(SpA, C.c_double), _p(Tp, C.c_double), SpA.shape[0], int(ks), int(kt), int(min_cor),
+                           C.c_float(conv_t), C.c_float(conv_r), _p(out, C.c_double))
+    return float(out[0]), float(out[1]), int(out[2])

@@ -97,10 +97,22 @@ def test_iteration_members(ref, feature, corr, tmp_path, monkeypatch):
                 assert rr["fdm"] == tr["fdm"] and rr["fdstd"] == tr["fdstd"]
         if corr == "KM":
             assert rr["energy"] == tr["energy"]
+        # the scalar tail of transformestimation (ghicp_reg.cpp:795-799, 870-914) on the iteration's 4x4 and updated correspondences
+        if tr["cor"] > 0:
+            sp = np.array([int(v) for v in rr["SP"]]); tp = np.array([int(v) for v in rr["TP"]])
+            iou, rmse_after, conv = O.ref_te_tail(tr["Rt"], _apply(kp[sp], tr["Rt"]), kpT[tp], ks, kt, P.min_cor, P.converge_t, P.converge_r)
+            assert iou == tr["iou"] and rmse_after == tr["rmse_after"] and conv == tr["converged"], (it, iou, rmse_after, conv, tr)
         a1, a2 = O.ref_adjustweight(P.est_iou, tr["iou"], P.adjust_ratio, P.adjust_step, p1, p2)
         assert (a1, a2) == (tr["para1"], tr["para2"])
         RMS, FDM, FDstd, p1, p2 = tr["rmse"], tr["fdm"], tr["fdstd"], tr["para1"], tr["para2"]
         kp = _apply(kp, tr["Rt"])
+
+
+def test_bbx_magnitude(ref, synth):
+    """CloudUtility::getCloudBound (utility.h:153-183) + test/ghicp_main.cpp:93 (f64 bounds, float result) == orc_bbx_magnitude."""
+    rng = np.random.default_rng(2)
+    for c in (synth.tls_pair(30_000, pair_id=2).source, (rng.normal(size=(1000, 3)) * [50, 3, 0.1]).astype(np.float32), np.ones((1, 3), np.float32)):
+        assert np.float32(ref.ref_bbx_magnitude(c)) == np.float32(ref.bbx_magnitude(c))
 
 
 def test_feature_dump_format(ref, api, tmp_path):
