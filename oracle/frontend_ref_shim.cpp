@@ -3,6 +3,8 @@
 // extracts their line ranges from the headers where they lie into the git-ignored oracle/_ref/ at build time, and this file gives them
 // a class to live in that declares the same data members (themselves extracted: binary_feature_extraction.hpp:37-60):
 //   include/binary_feature_extraction.hpp  62-117   BSCEncoder constructor (sample pattern from rand(), or sample_pattern.txt)
+//                                          196-373  constructCubicGrid (the Gaussian-weighted 3 x 7 x 7 cells; its 2-D radius searches go to the
+//                                                   stand-in exact KdTreeFLANN of oracle/ref_stubs: ascending distance, ties by index)
 //                                          463-565  computeFeatureProjectedGridAndCompareFeature2D (occupancy + depth / density bits)
 //                                          678-758  ReArrangeGrid / ReArrange_2D and the three re-arrangements
 //                                          839-872  getVoxelNum, getVoxelIndex, contain2DPair
@@ -34,6 +36,7 @@ class BSCEncoder : public StereoBinaryFeature {
  public:
 #include "bfe_fields.inc"
 #include "bfe_ctor.inc"
+#include "bfe_grid.inc"
 #include "bfe_binarize.inc"
 #include "bfe_rearrange.inc"
 #include "bfe_private.inc"
@@ -99,6 +102,18 @@ void ref_bsc_strings(const float* weight147, const float* depth147, int dof, con
     f = e.computeFeatureProjectedGridAndCompareFeature2D(grid_k);
     std::memcpy(out + v * 56, f.feature_, 56);
   }
+}
+
+// constructCubicGrid (bfe:196-373) on a neighbourhood already rotated into the LCS: 147 normalized weights + 147 average depths.
+void ref_cubic_grid(const float* loc, int n, float R, float* cells294) {
+  Quiet q;
+  Enc e(R, 7, false);
+  pcl::PointCloud<pcl::PointXYZ>::Ptr cloud(new pcl::PointCloud<pcl::PointXYZ>);
+  cloud->points.resize(n);
+  for (int i = 0; i < n; i++) { cloud->points[i].x = loc[(size_t)i * 3]; cloud->points[i].y = loc[(size_t)i * 3 + 1]; cloud->points[i].z = loc[(size_t)i * 3 + 2]; }
+  std::vector<Enc::GridVoxel> grid(e.gridFeatureDimension_);
+  e.constructCubicGrid(cloud, grid);
+  for (int i = 0; i < 147; i++) { cells294[i] = grid[i].normalized_point_weight; cells294[147 + i] = grid[i].average_depth; }
 }
 
 // CFilter::voxelfilter (filter.hpp:28-88).  Returns the number of kept points; out (capacity n + 1) receives their xyz.

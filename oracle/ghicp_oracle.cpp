@@ -389,7 +389,7 @@ static void bsc_strings(const float* weight147, const float* depth147, int dof, 
 }
 
 static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K, float R, int dof, const int* pattern,
-                       uint8_t* feat, float* lcs, double* mean_nb) {
+                       uint8_t* feat, float* lcs, double* mean_nb, std::vector<float>* dbg_loc = nullptr, float* dbg_cells294 = nullptr) {
   const double r_search = std::sqrt(3.0) * (double)R;  // bfe:641
   const float r2s = (float)(r_search * r_search);
   Grid g;
@@ -507,6 +507,8 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
       weight[i] = (ndens != 0.0f) ? gdens / ndens : 0.0f;
       depth[i] = avg;
     }
+    if (dbg_loc) *dbg_loc = loc;  // (tests) the neighbourhood in the LCS and its 147 cells: weight[0..147), depth[147..294)
+    if (dbg_cells294) for (int i = 0; i < 147; i++) { dbg_cells294[i] = weight[i]; dbg_cells294[147 + i] = depth[i]; }
     // ---- a8: binarise (+ flip variants with quirk Q3: [147 zero cells | re-arranged cells])
     uint8_t four[4 * 56];
     bsc_strings(weight, depth, dof, pattern, four);
@@ -799,6 +801,16 @@ int orc_keypoints(const float* xyz, int m, int stride, float radius, float ratio
 void orc_bsc(const float* xyz, int m, int stride, const int* kp, int K, float R, int dof, const int* pattern, uint8_t* feat, float* lcs,
              double* mean_nb) {
   orc::bsc_encode(xyz, m, stride, kp, K, R, dof, pattern, feat, lcs, mean_nb);
+}
+// (tests) one keypoint: its neighbourhood rotated into the LCS (n x 3, the input of constructCubicGrid) and its 147 cells
+int orc_bsc_cells(const float* xyz, int m, int stride, int point_id, float R, const int* pattern, float* loc_out, int cap, float* cells294) {
+  std::vector<float> loc;
+  uint8_t feat[4 * 56];
+  float lcs[12];
+  orc::bsc_encode(xyz, m, stride, &point_id, 1, R, 0, pattern, feat, lcs, nullptr, &loc, cells294);
+  const int n = (int)(loc.size() / 3);
+  if (n <= cap) std::memcpy(loc_out, loc.data(), loc.size() * sizeof(float));
+  return n;
 }
 void orc_bsc_strings(const float* weight147, const float* depth147, int dof, const int* pattern, uint8_t* out4x56) {
   orc::bsc_strings(weight147, depth147, dof, pattern, out4x56);

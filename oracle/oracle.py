@@ -578,3 +578,21 @@ def ref_te_tail(Rt, SpA, Tp, ks, kt, min_cor=10, conv_t=0.02, conv_r=0.02):
     ref2_lib().ref_te_tail(_p(Rt, C.c_double), _p(SpA, C.c_double), _p(Tp, C.c_double), SpA.shape[0], int(ks), int(kt), int(min_cor),
                            C.c_float(conv_t), C.c_float(conv_r), _p(out, C.c_double))
     return float(out[0]), float(out[1]), int(out[2])
+
+
+def bsc_cells(xyz, point_id, R, pattern):
+    """(tests) one keypoint of the oracle's BSC encoder: (neighbourhood in the LCS (n,3) f32, weight (147,), depth (147,))."""
+    xyz = _f32(xyz)
+    pattern = np.ascontiguousarray(pattern, np.int32)
+    loc = np.zeros((xyz.shape[0], 3), np.float32)
+    cells = np.zeros(294, np.float32)
+    n = lib().orc_bsc_cells(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], int(point_id), C.c_float(R), _p(pattern, C.c_int), _p(loc, C.c_float),
+                            xyz.shape[0], _p(cells, C.c_float))
+    return loc[:n].copy(), cells[:147].copy(), cells[147:].copy()
+
+
+def ref_cubic_grid(loc, R):
+    loc = _f32(loc)
+    cells = np.zeros(294, np.float32)
+    ref3_lib().ref_cubic_grid(_p(loc, C.c_float), loc.shape[0], C.c_float(R), _p(cells, C.c_float))
+    return cells[:147].copy(), cells[147:].copy()

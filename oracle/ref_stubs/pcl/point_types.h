@@ -44,6 +44,8 @@ template <typename T> inline void getMinMax3D(const PointCloud<T>& c, Eigen::Vec
 }
 struct PointIndices { std::vector<int> indices; };
 typedef std::shared_ptr<PointIndices> PointIndicesPtr;
+template <typename T> inline float kd_d2_(const T& p, const T& q) { const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z; return dx * dx + dy * dy + dz * dz; }
+inline float kd_d2_(const PointXY& p, const PointXY& q) { const float dx = p.x - q.x, dy = p.y - q.y; return dx * dx + dy * dy; }
 // pcl::KdTreeFLANN: exact search (FLANN with eps = 0).  radiusSearch: squared L2 distance in float, strict d^2 < r^2 (FLANN's
 // RadiusResultSet), the query itself included when it is a point of the cloud, results sorted by distance (ties: lower index).
 template <typename T> class KdTreeFLANN {
@@ -55,8 +57,7 @@ template <typename T> class KdTreeFLANN {
     std::vector<std::pair<float, int>> hits;
     for (std::size_t i = 0; i < cloud_->points.size(); i++) {
       const T& p = cloud_->points[i];
-      const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-      const float d = dx * dx + dy * dy + dz * dz;
+      const float d = kd_d2_(p, q);
       if (d < r2) hits.push_back(std::make_pair(d, (int)i));
     }
     std::sort(hits.begin(), hits.end());
