@@ -138,13 +138,12 @@ def main():
     strong = CF["scaling"] == "strong"
 
     # ---- the pair manifest of the whole job (rank 0's copy is the one that counts: it is broadcast below).  Weak scaling: B pairs
-    # per rank per step; strong scaling (cfg4): B pairs per step in total.  Entry = pair id = seed offset of the scene.
-    n_job = B if strong else B * world
-    n_scenes = min(n_job, distinct if strong else distinct * world)
-    manifest = [p % n_scenes for p in range(n_job)]
+    # per rank per step; strong scaling (cfg4): B pairs per step in total.  Entry = scene id = seed offset of the scene.
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    manifest = pq.job_manifest(B, distinct, world, strong)
+    n_job = len(manifest)
 
     # ---- scenes this rank needs, generated in parallel BEFORE HIP is initialised (fork-safe), untimed
-    pq = importlib.import_module("gh-icp_amd.pairqueue")
     mine = pq.pairs_for_rank(n_job, rank, world)
     my_scenes = sorted({manifest[p] for p in mine})
     t0 = time.time()
@@ -169,9 +168,7 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
-        box = [manifest if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)  # the manifest: scene ids, not point data
-        manifest = box[0]
+        manifest = pq.broadcast_manifest(manifest, dist)  # scene ids, not point data
 
     api = importlib.import_module("gh-icp_amd.api")
     synth = importlib.import_module("gh-icp_amd.synth")
@@ -195,9 +192,9 @@ def main():
     group_of = np.zeros(max(1, nb), np.int64)
     for g in range(G):
         group_of[bounds[g]:bounds[g + 1]] = g
-    nb_max = max(1, -(-n_job // world))  # same record block on every rank (all_gather wants equal shapes)
-    rec_dev = torch.zeros((nb_max, 19), dtype=torch.float64, device="cuda")
-    gathered = [torch.zeros_like(rec_dev) for _ in range(world)] if world > 1 else None
+    nb_max = pq.records_per_rank(n_job, world)  # same record block on every rank (all_gather wants equal shapes)
+    rec_dev = torch.zeros((nb_max, pq.RECORD_WIDTH), dtype=torch.float64, device="cuda")
+    job_records = {}
     last_results = [None] * G
     thread_busy = {"front_end": 0.0, "loop": 0.0}
 
@@ -290,14 +287,9 @@ def main():
             if err:
                 break
             flat = [st for r in res[k] for st in r]
-            rec = np.zeros((nb_max, 19))
-            rec[:, 0] = -1
-            for i, st in enumerate(flat):
-                rec[i, 0], rec[i, 1], rec[i, 2] = mine[i], st.iterations, st.converged
-                rec[i, 3:] = st.Rt[:]
-            rec_dev.copy_(torch.from_numpy(rec))
-            if world > 1:
-                dist.all_gather(gathered, rec_dev)
+            rec_dev.copy_(torch.from_numpy(pq.pack_records(mine, [(st.iterations, st.converged, st.Rt[:]) for st in flat], nb_max)))
+            job_records.clear()
+            job_records.update(pq.gather_records(rec_dev, dist))  # every rank holds every pair's record of the step
         for x in th:
             x.join()
         if err:

@@ -80,3 +80,59 @@ def run_multiview(n_clouds: int, pairs: Sequence[Sequence[int]], make_cloud: Cal
         for i, rec in g:
             out[i] = rec
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Batched variant used by bench.py: the manifest is broadcast ONCE per job, every step ends with ONE all-gather of fixed-size
+# result records (tensors on the ranks' device: RCCL on GPUs, gloo on CPU in the tests).
+RECORD_WIDTH = 19  # pair id, iterations, converged, 16 entries of the 4x4 (row-major)
+
+
+def job_manifest(pairs_per_step: int, distinct: int, world: int, strong: bool):
+    """Scene id of every pair of ONE step of the whole job.  Weak scaling: `pairs_per_step` pairs and `distinct` scenes PER RANK;
+    strong scaling (a fixed job, BASELINE cfg4): `pairs_per_step` pairs and `distinct` scenes in total."""
+    n_job = pairs_per_step if strong else pairs_per_step * world
+    n_scenes = max(1, min(n_job, distinct if strong else distinct * world))
+    return [p % n_scenes for p in range(n_job)]
+
+
+def broadcast_manifest(manifest, dist=None):
+    """Rank 0's manifest on every rank (scene ids / seeds / paths: never point data)."""
+    if dist is None or not dist.is_initialized():
+        return list(manifest)
+    box = [list(manifest) if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def records_per_rank(n_job: int, world: int) -> int:
+    """Rows of the per-rank record block (equal on every rank: all_gather wants equal shapes; unused rows carry pair id -1)."""
+    return max(1, -(-n_job // world))
+
+
+def pack_records(mine: Sequence[int], results, rows: int):
+    """`results[i]` (iterations, converged, Rt[16]) of pair `mine[i]` -> (rows, RECORD_WIDTH) float64 numpy block."""
+    import numpy as np
+
+    rec = np.zeros((rows, RECORD_WIDTH))
+    rec[:, 0] = -1
+    for i, (pid, r) in enumerate(zip(mine, results)):
+        rec[i, 0], rec[i, 1], rec[i, 2] = pid, r[0], r[1]
+        rec[i, 3:] = r[2]
+    return rec
+
+
+def gather_records(block, dist=None):
+    """All ranks' record blocks (torch tensors of equal shape) -> dict pair id -> (iterations, converged, Rt16 list)."""
+    blocks = [block]
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+
+        blocks = [torch.zeros_like(block) for _ in range(dist.get_world_size())]
+        dist.all_gather(blocks, block)
+    out = {}
+    for b in blocks:
+        for row in b.cpu().numpy():
+            if row[0] >= 0:
+                out[int(row[0])] = (int(row[1]), int(row[2]), [float(v) for v in row[3:]])
+    return out

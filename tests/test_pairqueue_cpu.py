@@ -127,3 +127,51 @@ def test_two_rank_gloo_multiview():
         assert [(r["s"], r["t"]) for r in out] == pairs  # every rank ends up with every record, in pair order
         assert [r["rank"] for r in out] == [i % 2 for i in range(len(pairs))]  # pair p was registered on rank p mod 2
     assert got[0][2] == got[1][2]
+
+
+def _records_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    # what bench.py does per job / per step, on CPU tensors: manifest from rank 0, static shard, one all-gather of the records
+    manifest = pq.broadcast_manifest(pq.job_manifest(5, 3, world, False) if rank == 0 else [], dist)
+    mine = pq.pairs_for_rank(len(manifest), rank, world)
+    rows = pq.records_per_rank(len(manifest), world)
+    results = [(10 + p, p % 2, [float(manifest[p] * 100 + k) for k in range(16)]) for p in mine]
+    block = torch.from_numpy(pq.pack_records(mine, results, rows))
+    out = pq.gather_records(block, dist)
+    q.put((rank, manifest, mine, sorted(out.items())))
+    dist.destroy_process_group()
+
+
+def test_job_manifest_and_record_gather_two_ranks():
+    """bench.py's job plumbing (manifest broadcast, static shard, per-step all-gather of the 19-double result records) with two gloo
+    ranks: every rank ends up with the record of every pair of the job."""
+    import torch.multiprocessing as mp
+
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    assert pq.job_manifest(6, 4, 1, False) == [0, 1, 2, 3, 0, 1]
+    assert pq.job_manifest(6, 4, 2, False) == [p % 8 for p in range(12)]     # weak: per-rank pairs and scenes
+    assert pq.job_manifest(64, 64, 8, True) == list(range(64))              # strong: the fixed 64-pair job of cfg4
+    assert pq.records_per_rank(7, 2) == 4 and pq.records_per_rank(0, 2) == 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_records_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    (r0, man0, mine0, out0), (r1, man1, mine1, out1) = got
+    assert man0 == man1 == [p % 6 for p in range(10)]
+    assert mine0 == [0, 2, 4, 6, 8] and mine1 == [1, 3, 5, 7, 9]
+    assert out0 == out1 and [k for k, _ in out0] == list(range(10))
+    for pid, (it, conv, Rt) in out0:
+        assert it == 10 + pid and conv == pid % 2 and Rt == [float(man0[pid] * 100 + k) for k in range(16)]
