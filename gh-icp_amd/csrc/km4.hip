@@ -107,8 +107,8 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         c[j] = cb + off + 16u * j + lig;
-        const unsigned cc = ce > cb ? min(c[j], ce - 1u) : cb;
-        col[j] = s.cols[cc]; val[j] = s.vals[cc];
+        col[j] = 0; val[j] = 0.0;  // a lane without a row, or with an empty row, loads nothing (found by tests/hipsim: cols[cb] may lie past the CSR)
+        if (ce > cb) { const unsigned cc = min(c[j], ce - 1u); col[j] = s.cols[cc]; val[j] = s.vals[cc]; }
       }
       double lyv[4];
 #pragma unroll

@@ -36,6 +36,13 @@ def api():
 def ctx(api):
     import torch
 
+    if os.environ.get("GHICP_SIM") == "1":  # kernel development aid: the same tests on the host SIMT interpreter (tests/hipsim), never on the GPU box
+        from hipsim import simctx
+
+        c = simctx.make_context(api)
+        yield c
+        c.close()
+        return
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     c = api.Context(0)

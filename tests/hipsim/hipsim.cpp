@@ -1,0 +1,321 @@
+// TEST INFRASTRUCTURE -- see include/hip/hip_runtime.h.  Block scheduler of the host SIMT interpreter: lanes are fibers (hand-written
+// x86-64 context switch), a workgroup runs on one OS thread, the workgroups of a launch are spread over a small pool of OS threads.
+#include <hip/hip_runtime.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+extern "C" void hipsim_swap(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipsim_swap
+.type hipsim_swap,@function
+hipsim_swap:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipsim_swap,.-hipsim_swap
+)");
+
+namespace hipsim {
+enum { S_RUN = 0, S_SYNC = 1, S_WAVE = 2, S_DONE = 3 };
+static const size_t STACK_BYTES = 256 * 1024;
+static const int MAX_LANES = 1024;
+
+struct Worker {
+  char* stacks = nullptr;
+  Lane lanes[MAX_LANES];
+  void* sched_sp = nullptr;
+  void (*tramp)(void*) = nullptr;
+  void* closure = nullptr;
+  bool yielded = false;
+  ~Worker() { if (stacks) munmap(stacks, STACK_BYTES * MAX_LANES); }
+};
+thread_local Lane* cur = nullptr;
+thread_local BlockInfo binfo;
+static thread_local Worker* W = nullptr;
+static thread_local hipError_t last_error = hipSuccess;
+static std::atomic<long long> n_divergent{0}, n_launches{0}, n_blocks{0};
+static int trace_div = -1;
+
+hipError_t take_last_error(bool clear) {
+  const hipError_t e = last_error;
+  if (clear) last_error = hipSuccess;
+  return e;
+}
+
+static void to_scheduler() { hipsim_swap(&cur->sp, W->sched_sp); }
+
+static void fiber_main() {
+  W->tramp(W->closure);
+  cur->state = S_DONE;
+  to_scheduler();
+  fprintf(stderr, "hipsim: a finished lane was resumed\n");
+  abort();
+}
+
+uint64_t wave_collective(int op, int site, uint64_t payload, int src) {
+  Lane* me = cur;
+  me->op = op; me->site = site; me->payload = payload; me->src = src;
+  me->state = S_WAVE;
+  to_scheduler();
+  return me->result;
+}
+void sync_threads() {
+  cur->state = S_SYNC;
+  to_scheduler();
+}
+void yield() {
+  if (!cur) return;  // host code
+  W->yielded = true;
+  to_scheduler();
+}
+
+static Worker* worker() {
+  static thread_local Worker holder;
+  if (!holder.stacks) {
+    void* m = mmap(nullptr, STACK_BYTES * MAX_LANES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) { perror("hipsim: mmap of the lane stacks"); abort(); }
+    holder.stacks = static_cast<char*>(m);
+  }
+  return &holder;
+}
+
+// resolve the pending collective of wave [l0, l1): the group at the smallest source line goes first (lanes that took a divergent
+// branch are behind the lanes already waiting at the reconvergence point)
+static void resolve(Lane* L, int l0, int l1, int n_live) {
+  int site = INT32_MAX, op = 0;
+  for (int i = l0; i < l1; i++)
+    if (L[i].state == S_WAVE && L[i].site < site) { site = L[i].site; op = L[i].op; }
+  uint64_t mask = 0, ball = 0;
+  int first = -1, n = 0;
+  for (int i = l0; i < l1; i++)
+    if (L[i].state == S_WAVE && L[i].site == site && L[i].op == op) {
+      mask |= 1ull << (i - l0);
+      if (first < 0) first = i;
+      if (L[i].payload & 1) ball |= 1ull << (i - l0);
+      n++;
+    }
+  if (n != n_live) {
+    n_divergent++;
+    if (trace_div > 0) fprintf(stderr, "hipsim: divergent collective op %d at line %d: %d of %d live lanes\n", op, site, n, n_live);
+  }
+  for (int i = l0; i < l1; i++) {
+    if (!((mask >> (i - l0)) & 1)) continue;
+    switch (op) {
+      case OP_BALLOT: L[i].result = ball; break;
+      case OP_SHFL: {
+        const int s = L[i].src;
+        L[i].result = (s >= 0 && s < l1 - l0 && ((mask >> s) & 1)) ? L[l0 + s].payload : L[i].payload;
+        break;
+      }
+      case OP_FIRST: L[i].result = L[first].payload; break;
+      default: L[i].result = 0;
+    }
+  }
+  for (int i = l0; i < l1; i++)
+    if ((mask >> (i - l0)) & 1) L[i].state = S_RUN;
+}
+
+static void run_block(const dim3& grid, const dim3& block, unsigned long long b) {
+  Worker* w = W;
+  Lane* L = w->lanes;
+  const int nt = (int)(block.x * block.y * block.z);
+  binfo.bdim = block; binfo.gdim = grid;
+  binfo.bid.x = (unsigned)(b % grid.x); binfo.bid.y = (unsigned)((b / grid.x) % grid.y); binfo.bid.z = (unsigned)(b / ((unsigned long long)grid.x * grid.y));
+  for (int t = 0; t < nt; t++) {
+    Lane& l = L[t];
+    l.tid.x = t % block.x; l.tid.y = (t / block.x) % block.y; l.tid.z = t / (block.x * block.y);
+    l.lane = t & 63; l.wave = t >> 6; l.state = S_RUN;
+    void** top = reinterpret_cast<void**>(w->stacks + STACK_BYTES * (size_t)(t + 1));
+    top[-1] = nullptr;                                   // return address slot of fiber_main (never used)
+    top[-2] = reinterpret_cast<void*>(&fiber_main);      // `ret` of the first switch lands here
+    for (int k = 3; k <= 8; k++) top[-k] = nullptr;      // rbp rbx r12 r13 r14 r15
+    l.sp = top - 8;
+  }
+  const int nw = (nt + 63) / 64;
+  long long idle_rounds = 0;
+  for (;;) {
+    bool progressed = false;
+    for (int wv = 0; wv < nw; wv++) {
+      const int l0 = wv * 64, l1 = std::min(nt, l0 + 64);
+      for (;;) {
+        int ran = 0;
+        w->yielded = false;
+        for (int i = l0; i < l1; i++)
+          if (L[i].state == S_RUN) { cur = &L[i]; hipsim_swap(&w->sched_sp, L[i].sp); ran++; }
+        cur = nullptr;
+        int n_run = 0, n_wave = 0, n_live = 0;
+        for (int i = l0; i < l1; i++) { n_run += L[i].state == S_RUN; n_wave += L[i].state == S_WAVE; n_live += L[i].state != S_DONE; }
+        if (ran && !(w->yielded && n_run == ran && n_wave == 0)) progressed = true;
+        if (n_run > 0) break;  // pollers: let the other waves run
+        if (n_wave > 0) { resolve(L, l0, l1, n_live); progressed = true; continue; }
+        break;
+      }
+    }
+    int n_run = 0, n_sync = 0, n_done = 0;
+    for (int i = 0; i < nt; i++) { n_run += L[i].state == S_RUN; n_sync += L[i].state == S_SYNC; n_done += L[i].state == S_DONE; }
+    if (n_done == nt) return;
+    if (n_run == 0) {
+      if (n_sync + n_done != nt) { fprintf(stderr, "hipsim: scheduler inconsistency\n"); abort(); }
+      for (int i = 0; i < nt; i++)
+        if (L[i].state == S_SYNC) L[i].state = S_RUN;  // barrier of the lanes that have not exited
+      idle_rounds = 0;
+      continue;
+    }
+    if (!progressed && ++idle_rounds > 50'000'000) {
+      fprintf(stderr, "hipsim: workgroup (%u,%u,%u) only polls: %d lanes spin, %d wait at a barrier (a wait on another workgroup cannot be simulated)\n",
+              binfo.bid.x, binfo.bid.y, binfo.bid.z, n_run, n_sync);
+      abort();
+    }
+    if (progressed) idle_rounds = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- launches
+struct Job {
+  dim3 grid, block;
+  void (*tramp)(void*);
+  void* closure;
+  std::atomic<unsigned long long> next{0};
+  unsigned long long total = 0;
+  std::atomic<int> active{0};
+};
+// leaked on purpose: the detached pool threads wait on these until the process ends
+static std::mutex &pool_mu = *new std::mutex, &job_mu = *new std::mutex;
+static std::condition_variable &pool_cv = *new std::condition_variable, &done_cv = *new std::condition_variable;
+static Job* pool_job = nullptr;
+static unsigned long long pool_gen = 0;
+static bool pool_started = false;
+static bool pool_stop = false;
+
+static void thread_altstack();
+static void work_on(Job* j) {
+  thread_altstack();
+  W = worker();
+  W->tramp = j->tramp; W->closure = j->closure;
+  for (;;) {
+    const unsigned long long b = j->next.fetch_add(1);
+    if (b >= j->total) break;
+    run_block(j->grid, j->block, b);
+  }
+}
+static void pool_main() {
+  unsigned long long seen = 0;
+  for (;;) {
+    Job* j;
+    {
+      std::unique_lock<std::mutex> lk(pool_mu);
+      pool_cv.wait(lk, [&] { return pool_stop || (pool_job && pool_gen != seen); });
+      if (pool_stop) return;
+      seen = pool_gen;
+      j = pool_job;
+      j->active++;
+    }
+    work_on(j);
+    {
+      std::unique_lock<std::mutex> lk(pool_mu);
+      j->active--;
+      done_cv.notify_all();
+    }
+  }
+}
+static int pool_threads() {
+  static int n = [] {
+    const char* e = getenv("HIPSIM_THREADS");
+    int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(v, 64));
+  }();
+  return n;
+}
+
+static void on_segv(int sig, siginfo_t* si, void*) {
+  char msg[256];
+  Lane* l = cur;
+  int n = snprintf(msg, sizeof msg, "\nhipsim: signal %d at address %p; workgroup (%u,%u,%u) thread (%u,%u,%u)%s\n", sig, si->si_addr, binfo.bid.x, binfo.bid.y,
+                   binfo.bid.z, l ? l->tid.x : 0, l ? l->tid.y : 0, l ? l->tid.z : 0, l ? "" : " [host code]");
+  (void)!write(2, msg, n);
+  void* bt[48];
+  backtrace_symbols_fd(bt, backtrace(bt, 48), 2);
+  _exit(139);
+}
+static bool segv_trace = false;
+static void thread_altstack() {
+  static thread_local char* alt = nullptr;
+  if (!segv_trace || alt) return;
+  alt = static_cast<char*>(malloc(1 << 16));
+  stack_t ss;
+  ss.ss_sp = alt; ss.ss_size = 1 << 16; ss.ss_flags = 0;
+  sigaltstack(&ss, nullptr);
+}
+static void install_segv_trace() {
+  segv_trace = true;
+  struct sigaction sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_sigaction = on_segv;
+  sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+  sigaction(SIGSEGV, &sa, nullptr);
+  sigaction(SIGBUS, &sa, nullptr);
+}
+
+void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure) {
+  if (trace_div < 0) {
+    trace_div = getenv("HIPSIM_TRACE_DIVERGENCE") ? 1 : 0;
+    if (getenv("HIPSIM_SEGV_TRACE")) install_segv_trace();
+  }
+  const unsigned long long total = (unsigned long long)grid.x * grid.y * grid.z;
+  const unsigned long long nt = (unsigned long long)block.x * block.y * block.z;
+  if (total == 0 || nt == 0 || nt > MAX_LANES || shmem > 160 * 1024 || grid.y > 65535 || grid.z > 65535) {
+    last_error = hipErrorInvalidConfiguration;
+    return;
+  }
+  if (cur) { fprintf(stderr, "hipsim: launch from device code\n"); abort(); }
+  n_launches++; n_blocks += (long long)total;
+  Job j;
+  j.grid = grid; j.block = block; j.tramp = tramp; j.closure = closure; j.total = total;
+  const int nthreads = pool_threads();
+  if (total < 4 || nthreads == 1) {  // small launches stay on the calling thread (host threads may launch concurrently)
+    work_on(&j);
+    return;
+  }
+  std::lock_guard<std::mutex> one_job(job_mu);
+  {
+    std::unique_lock<std::mutex> lk(pool_mu);
+    if (!pool_started) {
+      pool_started = true;
+      for (int i = 0; i < nthreads - 1; i++) std::thread(pool_main).detach();
+    }
+    pool_job = &j;
+    pool_gen++;
+  }
+  pool_cv.notify_all();
+  work_on(&j);
+  std::unique_lock<std::mutex> lk(pool_mu);
+  pool_job = nullptr;  // late wakers must not pick the job up any more
+  done_cv.wait(lk, [&] { return j.active.load() == 0; });
+}
+}  // namespace hipsim
+
+extern "C" void hipsim_counters(long long* out3) {
+  out3[0] = hipsim::n_launches.load(); out3[1] = hipsim::n_blocks.load(); out3[2] = hipsim::n_divergent.load();
+}

@@ -28,7 +28,7 @@ def test_cfg4_indoor_fragment_batch(ctx, api, oracle, synth):
     pat = synth.bsc_pattern_glibc()
     pairs = [synth.indoor_pair(i, 60_000) for i in range(3)]
     cfg = api.pair_config(api.FEATURE_BSC, api.CORR_NN, 6, 0.6, 0.025, 0.10, 0.30, pat, max_iter=80)
-    stats = ctx.register_pairs(cfg, [(torch.from_numpy(p.source).cuda(), torch.from_numpy(p.target).cuda()) for p in pairs])
+    stats = ctx.register_pairs(cfg, [(torch.from_numpy(p.source).to(ctx.dev), torch.from_numpy(p.target).to(ctx.dev)) for p in pairs])
     for p, st in zip(pairs, stats):
         ro, kp = _oracle_pair(oracle, synth, p.source, p.target, 0.025, 0.10, 0.30, 6, oracle.NN, 0.6, pat)
         assert (st.k_s, st.k_t, st.iterations) == (kp["S"].size, kp["T"].size, ro["iters"])
@@ -82,7 +82,7 @@ def test_edge_cases(ctx, api, oracle):
     assert ctx.keypoints(np.zeros((0, 3), np.float32), 0.5, 1.5).numel() == 0
     assert ctx.voxel_filter(np.zeros((0, 3), np.float32), 0.1).numel() == 0
     # a tiny cloud: nothing survives the prune (ptNum > 20), the pair API still returns cleanly
-    tiny = torch.from_numpy(rng.normal(size=(50, 3)).astype(np.float32)).cuda()
+    tiny = torch.from_numpy(rng.normal(size=(50, 3)).astype(np.float32)).to(ctx.dev)
     st, _ = ctx.register_pair(api.pair_config(api.FEATURE_BSC, api.CORR_NN, 6, 0.6, 0.1, 0.5, 1.5, None, max_iter=5), tiny, tiny)
     assert (st.k_s, st.k_t, st.iterations) == (0, 0, 0)
     # host-pointer mode of the C ABI (what the C++ drop-in classes use)

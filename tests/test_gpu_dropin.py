@@ -23,10 +23,12 @@ def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr, types):
     """`types`: the repo's stand-in PCL / Eigen types, or -DGHICP_WITH_PCL against interface-only fakes of the real libraries
     (column-major Eigen, 16-byte PointXYZI): the same caller code, the same results."""
     exe = tmp_path / "test_dropin"
-    libdir = os.path.join(ROOT, "gh-icp_amd")
+    libdir, libname = os.path.join(ROOT, "gh-icp_amd"), "ghicp_hip"
+    if getattr(ctx, "simulated", False):  # GHICP_SIM=1 (kernel development on the build container): same C ABI from tests/hipsim
+        libdir, libname = os.path.join(ROOT, "tests", "hipsim", "_build"), "ghicp_sim"
     extra = [] if types == "shim" else ["-DGHICP_WITH_PCL", "-I", os.path.join(ROOT, "oracle", "ref_stubs")]
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include")] + extra + [os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
-                           "-L", libdir, "-lghicp_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+                           "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", str(exe)])
     p = synth.tls_pair(100_000, pair_id=5)
     dsT = p.target[oracle.voxel_filter(p.target, 0.1)]
     dsS = p.source[oracle.voxel_filter(p.source, 0.1)]

@@ -154,7 +154,7 @@ def test_register_pairs_batch_equals_single(ctx, api, synth, tls):
     import torch
 
     jobs = [(tls.source, tls.target), (other.source, other.target), (tls.target, tls.source), (other.source[:100], other.target[:100])]
-    dev = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in jobs]
+    dev = [(torch.from_numpy(a).to(ctx.dev), torch.from_numpy(b).to(ctx.dev)) for a, b in jobs]
     batch = ctx.register_pairs(cfg, dev)
     assert len(batch) == len(jobs)
     for (a, b), st in zip(dev, batch):

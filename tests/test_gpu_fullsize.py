@@ -18,7 +18,7 @@ def scan(synth):
 def test_front_end_properties_at_full_size(ctx, scan):
     import torch
 
-    cloud = torch.from_numpy(scan.target).cuda()
+    cloud = torch.from_numpy(scan.target).to(ctx.dev)
     keep = ctx.voxel_filter(cloud, 0.1)
     ds = cloud[keep.long()].contiguous()
     assert int(keep[0]) == 0 and 200_000 < ds.shape[0] < 600_000
@@ -47,7 +47,7 @@ def test_front_end_properties_at_full_size(ctx, scan):
 def test_fine_registration_identities_at_full_size(ctx, api, scan):
     import torch
 
-    cloud = torch.from_numpy(scan.target).cuda()
+    cloud = torch.from_numpy(scan.target).to(ctx.dev)
     ds = cloud[ctx.voxel_filter(cloud, 0.1).long()][:, :3].contiguous()
     n = ds.shape[0]
     assert ctx.cal_overlap(ds, ds, 0.05) == np.float32((0.01 + n) / n)

@@ -61,7 +61,7 @@ def test_loop_bsc_energy(ctx, api, synth, oracle, corr):
     po = oracle.default_params(oracle.BSC, corr, 6, 0.6, 1.5, bbx, max_iter=40)
     ro = oracle.register(po, kpS, kpT, FD, want_matchlist=True)
     pg = api.default_params(api.FEATURE_BSC, corr, 6, 0.6, 1.5, bbx, max_iter=40)
-    FDg = torch.from_numpy(FD.astype(np.int16)).cuda()
+    FDg = torch.from_numpy(FD.astype(np.int16)).to(ctx.dev)
     rg = ctx.register(pg, kpS, kpT, FDg, want_matchlist=True)
     assert rg["iters"] == ro["iters"]
     np.testing.assert_array_equal(rg["matchlist"], ro["matchlist"])
@@ -80,7 +80,7 @@ def test_loop_fpfh_energy(ctx, api, synth, oracle, corr):
     po = oracle.default_params(oracle.FPFH, corr, 6, 0.6, 1.5, bbx, max_iter=40)
     ro = oracle.register(po, kpS, kpT, FD.astype(np.float64), want_matchlist=True)
     pg = api.default_params(api.FEATURE_FPFH, corr, 6, 0.6, 1.5, bbx, max_iter=40)
-    rg = ctx.register(pg, kpS, kpT, torch.from_numpy(FD).cuda(), want_matchlist=True)
+    rg = ctx.register(pg, kpS, kpT, torch.from_numpy(FD).to(ctx.dev), want_matchlist=True)
     assert rg["iters"] == ro["iters"]
     np.testing.assert_array_equal(rg["matchlist"], ro["matchlist"])
     _compare_traces(rg["trace"], ro["trace"], rel=1e-7)  # device pow() vs glibc pow(): <= 1 ulp apart

@@ -1,0 +1,41 @@
+"""The GPU parity tests' LOGIC on the build container: a subset of the `-m gpu` tests runs, unchanged, against the library's own
+kernel sources compiled for the host SIMT interpreter of tests/hipsim (every lane a fiber; wave collectives and barriers are
+scheduling points).  This is test infrastructure for kernel development without a GPU -- it caught an out-of-CSR read of k_km4 that
+the MI355X tolerates -- and NOT a parity claim: parity is `pytest -m gpu` on the MI355X through libghicp_hip.so.  The package never
+loads the simulated library (gh-icp_amd/api.py: "There is no CPU fallback")."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the slow ones stay on the GPU (and on `GHICP_SIM=1 python -m pytest tests -m gpu` when a kernel is being changed)
+SLOW = ["register_pairs_batch_equals_single", "pair_pipeline_vs_oracle", "pair_pipeline_fpfh_nnr", "cached_clouds_match_pair_api", "GHICP_KM_POOL",
+        "GHICP_KM_V2", "sbf_dump_round_trip", "icp_after_coarse", "km_kat_and_random", "cpp_dropin", "full_size", "multiview"]
+
+
+def test_package_never_loads_the_simulated_library():
+    for root, _, files in os.walk(os.path.join(ROOT, "gh-icp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f), errors="replace").read()
+                assert "ghicp_sim" not in txt and "hipsim/" not in txt and "import hipsim" not in txt, f
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert "hipsim" not in open(os.path.join(ROOT, f)).read(), f
+
+
+def test_gpu_tests_on_the_host_simt_interpreter():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hipsim import build
+
+    build.build()  # once, before the workers start
+    env = dict(os.environ, GHICP_SIM="1", HIPSIM_THREADS="2", HIPSIM_SEGV_TRACE="1")
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-n", "4",
+           "-k", " and ".join("not " + s for s in SLOW)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    import re
+
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 40 and "failed" not in r.stdout, tail
