@@ -1,0 +1,230 @@
+// Binary Shape Context of ONE keypoint by one 256-thread workgroup (bfe:603-837); shared by the single-cloud kernel (bsc.hip) and the
+// batched front end (batch.hip).  feat: [variant][K][56] of the keypoint's cloud, lcs: [K][12] (origin in 9..11 on entry).
+#pragma once
+#include "grid.h"
+#include "devmath.h"
+
+struct BscConst {
+  float R, r2s, u, den, r2c, area;
+  double radius_w;
+  float centre[7];
+  int pattern[98];
+  int K, nvar;
+};
+
+constexpr int BT = 256;
+
+__device__ inline int rearr_src(int type, int k) {  // bfe:700-739
+  switch (type) {
+    case 1: return 48 - k;
+    case 2: return (6 - k / 7) * 7 + k % 7;
+    default: return (k / 7) * 7 + 6 - k % 7;
+  }
+}
+
+__device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int kk, int K, uint8_t* __restrict__ feat, float* __restrict__ lcs) {
+
+  __shared__ double red[16];
+  __shared__ double s_pnum[147], s_dsum[147];
+  __shared__ float s_weight[147], s_depth[147];
+  __shared__ float s_axes[9];
+  __shared__ double s_stat[3][4];  // per plane: avg_d, sd_d, avg_w, sd_w
+  __shared__ unsigned s_bits[4][16];
+  const int tid = threadIdx.x;
+  // the keypoint itself: kp holds ORIGINAL indices; find its coordinates through the original cloud copy kept in pts? -> passed via lcs origin
+  const float qx = lcs[(size_t)kk * 12 + 9], qy = lcs[(size_t)kk * 12 + 10], qz = lcs[(size_t)kk * 12 + 11];
+  const int cx = gh_cell_coord(qx, G.d.mn[0], G.d.inv, G.d.dim[0]);
+  const int cy = gh_cell_coord(qy, G.d.mn[1], G.d.inv, G.d.dim[1]);
+  const int cz = gh_cell_coord(qz, G.d.mn[2], G.d.inv, G.d.dim[2]);
+
+  // ---- sweep A
+  double sx = 0, sy = 0, sz = 0, sw = 0;
+  int cnt = 0;
+  gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+    for (unsigned q = b + tid; q < e; q += BT) {
+      const float4 P = G.pts[q];
+      const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+      float d2 = dx * dx;
+      d2 += dy * dy;
+      d2 += dz * dz;
+      if (d2 < C.r2s) {
+        cnt++;
+        sx += (double)P.x; sy += (double)P.y; sz += (double)P.z;
+        sw += C.radius_w - (double)sqrtf(d2);
+      }
+    }
+  });
+  sx = gh_block_sum(sx, red); sy = gh_block_sum(sy, red); sz = gh_block_sum(sz, red); sw = gh_block_sum(sw, red);
+  const int mm = (int)gh_block_sum((double)cnt, red);
+  const double mx = sx / (double)mm, my = sy / (double)mm, mz = sz / (double)mm;
+
+  // ---- sweep B
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  if (mm >= 3) {
+    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+      for (unsigned q = b + tid; q < e; q += BT) {
+        const float4 P = G.pts[q];
+        const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        if (d2 < C.r2s) {
+          const double w = (double)(float)(C.radius_w - (double)sqrtf(d2));  // float weight (bfe:975-976), negative beyond sqrt2*R
+          const double ex = (double)P.x - mx, ey = (double)P.y - my, ez = (double)P.z - mz;
+          c00 += w * ex * ex; c01 += w * ex * ey; c02 += w * ex * ez;
+          c11 += w * ey * ey; c12 += w * ey * ez; c22 += w * ez * ez;
+        }
+      }
+    });
+    c00 = gh_block_sum(c00, red); c01 = gh_block_sum(c01, red); c02 = gh_block_sum(c02, red);
+    c11 = gh_block_sum(c11, red); c12 = gh_block_sum(c12, red); c22 = gh_block_sum(c22, red);
+  }
+  if (tid == 0) {
+    float X[3] = {1, 0, 0}, Y[3] = {0, 1, 0}, Z[3] = {0, 0, 1};
+    if (mm >= 3) {
+      const float da = (float)sw;
+      double Cq[6] = {c00, c01, c02, c11, c12, c22};
+      gh_quant_grid(Cq, 6);  // N2: Matrix3f covariance
+      double a00 = (double)((float)Cq[0] / da), a01 = (double)((float)Cq[1] / da), a02 = (double)((float)Cq[2] / da),
+             a11 = (double)((float)Cq[3] / da), a12 = (double)((float)Cq[4] / da), a22 = (double)((float)Cq[5] / da);
+      double V[9];
+      gh_jacobi3(a00, a01, a02, a11, a12, a22, V);
+      const double ev[3] = {a00, a11, a22};
+      int imax = 0, imin = 0;
+      for (int i = 0; i < 3; i++) {
+        if ((float)ev[i] > (float)ev[imax]) imax = i;
+        if ((float)ev[i] < (float)ev[imin]) imin = i;
+      }
+      float P[3], N[3];
+      for (int which = 0; which < 2; which++) {
+        const int col = which == 0 ? imax : imin;
+        const double e[3] = {V[0 * 3 + col], V[1 * 3 + col], V[2 * 3 + col]};
+        int b = 0;
+        if (fabs(e[1]) > fabs(e[b])) b = 1;
+        if (fabs(e[2]) > fabs(e[b])) b = 2;
+        const double sg = (e[b] < 0) ? -1.0 : 1.0;
+        float* o = which == 0 ? P : N;
+        for (int d = 0; d < 3; d++) o[d] = (float)(sg * e[d]);
+      }
+      const float M0 = P[1] * N[2] - P[2] * N[1], M1 = P[2] * N[0] - P[0] * N[2], M2 = P[0] * N[1] - P[1] * N[0];
+      X[0] = P[0]; X[1] = P[1]; X[2] = P[2];
+      Y[0] = M0; Y[1] = M1; Y[2] = M2;
+      Z[0] = X[1] * Y[2] - X[2] * Y[1];
+      Z[1] = X[2] * Y[0] - X[0] * Y[2];
+      Z[2] = X[0] * Y[1] - X[1] * Y[0];
+      const float nx = sqrtf((X[0] * X[0] + X[1] * X[1]) + X[2] * X[2]);
+      const float ny = sqrtf((Y[0] * Y[0] + Y[1] * Y[1]) + Y[2] * Y[2]);
+      for (int d = 0; d < 3; d++) { X[d] = X[d] / nx; Y[d] = Y[d] / ny; }
+    }
+    for (int d = 0; d < 3; d++) { s_axes[d] = X[d]; s_axes[3 + d] = Y[d]; s_axes[6 + d] = Z[d]; }
+    float* o = &lcs[(size_t)kk * 12];
+    for (int d = 0; d < 3; d++) { o[d] = X[d]; o[3 + d] = Y[d]; o[6 + d] = Z[d]; }
+  }
+  for (int i = tid; i < 147; i += BT) { s_pnum[i] = 0.0; s_dsum[i] = 0.0; }
+  if (tid < 64) s_bits[tid >> 4][tid & 15] = 0u;
+  __syncthreads();
+  const float X0 = s_axes[0], X1 = s_axes[1], X2 = s_axes[2], Y0 = s_axes[3], Y1 = s_axes[4], Y2 = s_axes[5], Z0 = s_axes[6], Z1 = s_axes[7],
+              Z2 = s_axes[8];
+
+  // ---- sweep C
+  gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+    for (unsigned q = b + tid; q < e; q += BT) {
+      const float4 P = G.pts[q];
+      const float tx = qx - P.x, ty = qy - P.y, tz = qz - P.z;
+      float d2 = tx * tx;
+      d2 += ty * ty;
+      d2 += tz * tz;
+      if (!(d2 < C.r2s)) continue;
+      const float d0 = P.x - qx, d1 = P.y - qy, d2v = P.z - qz;  // bfe:178-180
+      const float loc[3] = {(X0 * d0 + X1 * d1) + X2 * d2v, (Y0 * d0 + Y1 * d1) + Y2 * d2v, (Z0 * d0 + Z1 * d1) + Z2 * d2v};
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) {
+        const float a = loc[pl == 2 ? 1 : 0], bb = loc[pl == 0 ? 1 : 2];
+        const float depth = loc[pl == 0 ? 2 : (pl == 1 ? 1 : 0)] + C.R;
+        for (int j = 0; j < 7; j++) {
+          const float dy = bb - C.centre[j];
+          const float dy2 = dy * dy;
+          if (!(dy2 < C.r2c)) continue;  // dx*dx + dy2 >= dy2 in f32, so this skip is exact
+          for (int i = 0; i < 7; i++) {
+            const float dx = a - C.centre[i];
+            float dd = dx * dx;
+            dd += dy2;
+            if (dd < C.r2c) {
+              const float ew = (float)exp((double)(-dd / C.den));  // expf, correctly rounded (bfe:239)
+              atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);
+              atomicAdd(&s_dsum[i + 7 * j + 49 * pl], (double)depth * (double)ew);
+            }
+          }
+        }
+      }
+    }
+  });
+  __syncthreads();
+
+  // ---- cell quantities (bfe:333-372)
+  if (tid < 147) {
+    const float ndens = (float)mm / C.area;
+    float avg = (float)s_dsum[tid];
+    avg = (s_pnum[tid] == 0.0) ? 0.0f : (float)((double)avg / s_pnum[tid]);
+    const float garea = C.u * C.u;
+    const float gdens = (float)(s_pnum[tid] / (double)garea);
+    s_weight[tid] = (ndens != 0.0f) ? gdens / ndens : 0.0f;
+    s_depth[tid] = avg;
+  }
+  __syncthreads();
+  // ---- per-plane statistics over the 49 pairs, sequential f64 exactly as bfe:500-525
+  if (tid < 3) {
+    const int off = 49 * tid;
+    double avg_d = 0, var_d = 0, avg_w = 0, var_w = 0;
+    for (int i = 0; i < 49; i++) {
+      const int a = C.pattern[2 * i] + off, b = C.pattern[2 * i + 1] + off;
+      avg_d += (double)(s_depth[a] - s_depth[b]);
+      avg_w += (double)(s_weight[a] - s_weight[b]);
+    }
+    avg_d /= 49; avg_w /= 49;
+    for (int i = 0; i < 49; i++) {
+      const int a = C.pattern[2 * i] + off, b = C.pattern[2 * i + 1] + off;
+      const double dd = (double)(s_depth[a] - s_depth[b]), dw = (double)(s_weight[a] - s_weight[b]);
+      var_d += (dd - avg_d) * (dd - avg_d);
+      var_w += (dw - avg_w) * (dw - avg_w);
+    }
+    var_d /= 49; var_w /= 49;
+    s_stat[tid][0] = avg_d; s_stat[tid][1] = sqrt(var_d); s_stat[tid][2] = avg_w; s_stat[tid][3] = sqrt(var_w);
+  }
+  __syncthreads();
+  // ---- bits (A.2 layout): variant 0 = 147 occupancy + 3 x 49 x (depth, density); variants 1..3 = Q3 layout
+  for (int base = 0; base < 448; base += BT) {
+    const int k = base + tid;
+    for (int v = 0; v < C.nvar; v++) {
+      bool bit = false;
+      if (v == 0) {
+        if (k < 147) bit = s_weight[k] > 0.1f;
+        else if (k < 441) {
+          const int r = k - 147, pl = r / 98, p = (r % 98) >> 1, off = 49 * pl;
+          const int a = C.pattern[2 * p], b = C.pattern[2 * p + 1];
+          if ((r & 1) == 0) {
+            const double dd = (double)(s_depth[a + off] - s_depth[b + off]);
+            bit = fabs(dd - s_stat[pl][0]) > s_stat[pl][1];
+          } else if (!(s_weight[a] < 0.1f && s_weight[b] < 0.1f)) {  // Q4: no plane offset (bfe:543)
+            const double dw = (double)(s_weight[a + off] - s_weight[b + off]);
+            bit = fabs(dw - s_stat[pl][2]) > s_stat[pl][3];
+          }
+        }
+      } else if (k >= 147 && k < 294) {
+        static const int TR[4][3] = {{0, 0, 0}, {1, 2, 2}, {3, 2, 1}, {2, 1, 3}};  // bfe:795, 808, 817
+        const int r = k - 147, pl = r / 49, kk2 = r % 49;
+        bit = s_weight[49 * pl + rearr_src(TR[v][pl], kk2)] > 0.1f;
+      }
+      const unsigned long long bal = __ballot(bit);
+      if ((tid & 63) == 0 && k < 448) {
+        s_bits[v][k >> 5] = (unsigned)bal;
+        if (k + 32 < 448) s_bits[v][(k >> 5) + 1] = (unsigned)(bal >> 32);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 14 * C.nvar) {
+    const int v = tid / 14, w = tid % 14;
+    reinterpret_cast<unsigned*>(feat)[((size_t)v * K + kk) * 14 + w] = s_bits[v][w];
+  }
+}

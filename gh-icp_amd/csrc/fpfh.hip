@@ -15,12 +15,6 @@ namespace {
 
 constexpr int KNN = 20;
 
-struct GridArgs {
-  GridDesc d;
-  const float4* pts;
-  const unsigned* start;
-};
-
 __device__ inline bool pair_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
 // `kk` <= KNN neighbours are kept (rows of nn/nd stay KNN wide; slots >= kk are never filled)

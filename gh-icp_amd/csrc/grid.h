@@ -20,6 +20,13 @@ struct DeviceGrid {
   const unsigned* keys;   // n sorted cell keys
 };
 
+// what a kernel needs of a grid (by value in the launch arguments, or one entry per cloud of a batch)
+struct GridArgs {
+  GridDesc d;
+  const float4* pts;
+  const unsigned* start;
+};
+
 struct GridSlots {
   BufSlot keys, keys2, vals, vals2, start, pts;
 };

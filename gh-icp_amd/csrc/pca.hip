@@ -11,18 +11,11 @@
 // served by LDS/L2 (streamed traffic 16*M*27-cell amplification).
 #include "grid.h"
 #include "devmath.h"
+#include "pca_dev.h"
 
 #include <hipcub/hipcub.hpp>
 
 namespace {
-
-constexpr int PCA_CHUNK = 512;
-
-struct GridArgs {
-  GridDesc d;
-  const float4* pts;
-  const unsigned* start;
-};
 
 __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __restrict__ cells, const int* __restrict__ ncells,
                                                    int* __restrict__ counter, float r2, float* __restrict__ lambda,
@@ -37,86 +30,7 @@ __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __
     const int c = __builtin_amdgcn_readfirstlane(s_cell);
     __syncthreads();
     if (c >= nc) break;
-    const unsigned key = cells[c];
-    const int cz = key % G.d.dim[2];
-    const int cy = (key / G.d.dim[2]) % G.d.dim[1];
-    const int cx = key / (G.d.dim[2] * G.d.dim[1]);
-    const unsigned qb = G.start[key], qe = G.start[key + 1];
-    for (unsigned q0 = qb; q0 < qe; q0 += 64) {
-      const unsigned q = q0 + lane;
-      const bool live = q < qe;
-      float4 P = make_float4(0, 0, 0, 0);
-      if (live) P = G.pts[q];
-      // ---- sweep 1: neighbour count and centroid (pca.h:151, pcl::PCA mean)
-      int k = 0;
-      double sx = 0, sy = 0, sz = 0;
-      gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
-        for (unsigned base = rb; base < re; base += PCA_CHUNK) {
-          const int cnt = min((unsigned)PCA_CHUNK, re - base);
-          for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
-          __syncthreads();
-          if (live)
-            for (int t = 0; t < cnt; t++) {
-              const float4 Cc = sC[t];
-              const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
-              float d2 = dx * dx;
-              d2 += dy * dy;
-              d2 += dz * dz;
-              if (d2 < r2) { k++; sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z; }
-            }
-          __syncthreads();
-        }
-      });
-      const double mx = sx / (double)k, my = sy / (double)k, mz = sz / (double)k;
-      // ---- sweep 2: de-meaned scatter
-      double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
-      gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
-        for (unsigned base = rb; base < re; base += PCA_CHUNK) {
-          const int cnt = min((unsigned)PCA_CHUNK, re - base);
-          for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
-          __syncthreads();
-          if (live && k >= 3)
-            for (int t = 0; t < cnt; t++) {
-              const float4 Cc = sC[t];
-              const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
-              float d2 = dx * dx;
-              d2 += dy * dy;
-              d2 += dz * dz;
-              if (d2 < r2) {
-                const double ex = (double)Cc.x - mx, ey = (double)Cc.y - my, ez = (double)Cc.z - mz;
-                s00 += ex * ex; s01 += ex * ey; s02 += ex * ez;
-                s11 += ey * ey; s12 += ey * ez; s22 += ez * ez;
-              }
-            }
-          __syncthreads();
-        }
-      });
-      if (live) {
-        const unsigned orig = __float_as_uint(P.w);
-        float l1 = 0.f, l2 = 0.f, l3 = 0.f;
-        double cv = 0.0;
-        if (k >= 3) {  // pca.h:209
-          double S[6] = {s00, s01, s02, s11, s12, s22};
-          gh_quant_grid(S, 6);  // N2: pcl::PCA's Matrix3f
-          double a00 = (double)(float)S[0], a01 = (double)(float)S[1], a02 = (double)(float)S[2], a11 = (double)(float)S[3],
-                 a12 = (double)(float)S[4], a22 = (double)(float)S[5];
-          double V[9];
-          gh_jacobi3(a00, a01, a02, a11, a12, a22, V);
-          double e0 = a00, e1 = a11, e2 = a22, t;  // ascending sort
-          if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
-          if (e1 > e2) { t = e1; e1 = e2; e2 = t; }
-          if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
-          l1 = (float)e2; l2 = (float)e1; l3 = (float)e0;
-          const double d1 = (double)l1, d2_ = (double)l2, d3 = (double)l3;
-          cv = ((d1 + d2_ + d3) == 0.0) ? 0.0 : d3 / (d1 + d2_ + d3);  // pca.h:240-247
-        }
-        lambda[(size_t)orig * 3] = l1;
-        lambda[(size_t)orig * 3 + 1] = l2;
-        lambda[(size_t)orig * 3 + 2] = l3;
-        curvature[orig] = cv;
-        count[orig] = k;
-      }
-    }
+    gh_pca_cell(G, cells[c], r2, lambda, curvature, count, sC, lane);
   }
 }
 

@@ -57,6 +57,8 @@ static thread_local Worker* W = nullptr;
 static thread_local hipError_t last_error = hipSuccess;
 static std::atomic<long long> n_divergent{0}, n_launches{0}, n_blocks{0};
 static int trace_div = -1;
+static std::atomic<long long> api_calls[C_NUM];
+void count(int what) { api_calls[what]++; }
 
 hipError_t take_last_error(bool clear) {
   const hipError_t e = last_error;
@@ -316,6 +318,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* clo
 }
 }  // namespace hipsim
 
-extern "C" void hipsim_counters(long long* out3) {
-  out3[0] = hipsim::n_launches.load(); out3[1] = hipsim::n_blocks.load(); out3[2] = hipsim::n_divergent.load();
+extern "C" void hipsim_counters(long long* out8) {
+  out8[0] = hipsim::n_launches.load(); out8[1] = hipsim::n_blocks.load(); out8[2] = hipsim::n_divergent.load();
+  for (int i = 0; i < hipsim::C_NUM; i++) out8[3 + i] = hipsim::api_calls[i].load();
 }

@@ -65,6 +65,8 @@ uint64_t wave_collective(int op, int site, uint64_t payload, int src);
 void sync_threads();
 void yield();
 void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure);
+enum { C_MEMCPY = 0, C_MEMSET, C_SYNC, C_LIBCALL, C_MALLOC, C_NUM };
+void count(int what);  // host API calls, for "operations per cloud" bookkeeping (hipsim_counters)
 }  // namespace hipsim
 
 #define threadIdx (hipsim::cur->tid)
@@ -227,31 +229,32 @@ namespace hipsim { hipError_t take_last_error(bool clear); }
 static inline hipError_t hipGetLastError() { return hipsim::take_last_error(true); }
 static inline hipError_t hipPeekAtLastError() { return hipsim::take_last_error(false); }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : e == hipErrorInvalidConfiguration ? "hipErrorInvalidConfiguration (hipsim)" : "hipsim error"; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipMalloc(void** p, size_t n) { hipsim::count(hipsim::C_MALLOC); *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc(reinterpret_cast<void**>(p), n, f); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { hipsim::count(hipsim::C_MEMCPY); if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s, n, k); }
 static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+  hipsim::count(hipsim::C_MEMCPY);
   for (size_t r = 0; r < h; r++) memmove((char*)d + r * dp, (const char*)s + r * sp, w);
   return hipSuccess;
 }
-static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { hipsim::count(hipsim::C_MEMSET); if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipsimStream{1}; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { hipsim::count(hipsim::C_SYNC); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { hipsim::count(hipsim::C_SYNC); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipsimEvent{0.0}; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t_ms = hipsim_now_ms(); return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { hipsim::count(hipsim::C_SYNC); return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }

@@ -17,6 +17,7 @@ struct DeviceSelect {
   template <class In, class Flag, class Out, class Count>
   static hipError_t Flagged(void* tmp, size_t& bytes, In in, Flag flags, Out out, Count num_selected, int n, hipStream_t = nullptr) {
     if (!tmp) { bytes = 256; return hipSuccess; }
+    hipsim::count(hipsim::C_LIBCALL);
     int k = 0;
     for (int i = 0; i < n; i++)
       if (flags[i]) out[k++] = in[i];
@@ -26,6 +27,7 @@ struct DeviceSelect {
   template <class In, class Out, class Count>
   static hipError_t Unique(void* tmp, size_t& bytes, In in, Out out, Count num_selected, int n, hipStream_t = nullptr) {
     if (!tmp) { bytes = 256; return hipSuccess; }
+    hipsim::count(hipsim::C_LIBCALL);
     int k = 0;
     for (int i = 0; i < n; i++)
       if (i == 0 || !(in[i] == in[i - 1])) out[k++] = in[i];
@@ -65,12 +67,14 @@ struct DeviceRadixSort {
   template <class K, class V>
   static hipError_t SortPairs(void* tmp, size_t& bytes, const K* kin, K* kout, const V* vin, V* vout, int n, int b = 0, int e = 8 * sizeof(K), hipStream_t = nullptr) {
     if (!tmp) { bytes = 256; return hipSuccess; }
+    hipsim::count(hipsim::C_LIBCALL);
     detail::sort_pairs(kin, kout, vin, vout, (size_t)n, b, e, false);
     return hipSuccess;
   }
   template <class K, class V>
   static hipError_t SortPairsDescending(void* tmp, size_t& bytes, const K* kin, K* kout, const V* vin, V* vout, int n, int b = 0, int e = 8 * sizeof(K), hipStream_t = nullptr) {
     if (!tmp) { bytes = 256; return hipSuccess; }
+    hipsim::count(hipsim::C_LIBCALL);
     detail::sort_pairs(kin, kout, vin, vout, (size_t)n, b, e, true);
     return hipSuccess;
   }
@@ -84,6 +88,7 @@ template <class Config = default_config, class K, class V>
 static inline hipError_t radix_sort_pairs(void* tmp, size_t& bytes, const K* kin, K* kout, const V* vin, V* vout, size_t n, unsigned b = 0, unsigned e = 8 * sizeof(K),
                                           hipStream_t = nullptr, bool = false) {
   if (!tmp) { bytes = 256; return hipSuccess; }
+    hipsim::count(hipsim::C_LIBCALL);
   hipcub::detail::sort_pairs(kin, kout, vin, vout, n, (int)b, (int)e, false);
   return hipSuccess;
 }

@@ -44,6 +44,7 @@ def make_context(api):
 
 
 def counters(lib):
-    out = (C.c_longlong * 3)()
+    out = (C.c_longlong * 8)()
     lib.hipsim_counters(out)
-    return {"launches": out[0], "workgroups": out[1], "divergent_collectives": out[2]}
+    keys = ("launches", "workgroups", "divergent_collectives", "memcpys", "memsets", "host_syncs", "library_calls", "mallocs")
+    return dict(zip(keys, (int(v) for v in out)))
