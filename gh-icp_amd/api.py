@@ -52,7 +52,7 @@ EXPORTS = [
     "ghicp_register_pairs",
     "ghicp_icp_params_default", "ghicp_cal_overlap", "ghicp_icp", "ghicp_knn_normals", "ghicp_nn_search", "ghicp_inv_transform",
     "ghicp_transform_cloud_f32",
-    "ghicp_cloud_create", "ghicp_cloud_recompute", "ghicp_cloud_from_features", "ghicp_cloud_destroy", "ghicp_cloud_get_info", "ghicp_cloud_download",
+    "ghicp_cloud_create", "ghicp_cloud_recompute", "ghicp_clouds_recompute", "ghicp_cloud_from_features", "ghicp_cloud_destroy", "ghicp_cloud_get_info", "ghicp_cloud_download",
     "ghicp_register_clouds", "ghicp_sbf_write", "ghicp_sbf_read",
 ]
 
@@ -533,7 +533,23 @@ def _register_clouds(self, cfg, pairs):
     return list(stats)
 
 
+def _clouds_recompute(self, clouds, xyzs):
+    """ghicp_clouds_recompute: the front ends of several raw clouds into existing handles (same configuration, this context) with one
+    launch sequence for the whole batch; same results as Cloud.recompute() one by one."""
+    n = len(clouds)
+    if n == 0:
+        return clouds
+    xs = [self._xyz(x) for x in xyzs]
+    assert len(xs) == n and all(x.shape[1] == xs[0].shape[1] for x in xs)
+    H = (C.c_void_p * n)(*[c.h.value for c in clouds])
+    P = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    N = (C.c_int64 * n)(*[x.shape[0] for x in xs])
+    self._check(self.lib.ghicp_clouds_recompute(self.h, n, H, P, N, xs[0].shape[1]))
+    return clouds
+
+
 Context.cloud_create = _cloud_create
+Context.clouds_recompute = _clouds_recompute
 Context.cloud_from_features = _cloud_from_features
 Context.register_clouds = _register_clouds
 

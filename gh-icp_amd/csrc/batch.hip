@@ -1,0 +1,647 @@
+// Batched per-cloud front end (gfx950): nb clouds go through down-sampling, keypoint detection and BSC encoding
+// (test/ghicp_main.cpp:86-127 per cloud) with ONE sequence of launches.
+//
+// Why: one cloud's front end is ~100 device operations (24 kernels, 3 radix sorts, 4 selects, copies, 7 host synchronisations that size
+// the next stage) and the host issues them at ~8 us each, so a cloud costs 0.85 ms however many streams submit clouds.
+// Here the clouds of a batch are CONCATENATED: every elementwise kernel, sort and select runs once over all their points, the kernels
+// that work per cell / per cloud / per keypoint (gh_pca_cell, gh_nms_greedy_cloud, gh_bsc_keypoint -- the same device code as the
+// single-cloud path) look their cloud up in a descriptor block, and the six host synchronisations serve the whole batch.
+//   * voxel keys carry the cloud id above the voxel key's bits  -> one stable radix sort keeps clouds apart and ordered;
+//   * grid cells are numbered globally (cell base of the cloud + cell) -> one sort / one cell table per grid for all clouds;
+//   * NMS ranks: one 64-bit descending sort of all candidates by curvature, then one stable pass over the cloud id.
+// Results are bit-identical to ghicp_cloud_recompute() cloud by cloud: same per-cloud boxes, same grids, same orders inside a cell,
+// same reduction trees (tests/test_gpu_batch.py).
+#include "cloud.h"
+#include "grid.h"
+#include "devmath.h"
+#include "pca_dev.h"
+#include "nms_dev.h"
+#include "bsc_dev.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <vector>
+
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096> GhSortConfig;  // see grid.hip
+
+namespace {
+
+constexpr int FB_MAX = 64;  // clouds per batch
+
+struct FbCloud {
+  const float* xyz;  // raw cloud
+  int n, stride;
+  float vmn[3], vinv;              // voxel filter (filter.hpp:28-40)
+  unsigned long long mul_x, mul_y;
+  float4* ds;                      // outputs: the cloud handle's buffers
+  int* kp;
+  double* kpx;
+  uint8_t* feat;
+};
+
+// Host -> device descriptor block (uploaded once per stage) ...
+struct FbBlock {
+  FbCloud c[FB_MAX];
+  GridDesc g1[FB_MAX], g2[FB_MAX], g3[FB_MAX];  // PCA grid, BSC grid, NMS grid of selected keypoints
+  int roff[FB_MAX + 1];                         // raw points
+  int hoff[FB_MAX + 1];                         // voxel run heads (device written)
+  int moff[FB_MAX + 1];                         // down-sampled points (device written)
+  int coff[FB_MAX + 1];                         // NMS candidates (device written)
+  int koff[FB_MAX + 1];                         // keypoints
+  unsigned cb1[FB_MAX + 1], cb2[FB_MAX + 1], hb[FB_MAX + 1];  // cell bases of the three grids
+  int nb, pad_;
+};
+// ... and what the device reports back
+struct FbOut {
+  int bb[FB_MAX * 6];
+  int hoff[FB_MAX + 1], moff[FB_MAX + 1], coff[FB_MAX + 1];
+  int kcount[FB_MAX];
+};
+
+// largest b in [0, nb) with off[b] <= i (off ascending; clouds without items are skipped over)
+__device__ inline int fb_find(const int* __restrict__ off, int nb, int i) {
+  int lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= i) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+__device__ inline int fb_find_u(const unsigned* __restrict__ off, int nb, unsigned i) {
+  int lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= i) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ void k_fb_bbox_init(int* __restrict__ bb, int nb) {  // enc(+FLT_MAX) x 3, enc(-FLT_MAX) x 3 per cloud
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nb * 6) bb[i] = (i % 6) < 3 ? 0x7f7fffff : (int)0x80800000;
+}
+
+// per-cloud bounding boxes; which = 0: raw clouds, 1: base = concatenated float4 points (moff), 2: base = float3 candidates (coff)
+__global__ __launch_bounds__(256) void k_fb_bbox(const FbBlock* __restrict__ D, const float* __restrict__ base, int which, int* __restrict__ bb) {
+  __shared__ float smin[3][4], smax[3][4];
+  const int b = blockIdx.y;
+  const float* xyz;
+  long long n;
+  int stride;
+  if (which == 0) { xyz = D->c[b].xyz; n = D->c[b].n; stride = D->c[b].stride; }
+  else {
+    const int* off = which == 1 ? D->moff : D->coff;
+    stride = which == 1 ? 4 : 3;
+    xyz = base + (size_t)off[b] * stride;
+    n = off[b + 1] - off[b];
+  }
+  if (n <= 0) return;
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    for (int d = 0; d < 3; d++) { const float v = xyz[i * stride + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+  for (int d = 0; d < 3; d++) {
+    for (int o = 32; o > 0; o >>= 1) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[d][threadIdx.x >> 6] = mn[d]; smax[d][threadIdx.x >> 6] = mx[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    float a = smin[d][0], e = smax[d][0];
+    for (int w = 1; w < 4; w++) { a = fminf(a, smin[d][w]); e = fmaxf(e, smax[d][w]); }
+    auto enc = [](float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; };
+    atomicMin(bb + b * 6 + d, enc(a));
+    atomicMax(bb + b * 6 + 3 + d, enc(e));
+  }
+}
+
+// filter.hpp:57-70 per cloud; the cloud id sits above the voxel key's bits
+__global__ __launch_bounds__(256) void k_fb_voxel_keys(const FbBlock* __restrict__ D, int N, int shift, unsigned long long* __restrict__ keys,
+                                                       unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int b = fb_find(D->roff, D->nb, i);
+  const FbCloud& C = D->c[b];
+  const float* p = C.xyz + (size_t)(i - D->roff[b]) * C.stride;
+  const unsigned long long vx = (unsigned long long)floorf((p[0] - C.vmn[0]) * C.vinv);
+  const unsigned long long vy = (unsigned long long)floorf((p[1] - C.vmn[1]) * C.vinv);
+  const unsigned long long vz = (unsigned long long)floorf((p[2] - C.vmn[2]) * C.vinv);
+  keys[i] = ((unsigned long long)b << shift) | (vx * C.mul_x + vy * C.mul_y + vz);
+  vals[i] = (unsigned)i;
+}
+
+// head of every voxel run whose voxel key > 0 (the run of voxel 0 is the reference's phantom group: filter.hpp:52,66,75-83)
+__global__ __launch_bounds__(256) void k_fb_voxel_flags(const unsigned long long* __restrict__ keys, int N, unsigned long long vmask,
+                                                        unsigned char* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const unsigned long long k = keys[i];
+  flags[i] = ((k & vmask) != 0ull && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+__device__ inline int fb_lower_bound(const int* __restrict__ a, int n, int v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// heads per cloud (sorted positions are grouped by cloud) and the offsets of the down-sampled clouds: heads + the phantom row
+__global__ __launch_bounds__(128) void k_fb_voxel_bounds(const int* __restrict__ headpos, const int* __restrict__ total, FbBlock* D, FbOut* O) {
+  const int nb = D->nb, t = threadIdx.x;
+  if (t <= nb) { const int v = fb_lower_bound(headpos, *total, D->roff[t]); D->hoff[t] = v; O->hoff[t] = v; }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int b = 0; b <= nb; b++) {
+      D->moff[b] = acc; O->moff[b] = acc;
+      if (b < nb) acc += (D->hoff[b + 1] - D->hoff[b]) + (D->c[b].n > 0 ? 1 : 0);
+    }
+  }
+}
+
+// candidates per cloud (ascending global point index)
+__global__ __launch_bounds__(128) void k_fb_cand_bounds(const int* __restrict__ cand, const int* __restrict__ total, FbBlock* D, FbOut* O) {
+  const int t = threadIdx.x;
+  if (t <= D->nb) { const int v = fb_lower_bound(cand, *total, D->moff[t]); D->coff[t] = v; O->coff[t] = v; }
+}
+
+// down-sampled clouds, concatenated: row 0 of a cloud is its raw point 0 (phantom group), then the lowest-index point of every voxel
+__global__ __launch_bounds__(256) void k_fb_gather_ds(const FbBlock* __restrict__ D, const int* __restrict__ headpos, const unsigned* __restrict__ vals2,
+                                                      float4* __restrict__ dsg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nb = D->nb;
+  if (i >= D->moff[nb]) return;
+  const int b = fb_find(D->moff, nb, i), j = i - D->moff[b];
+  const FbCloud& C = D->c[b];
+  const long long s = j == 0 ? 0ll : (long long)vals2[headpos[D->hoff[b] + j - 1]] - D->roff[b];
+  const float* p = C.xyz + (size_t)s * C.stride;
+  dsg[i] = make_float4(p[0], p[1], p[2], 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_fb_cell_keys(const FbBlock* __restrict__ D, int which, const float4* __restrict__ dsg, int M,
+                                                      unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int b = fb_find(D->moff, D->nb, i);
+  const GridDesc& g = which ? D->g2[b] : D->g1[b];
+  const float4 P = dsg[i];
+  const int cx = gh_cell_coord(P.x, g.mn[0], g.inv, g.dim[0]);
+  const int cy = gh_cell_coord(P.y, g.mn[1], g.inv, g.dim[1]);
+  const int cz = gh_cell_coord(P.z, g.mn[2], g.inv, g.dim[2]);
+  keys[i] = (which ? D->cb2[b] : D->cb1[b]) + (((unsigned)cx * g.dim[1] + cy) * g.dim[2] + cz);
+  vals[i] = (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void k_fb_gather_sorted(const float4* __restrict__ dsg, const unsigned* __restrict__ vals, int M, float4* __restrict__ pts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const unsigned s = vals[i];
+  const float4 P = dsg[s];
+  pts[i] = make_float4(P.x, P.y, P.z, __uint_as_float(s));  // w = index into the concatenated cloud
+}
+
+__global__ __launch_bounds__(256) void k_fb_cell_start(const unsigned* __restrict__ keys, unsigned n, unsigned ncell, unsigned* __restrict__ start) {
+  const unsigned c = blockIdx.x * 256u + threadIdx.x;
+  if (c > ncell) return;
+  unsigned lo = 0, hi = n;  // lower_bound(keys, c)
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (keys[mid] < c) lo = mid + 1;
+    else hi = mid;
+  }
+  start[c] = lo;
+}
+
+// pca.hip:k_pca_cells over the occupied cells of all clouds of the batch
+__global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__ D, const float4* __restrict__ pts, const unsigned* __restrict__ start,
+                                                      const unsigned* __restrict__ cells, const int* __restrict__ ncells, int* __restrict__ counter,
+                                                      float r2, float* __restrict__ lambda, double* __restrict__ curvature, int* __restrict__ count) {
+  __shared__ float4 sC[PCA_CHUNK];
+  __shared__ int s_cell;
+  const int lane = threadIdx.x;
+  const int nc = *ncells;
+  for (;;) {
+    if (lane == 0) s_cell = atomicAdd(counter, 1);
+    __syncthreads();
+    const int c = __builtin_amdgcn_readfirstlane(s_cell);
+    __syncthreads();
+    if (c >= nc) break;
+    const unsigned gkey = cells[c];
+    const int b = fb_find_u(D->cb1, D->nb, gkey);
+    GridArgs G;
+    G.d = D->g1[b]; G.pts = pts; G.start = start + D->cb1[b];
+    gh_pca_cell(G, gkey - D->cb1[b], r2, lambda, curvature, count, sC, lane);
+  }
+}
+
+// keypoint_detect.hpp:132-147 (pca.hip:k_prune_flags)
+__global__ __launch_bounds__(256) void k_fb_prune_flags(const float* __restrict__ lambda, const int* __restrict__ count, int m, float ratio_max, int min_n,
+                                                        unsigned char* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const double l1 = (double)lambda[(size_t)i * 3], l2 = (double)lambda[(size_t)i * 3 + 1], l3 = (double)lambda[(size_t)i * 3 + 2];
+  const float r1 = (float)(l2 / l1), r2 = (float)(l3 / l2);
+  flags[i] = (r1 < ratio_max && r2 < ratio_max && count[i] > min_n) ? 1 : 0;
+}
+
+__device__ inline unsigned long long fb_f64_key(double v) {  // order-preserving f64 -> u64 (nms.hip)
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(256) void k_fb_nms_keys(const double* __restrict__ curvature, const int* __restrict__ cand, int c,
+                                                     unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c) return;
+  keys[i] = fb_f64_key(curvature[cand[i]]);
+  vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_fb_cloud_keys(const FbBlock* __restrict__ D, const int* __restrict__ ord, int c, unsigned* __restrict__ ckeys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c) return;
+  ckeys[i] = (unsigned)fb_find(D->coff, D->nb, ord[i]);
+}
+
+// cpts[r] = xyz of the candidate at global rank position r (clouds in order, descending curvature inside a cloud)
+__global__ __launch_bounds__(256) void k_fb_nms_points(const float4* __restrict__ dsg, const int* __restrict__ cand, const int* __restrict__ ord, int c,
+                                                       float* __restrict__ cpts) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= c) return;
+  const float4 P = dsg[cand[ord[r]]];
+  cpts[(size_t)r * 3] = P.x; cpts[(size_t)r * 3 + 1] = P.y; cpts[(size_t)r * 3 + 2] = P.z;
+}
+
+__global__ __launch_bounds__(NMS_T) void k_fb_nms_greedy(const FbBlock* __restrict__ D, const float* __restrict__ cpts, float r2, int* __restrict__ head,
+                                                         int* __restrict__ next, const int* __restrict__ cand, const int* __restrict__ ord,
+                                                         int* __restrict__ kpg, int* __restrict__ kcount) {
+  const int b = blockIdx.x;
+  const int c0 = D->coff[b], c = D->coff[b + 1] - c0;
+  if (c <= 0) {
+    if (threadIdx.x == 0) kcount[b] = 0;
+    return;
+  }
+  gh_nms_greedy_cloud(cpts + (size_t)c0 * 3, c, D->g3[b], r2, head + D->hb[b], next + c0, cand, ord + c0, kpg + c0, kcount + b, D->moff[b]);
+}
+
+__global__ __launch_bounds__(256) void k_fb_copy_ds(const FbBlock* __restrict__ D, const float4* __restrict__ dsg, int M) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int b = fb_find(D->moff, D->nb, i);
+  D->c[b].ds[i - D->moff[b]] = dsg[i];
+}
+
+// keypoint ids, coordinates as f64 (dataio.hpp:609-627) and the LCS origins of the BSC encoder (bfe:146-148)
+__global__ __launch_bounds__(256) void k_fb_keypoints_out(const FbBlock* __restrict__ D, const float4* __restrict__ dsg, const int* __restrict__ kpg, int K,
+                                                          float* __restrict__ lcs) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K) return;
+  const int b = fb_find(D->koff, D->nb, t), j = t - D->koff[b];
+  const int id = kpg[D->coff[b] + j];
+  const float4 P = dsg[D->moff[b] + id];
+  const FbCloud& C = D->c[b];
+  C.kp[j] = id;
+  C.kpx[(size_t)j * 3] = (double)P.x; C.kpx[(size_t)j * 3 + 1] = (double)P.y; C.kpx[(size_t)j * 3 + 2] = (double)P.z;
+  if (lcs) { lcs[(size_t)t * 12 + 9] = P.x; lcs[(size_t)t * 12 + 10] = P.y; lcs[(size_t)t * 12 + 11] = P.z; }
+}
+
+__global__ __launch_bounds__(256) void k_fb_zero_feat(const FbBlock* __restrict__ D, int K) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K * 56) return;
+  const int q = t / 56, r = t % 56, v = r / 14, w = r % 14;
+  const int b = fb_find(D->koff, D->nb, q), j = q - D->koff[b], kb = D->koff[b + 1] - D->koff[b];
+  reinterpret_cast<unsigned*>(D->c[b].feat)[((size_t)v * kb + j) * 14 + w] = 0u;
+}
+
+__global__ __launch_bounds__(BT) void k_fb_bsc(const FbBlock* __restrict__ D, const float4* __restrict__ pts, const unsigned* __restrict__ start, BscConst C,
+                                               float* __restrict__ lcs) {
+  const int q = blockIdx.x;
+  const int b = fb_find(D->koff, D->nb, q);
+  GridArgs G;
+  G.d = D->g2[b]; G.pts = pts; G.start = start + D->cb2[b];
+  gh_bsc_keypoint(G, C, q - D->koff[b], D->koff[b + 1] - D->koff[b], D->c[b].feat, lcs + (size_t)D->koff[b] * 12);
+}
+
+int bits_for(unsigned long long maxv) {
+  int b = 1;
+  while (b < 64 && (maxv >> b) != 0ull) b++;
+  return b;
+}
+
+void decode_box(const int* enc, float* mm) {
+  for (int k = 0; k < 6; k++) {
+    const int i = enc[k] >= 0 ? enc[k] : enc[k] ^ 0x7fffffff;
+    memcpy(&mm[k], &i, 4);
+  }
+}
+
+// one grid of the batch: global cell keys -> stable sort -> points in cell order -> cell table
+int build_grid(ghicp_ctx* ctx, const FbBlock* D, int which, const float4* dsg, int M, unsigned total_cells, const GridSlots& sl, const float4** pts_out,
+               const unsigned** start_out, const unsigned** keys_out) {
+  hipStream_t s = ctx->stream;
+  unsigned *keys, *keys2, *vals, *vals2, *start;
+  float4* pts;
+  GH_TRY(ctx->reserve(sl.keys, (size_t)M + 1, &keys));
+  GH_TRY(ctx->reserve(sl.keys2, (size_t)M + 1, &keys2));
+  GH_TRY(ctx->reserve(sl.vals, (size_t)M + 1, &vals));
+  GH_TRY(ctx->reserve(sl.vals2, (size_t)M + 1, &vals2));
+  GH_TRY(ctx->reserve(sl.start, (size_t)total_cells + 2, &start));
+  GH_TRY(ctx->reserve(sl.pts, (size_t)M + 1, &pts));
+  hipLaunchKernelGGL(k_fb_cell_keys, dim3(cdiv(M, 256)), dim3(256), 0, s, D, which, dsg, M, keys, vals);
+  size_t tb = 0;
+  const int eb = bits_for(total_cells);
+  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, keys, keys2, vals, vals2, (size_t)M, 0u, (unsigned)eb, s)));
+  char* tmp;
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)M, 0u, (unsigned)eb, s)));
+  hipLaunchKernelGGL(k_fb_gather_sorted, dim3(cdiv(M, 256)), dim3(256), 0, s, dsg, vals2, M, pts);
+  hipLaunchKernelGGL(k_fb_cell_start, dim3(cdiv((long long)total_cells + 1, 256)), dim3(256), 0, s, keys2, (unsigned)M, total_cells, start);
+  GH_HIP(hipGetLastError());
+  *pts_out = pts; *start_out = start; *keys_out = keys2;
+  return GHICP_OK;
+}
+
+}  // namespace
+
+// Front ends of n_clouds raw clouds (device pointers xyz[i], n[i] points of `stride` floats) into existing handles of ONE front-end
+// configuration and one context.  Equivalent to ghicp_cloud_recompute(clouds[i], xyz[i], n[i], stride) for every i, bit for bit.
+extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cloud* const* clouds, const float* const* xyz, const int64_t* n, int stride) {
+  GH_ENTER(ctx);
+  GH_ARG(n_clouds >= 0 && (n_clouds == 0 || (clouds != nullptr && xyz != nullptr && n != nullptr)) && stride >= 3);
+  if (n_clouds == 0) return GHICP_OK;
+  long long N = 0;
+  for (int i = 0; i < n_clouds; i++) {
+    GH_ARG(clouds[i] != nullptr && clouds[i]->ctx == ctx && n[i] >= 0 && n[i] < (1ll << 31) - 2);
+    if (!same_front_end(clouds[i]->cfg, clouds[0]->cfg))
+      return ctx->fail(GHICP_ERR_ARG, "ghicp_clouds_recompute: cloud %d has a different front-end configuration", i);
+    for (int j = 0; j < i; j++) GH_ARG(clouds[j] != clouds[i]);
+    N += n[i];
+  }
+  const ghicp_pair_config cfg = clouds[0]->cfg;
+  // what the batch does not cover goes cloud by cloud: FPFH descriptors, no down-sampling, host pointers
+  if (cfg.reg.feature == GHICP_FEATURE_FPFH || !(cfg.voxel > 0.f) || ctx->host_ptrs) {
+    for (int i = 0; i < n_clouds; i++) GH_TRY(ghicp_cloud_recompute(clouds[i], xyz[i], n[i], stride));
+    return GHICP_OK;
+  }
+  if (n_clouds > FB_MAX || N + n_clouds >= (1ll << 31) - 2) {  // split (a single cloud always fits: n < 2^31 - 2)
+    if (n_clouds == 1) return ghicp_cloud_recompute(clouds[0], xyz[0], n[0], stride);
+    const int half = n_clouds / 2;
+    GH_TRY(ghicp_clouds_recompute(ctx, half, clouds, xyz, n, stride));
+    return ghicp_clouds_recompute(ctx, n_clouds - half, clouds + half, xyz + half, n + half, stride);
+  }
+  const int nb = n_clouds;
+  hipStream_t s = ctx->stream;
+  // pinned mirror of the descriptor block and of the report
+  if (!ctx->fb_pinned) {
+    if (hipHostMalloc(&ctx->fb_pinned, sizeof(FbBlock) + sizeof(FbOut) + 256, hipHostMallocDefault) != hipSuccess)
+      return ctx->fail(GHICP_ERR_HIP, "ghicp_clouds_recompute: pinned allocation failed");
+  }
+  FbBlock* H = reinterpret_cast<FbBlock*>(ctx->fb_pinned);
+  FbOut* HO = reinterpret_cast<FbOut*>(reinterpret_cast<char*>(ctx->fb_pinned) + ((sizeof(FbBlock) + 63) / 64) * 64);
+  char* dblock;
+  GH_TRY(ctx->reserve(B_FB_DESC, sizeof(FbBlock) + sizeof(FbOut) + 256, &dblock));
+  FbBlock* D = reinterpret_cast<FbBlock*>(dblock);
+  FbOut* O = reinterpret_cast<FbOut*>(dblock + ((sizeof(FbBlock) + 63) / 64) * 64);
+  memset(H, 0, sizeof(FbBlock));
+  H->nb = nb;
+  for (int b = 0; b < nb; b++) {
+    ghicp_cloud* c = clouds[b];
+    c->n = n[b]; c->m = 0; c->k = 0; c->bbx = 0.f;
+    c->V = cfg.reg.dof > 4 ? 4 : (cfg.reg.dof > 0 ? 2 : 1);
+    H->c[b].xyz = xyz[b]; H->c[b].n = (int)n[b]; H->c[b].stride = stride;
+    H->roff[b + 1] = H->roff[b] + (int)n[b];
+  }
+  if (N == 0) return GHICP_OK;
+  auto upload = [&]() -> hipError_t { return hipMemcpyAsync(D, H, sizeof(FbBlock), hipMemcpyHostToDevice, s); };
+  auto report = [&]() -> hipError_t {
+    hipError_t e = hipMemcpyAsync(HO, O, sizeof(FbOut), hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+  };
+
+  // ------------------------------------------------------------------ boxes of the raw clouds                          (sync 1)
+  GH_HIP(upload());
+  hipLaunchKernelGGL(k_fb_bbox_init, dim3(cdiv(nb * 6, 256)), dim3(256), 0, s, O->bb, nb);
+  hipLaunchKernelGGL(k_fb_bbox, dim3(64, nb), dim3(256), 0, s, (const FbBlock*)D, (const float*)nullptr, 0, O->bb);
+  GH_HIP(report());
+  int ebmax = 1;
+  for (int b = 0; b < nb; b++) {
+    if (n[b] == 0) continue;
+    float mm[6];
+    decode_box(HO->bb + b * 6, mm);
+    FbCloud& C = H->c[b];
+    C.vinv = 1.0f / cfg.voxel;  // filter.hpp:30
+    unsigned long long maxv[3];
+    for (int d = 0; d < 3; d++) {
+      C.vmn[d] = mm[d];
+      const float gap = mm[3 + d] - mm[d];
+      maxv[d] = (unsigned long long)(std::ceil(gap * C.vinv) + 1);  // filter.hpp:38-40
+    }
+    C.mul_x = maxv[1] * maxv[2];
+    C.mul_y = maxv[2];
+    const long double total = (long double)maxv[0] * (long double)maxv[1] * (long double)maxv[2];
+    if (total >= 18446744073709551615.0L) return ctx->fail(GHICP_ERR_CAPACITY, "voxel filter: the number of boxes exceeds the limit");  // filter.hpp:42-46
+    ebmax = std::max(ebmax, bits_for((maxv[0] - 1) * C.mul_x + (maxv[1] - 1) * C.mul_y + (maxv[2] - 1)));
+  }
+  const int cloud_bits = nb > 1 ? bits_for((unsigned long long)nb - 1) : 0;
+  if (ebmax + cloud_bits > 64) {  // no room for the cloud id above the voxel key
+    for (int i = 0; i < n_clouds; i++) GH_TRY(ghicp_cloud_recompute(clouds[i], xyz[i], n[i], stride));
+    return GHICP_OK;
+  }
+
+  // ------------------------------------------------------------------ voxel filter, down-sampled clouds, their boxes    (sync 2)
+  unsigned long long *vkeys, *vkeys2;
+  unsigned *vvals, *vvals2;
+  unsigned char* flags;
+  int *headpos, *misc;
+  float4* dsg;
+  GH_TRY(ctx->reserve(B_GRID_KEYS, (size_t)N * 2 + 2, (unsigned**)&vkeys));
+  GH_TRY(ctx->reserve(B_GRID_KEYS2, (size_t)N * 2 + 2, (unsigned**)&vkeys2));
+  GH_TRY(ctx->reserve(B_GRID_VALS, (size_t)N + 1, &vvals));
+  GH_TRY(ctx->reserve(B_GRID_VALS2, (size_t)N + 1, &vvals2));
+  GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)N + 16, &flags));
+  GH_TRY(ctx->reserve(B_FB_HEADPOS, (size_t)N + 1, &headpos));
+  GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
+  GH_TRY(ctx->reserve(B_FB_DS, (size_t)N + nb + 1, &dsg));
+  GH_HIP(upload());
+  hipLaunchKernelGGL(k_fb_voxel_keys, dim3(cdiv(N, 256)), dim3(256), 0, s, (const FbBlock*)D, (int)N, ebmax, vkeys, vvals);
+  size_t tb = 0, tb2 = 0;
+  hipcub::CountingInputIterator<int> iota(0);
+  const unsigned sort_bits = (unsigned)(ebmax + cloud_bits);
+  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));
+  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, iota, flags, headpos, misc, (int)N, s));
+  char* tmp;
+  GH_TRY(ctx->reserve(B_GRID_TMP, std::max(tb, tb2) + 16, &tmp));
+  hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
+  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));  // stable: lowest index leads its voxel
+  ctx->kt_end(KT_VOXEL_SORT, kev);
+  const unsigned long long vmask = ebmax >= 64 ? ~0ull : ((1ull << ebmax) - 1ull);
+  hipLaunchKernelGGL(k_fb_voxel_flags, dim3(cdiv(N, 256)), dim3(256), 0, s, vkeys2, (int)N, vmask, flags);
+  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, iota, flags, headpos, misc, (int)N, s));
+  hipLaunchKernelGGL(k_fb_voxel_bounds, dim3(1), dim3(128), 0, s, headpos, misc, D, O);
+  hipLaunchKernelGGL(k_fb_gather_ds, dim3(cdiv(N + nb, 256)), dim3(256), 0, s, (const FbBlock*)D, headpos, vvals2, dsg);
+  hipLaunchKernelGGL(k_fb_bbox_init, dim3(cdiv(nb * 6, 256)), dim3(256), 0, s, O->bb, nb);
+  hipLaunchKernelGGL(k_fb_bbox, dim3(64, nb), dim3(256), 0, s, (const FbBlock*)D, reinterpret_cast<const float*>(dsg), 1, O->bb);
+  GH_HIP(hipGetLastError());
+  GH_HIP(report());
+  const float r_pca = cfg.neighborhood_radius, r_nms = cfg.reg.radius_nonmax;
+  BscConst BC;
+  float r_search = 0.f;
+  const bool bsc = cfg.reg.feature == GHICP_FEATURE_BSC;
+  if (bsc) GH_TRY(gh_bsc_make_const(ctx, r_nms, cfg.reg.dof, cfg.pattern, &BC, &r_search));
+  unsigned long long t1 = 0, t2 = 0;
+  for (int b = 0; b <= nb; b++) { H->hoff[b] = HO->hoff[b]; H->moff[b] = HO->moff[b]; }
+  const int M = H->moff[nb];
+  for (int b = 0; b < nb; b++) {
+    ghicp_cloud* c = clouds[b];
+    c->m = H->moff[b + 1] - H->moff[b];
+    float mm[6] = {0, 0, 0, 0, 0, 0};
+    if (c->m > 0) decode_box(HO->bb + b * 6, mm);
+    c->bbx = (float)((double)mm[3] - (double)mm[0] + (double)mm[4] - (double)mm[1] + (double)mm[5] - (double)mm[2]);  // main:91-93
+    H->g1[b] = gh_grid_desc(mm, c->m, r_pca * 1.0001f);
+    H->cb1[b] = (unsigned)t1;
+    t1 += H->g1[b].ncell;
+    if (bsc) {
+      H->g2[b] = gh_grid_desc(mm, c->m, r_search * 1.0001f);
+      H->cb2[b] = (unsigned)t2;
+      t2 += H->g2[b].ncell;
+    }
+  }
+  H->cb1[nb] = (unsigned)t1; H->cb2[nb] = (unsigned)t2;
+  if (t1 >= (1ull << 31) || t2 >= (1ull << 31)) return ctx->fail(GHICP_ERR_CAPACITY, "ghicp_clouds_recompute: the cell tables of the batch exceed 2^31 cells");
+  if (M <= 0) return GHICP_OK;
+
+  // ------------------------------------------------------------------ PCA grid, PCA, prune                              (sync 3)
+  float* lambda;
+  double* curv;
+  int *count, *cand;
+  unsigned* cells;
+  GH_TRY(ctx->reserve(B_FE_LAMBDA, (size_t)M * 3 + 3, &lambda));
+  GH_TRY(ctx->reserve(B_FE_CURV, (size_t)M + 1, &curv));
+  GH_TRY(ctx->reserve(B_FE_COUNT, (size_t)M + 1, &count));
+  GH_TRY(ctx->reserve(B_FE_CAND, (size_t)M + 1, &cand));
+  GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)M * 2 + 2, &cells));
+  GH_HIP(upload());
+  const float4* pts1;
+  const unsigned *start1, *keys1;
+  const GridSlots sl1 = {B_GRID_KEYS, B_GRID_KEYS2, B_GRID_VALS, B_GRID_VALS2, B_GRID_START, B_GRID_PTS};
+  GH_TRY(build_grid(ctx, D, 0, dsg, M, (unsigned)t1, sl1, &pts1, &start1, &keys1));
+  tb = 0;
+  GH_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, keys1, cells, misc, M, s));
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+  GH_HIP(hipcub::DeviceSelect::Unique(tmp, tb, keys1, cells, misc, M, s));
+  GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
+  const float r2_pca = (float)((double)r_pca * (double)r_pca);  // pcl radiusSearch: static_cast<float>(radius*radius)
+  hipEvent_t kt = ctx->kt_begin(KT_PCA);
+  hipLaunchKernelGGL(k_fb_pca_cells, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells, (const int*)misc, misc + 1,
+                     r2_pca, lambda, curv, count);
+  ctx->kt_end(KT_PCA, kt);
+  hipLaunchKernelGGL(k_fb_prune_flags, dim3(cdiv(M, 256)), dim3(256), 0, s, lambda, count, M, cfg.ratio_max, cfg.min_neighbors, flags);
+  tb = 0;
+  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, iota, flags, cand, misc + 2, M, s));
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb, iota, flags, cand, misc + 2, M, s));
+  hipLaunchKernelGGL(k_fb_cand_bounds, dim3(1), dim3(128), 0, s, (const int*)cand, (const int*)(misc + 2), D, O);
+  GH_HIP(hipGetLastError());
+  GH_HIP(report());
+  for (int b = 0; b <= nb; b++) H->coff[b] = HO->coff[b];
+  const int Ctot = H->coff[nb];
+
+  // ------------------------------------------------------------------ NMS: ranks, candidate boxes (sync 4), greedy sweep (sync 5)
+  int* kpg = nullptr;
+  int Ktot = 0;
+  if (Ctot > 0) {
+    unsigned long long *nkeys, *nkeys2;
+    int *nvals, *ord1, *ordg, *next, *head;
+    unsigned *ckeys, *ckeys2;
+    float* cpts;
+    GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)Ctot + 1, &nkeys));  // (the PCA cell list is dead by now; Ctot <= M)
+    GH_TRY(ctx->reserve(B_FE_SORTK2, (size_t)Ctot + 1, &nkeys2));
+    GH_TRY(ctx->reserve(B_FE_SORTV, (size_t)Ctot + 1, &nvals));
+    GH_TRY(ctx->reserve(B_FE_SORTV2, (size_t)Ctot + 1, &ord1));
+    GH_TRY(ctx->reserve(B_FB_ORD, (size_t)Ctot + 1, &ordg));
+    GH_TRY(ctx->reserve(B_FE_STATE, (size_t)Ctot + 1, &next));
+    GH_TRY(ctx->reserve(B_FE_CPTS, (size_t)Ctot * 3 + 3, &cpts));
+    GH_TRY(ctx->reserve(B_FE_KP, (size_t)Ctot + 1, &kpg));
+    GH_TRY(ctx->reserve(B_GRID2_KEYS, (size_t)std::max(Ctot, M) + 1, &ckeys));   // grid 2 is built after the sweep: its buffers are free here
+    GH_TRY(ctx->reserve(B_GRID2_KEYS2, (size_t)std::max(Ctot, M) + 1, &ckeys2));
+    hipLaunchKernelGGL(k_fb_nms_keys, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const double*)curv, (const int*)cand, Ctot, nkeys, nvals);
+    tb = 0; tb2 = 0;
+    GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, nkeys, nkeys2, nvals, ord1, Ctot, 0, 64, s));
+    if (nb > 1) GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb2, ckeys, ckeys2, ord1, ordg, (size_t)Ctot, 0u, (unsigned)cloud_bits, s)));
+    GH_TRY(ctx->reserve(B_GRID_TMP, std::max(tb, tb2) + 16, &tmp));
+    GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, nkeys, nkeys2, nvals, ord1, Ctot, 0, 64, s));  // stable: ties -> lower point index
+    if (nb > 1) {
+      hipLaunchKernelGGL(k_fb_cloud_keys, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const FbBlock*)D, (const int*)ord1, Ctot, ckeys);
+      GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb2, ckeys, ckeys2, ord1, ordg, (size_t)Ctot, 0u, (unsigned)cloud_bits, s)));  // stable
+    } else {
+      ordg = ord1;
+    }
+    hipLaunchKernelGGL(k_fb_nms_points, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const float4*)dsg, (const int*)cand, (const int*)ordg, Ctot, cpts);
+    hipLaunchKernelGGL(k_fb_bbox_init, dim3(cdiv(nb * 6, 256)), dim3(256), 0, s, O->bb, nb);
+    hipLaunchKernelGGL(k_fb_bbox, dim3(16, nb), dim3(256), 0, s, (const FbBlock*)D, (const float*)cpts, 2, O->bb);
+    GH_HIP(hipGetLastError());
+    GH_HIP(report());
+    unsigned long long t3 = 0;
+    for (int b = 0; b < nb; b++) {
+      const int cb = H->coff[b + 1] - H->coff[b];
+      float mm[6] = {0, 0, 0, 0, 0, 0};
+      if (cb > 0) decode_box(HO->bb + b * 6, mm);
+      H->g3[b] = gh_grid_desc(mm, cb, r_nms * 1.0001f);
+      H->hb[b] = (unsigned)t3;
+      if (cb > 0) t3 += H->g3[b].ncell;
+    }
+    H->hb[nb] = (unsigned)t3;
+    if (t3 >= (1ull << 31)) return ctx->fail(GHICP_ERR_CAPACITY, "ghicp_clouds_recompute: the NMS cell tables of the batch exceed 2^31 cells");
+    GH_TRY(ctx->reserve(B_GRID_START, (size_t)std::max<unsigned long long>(t3, t1) + 2, &head));  // the PCA cell table is dead by now
+    GH_HIP(hipMemsetAsync(head, 0xff, (size_t)t3 * sizeof(int), s));
+    GH_HIP(upload());
+    const float r2_nms = (float)((double)r_nms * (double)r_nms);
+    hipEvent_t kn = ctx->kt_begin(KT_NMS_ROUND);
+    hipLaunchKernelGGL(k_fb_nms_greedy, dim3(nb), dim3(NMS_T), 0, s, (const FbBlock*)D, (const float*)cpts, r2_nms, head, next, (const int*)cand,
+                       (const int*)ordg, kpg, O->kcount);
+    ctx->kt_end(KT_NMS_ROUND, kn);
+    GH_HIP(hipGetLastError());
+    GH_HIP(report());
+    for (int b = 0; b < nb; b++) {
+      clouds[b]->k = HO->kcount[b];
+      H->koff[b + 1] = H->koff[b] + HO->kcount[b];
+    }
+    Ktot = H->koff[nb];
+  }
+
+  // ------------------------------------------------------------------ outputs into the handles, BSC                     (sync 6)
+  for (int b = 0; b < nb; b++) {
+    ghicp_cloud* c = clouds[b];
+    GH_HIP(c->ds.reserve(((size_t)c->m + 1) * sizeof(float4)));
+    GH_HIP(c->kp.reserve(((size_t)c->m + 1) * sizeof(int)));
+    GH_HIP(c->kpx.reserve(((size_t)c->k * 3 + 3) * sizeof(double)));
+    if (bsc) GH_HIP(c->feat.reserve((size_t)4 * c->k * 56 + 64));
+    H->c[b].ds = c->ds.as<float4>(); H->c[b].kp = c->kp.as<int>(); H->c[b].kpx = c->kpx.as<double>(); H->c[b].feat = c->feat.as<uint8_t>();
+  }
+  GH_HIP(upload());
+  hipLaunchKernelGGL(k_fb_copy_ds, dim3(cdiv(M, 256)), dim3(256), 0, s, (const FbBlock*)D, (const float4*)dsg, M);
+  if (Ktot > 0) {
+    float* lcs = nullptr;
+    if (bsc) GH_TRY(ctx->reserve(B_P_LCS, (size_t)Ktot * 12 + 12, &lcs));
+    hipLaunchKernelGGL(k_fb_keypoints_out, dim3(cdiv(Ktot, 256)), dim3(256), 0, s, (const FbBlock*)D, (const float4*)dsg, (const int*)kpg, Ktot, lcs);
+    if (bsc) {
+      const float4* pts2;
+      const unsigned *start2, *keys2;
+      const GridSlots sl2 = {B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS};
+      GH_TRY(build_grid(ctx, D, 1, dsg, M, (unsigned)t2, sl2, &pts2, &start2, &keys2));
+      hipLaunchKernelGGL(k_fb_zero_feat, dim3(cdiv((long long)Ktot * 56, 256)), dim3(256), 0, s, (const FbBlock*)D, Ktot);
+      hipEvent_t kb = ctx->kt_begin(KT_BSC);
+      hipLaunchKernelGGL(k_fb_bsc, dim3((unsigned)Ktot), dim3(BT), 0, s, (const FbBlock*)D, pts2, start2, BC, lcs);
+      ctx->kt_end(KT_BSC, kb);
+    }
+  }
+  GH_HIP(hipGetLastError());
+  GH_HIP(hipStreamSynchronize(s));
+  return GHICP_OK;
+}

@@ -31,15 +31,13 @@ __global__ __launch_bounds__(256) void k_bsc_origins(const float* __restrict__ x
 
 }  // namespace
 
-int gh_bsc_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, const int32_t* kp, long long K, float R, int dof, const int32_t* pattern_host,
-               uint8_t* feat, float* lcs) {
-  if (K <= 0) return GHICP_OK;
-  hipStream_t s = ctx->stream;
+// the constants of BSCEncoder(R, 7) (bfe:63-73) and of one extractBinaryFeatures call; r_search = sqrt(3) R as float (bfe:641)
+int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_host, BscConst* out, float* r_search) {
   BscConst C;
   memset(&C, 0, sizeof(C));
   C.R = R;
-  const double r_search = std::sqrt(3.0) * (double)R;  // bfe:641
-  C.r2s = (float)(r_search * r_search);
+  const double rs = std::sqrt(3.0) * (double)R;  // bfe:641
+  C.r2s = (float)(rs * rs);
   C.u = 2 * R / 7;                                      // bfe:71
   const float delta = (float)(C.u * 0.5);               // bfe:204
   C.den = 2 * delta * delta;                            // bfe:239
@@ -51,11 +49,24 @@ int gh_bsc_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, const 
     C.pattern[i] = pattern_host[i];
     if (C.pattern[i] < 0 || C.pattern[i] > 48) return ctx->fail(GHICP_ERR_ARG, "BSC sample pattern entry %d out of [0,48]", i);
   }
-  C.K = (int)K;
+  C.K = 0;
   C.nvar = (dof > 4) ? 4 : (dof > 0 ? 2 : 1);  // bfe:648-660
+  *out = C;
+  *r_search = (float)rs;
+  return GHICP_OK;
+}
+
+int gh_bsc_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, const int32_t* kp, long long K, float R, int dof, const int32_t* pattern_host,
+               uint8_t* feat, float* lcs) {
+  if (K <= 0) return GHICP_OK;
+  hipStream_t s = ctx->stream;
+  BscConst C;
+  float r_search_f = 0.f;
+  GH_TRY(gh_bsc_make_const(ctx, R, dof, pattern_host, &C, &r_search_f));
+  C.K = (int)K;
   DeviceGrid G;
   const GridSlots sl = {B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS};
-  GH_TRY(gh_grid_build(ctx, xyz, m, stride, (float)r_search * 1.0001f, sl, &G));
+  GH_TRY(gh_grid_build(ctx, xyz, m, stride, r_search_f * 1.0001f, sl, &G));
   GH_HIP(hipMemsetAsync(feat, 0, (size_t)4 * K * 56, s));
   hipLaunchKernelGGL(k_bsc_origins, dim3(cdiv(K, 256)), dim3(256), 0, s, xyz, stride, kp, (int)K, lcs);
   GridArgs A = {G.d, G.pts, G.start};

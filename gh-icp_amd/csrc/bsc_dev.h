@@ -14,6 +14,8 @@ struct BscConst {
 
 constexpr int BT = 256;
 
+int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_host, BscConst* out, float* r_search);  // bsc.hip
+
 __device__ inline int rearr_src(int type, int k) {  // bfe:700-739
   switch (type) {
     case 1: return 48 - k;

@@ -6,7 +6,7 @@
 // ghicp_sbf_write / ghicp_sbf_read speak the reference's dump format (StereoBinaryFeature::writeFeatures /
 // readFeatures, src/stereo_binary_feature.cpp:107-148) so a cache can live on disk and come back through
 // ghicp_cloud_from_features().
-#include "ctx.h"
+#include "cloud.h"
 
 #include <cstdio>
 
@@ -19,18 +19,6 @@ int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float
 int gh_fpfh_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float* normals_opt, float* hist);
 int gh_gather_rows33_dev(ghicp_ctx* ctx, const float* hist, const int32_t* idx, long long k, float* out);
 int gh_fd_fpfh_dev(ghicp_ctx* ctx, const float* histS, int ks, const float* histT, int kt, float* FD);
-
-struct ghicp_cloud {
-  ghicp_ctx* ctx = nullptr;
-  ghicp_pair_config cfg;
-  long long n = 0, m = 0, k = 0;
-  float bbx = 0.f;
-  int V = 1;
-  DevBuf ds;    // m float4 (down-sampled points; empty for handles rebuilt from stored features)
-  DevBuf kp;    // k int32: keypoint ids into ds
-  DevBuf kpx;   // k x 3 f64
-  DevBuf feat;  // BSC: 4 x k x 56 bytes (variants 0..V-1 filled) | FPFH: k x 33 f32 | None: empty
-};
 
 namespace {
 
@@ -47,12 +35,6 @@ __global__ __launch_bounds__(256) void k_cl_kpxyz(const float4* __restrict__ pts
   if (i >= k) return;
   const float4 p = pts[kp[i]];
   out[i * 3] = (double)p.x; out[i * 3 + 1] = (double)p.y; out[i * 3 + 2] = (double)p.z;
-}
-
-bool same_front_end(const ghicp_pair_config& a, const ghicp_pair_config& b) {
-  return a.reg.feature == b.reg.feature && a.reg.dof == b.reg.dof && a.reg.radius_nonmax == b.reg.radius_nonmax && a.voxel == b.voxel &&
-         a.neighborhood_radius == b.neighborhood_radius && a.ratio_max == b.ratio_max && a.min_neighbors == b.min_neighbors &&
-         (a.reg.feature != GHICP_FEATURE_BSC || memcmp(a.pattern, b.pattern, sizeof(a.pattern)) == 0);
 }
 
 }  // namespace

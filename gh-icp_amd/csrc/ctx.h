@@ -71,6 +71,8 @@ enum BufSlot {
   B_P_KEEP_S, B_P_KEEP_T, B_P_DS_S, B_P_DS_T, B_P_KP_S, B_P_KP_T, B_P_KPXYZ_S, B_P_KPXYZ_T, B_P_FEAT_S, B_P_FEAT_T, B_P_LCS,
   B_P_FD, B_P_MISC, B_P_PATTERN,
   B_KM_LX, B_KM_MISC, B_KM_SLACK, B_KM_LSTAT, B_KM_ORDER,
+  // batched front end (batch.hip)
+  B_FB_DESC, B_FB_HEADPOS, B_FB_DS, B_FB_ORD,
   // fine registration (icp.hip): coarse target grid, source grids (reciprocal), per-point state
   B_ICP_TC_KEYS, B_ICP_TC_KEYS2, B_ICP_TC_VALS, B_ICP_TC_VALS2, B_ICP_TC_START, B_ICP_TC_PTS,
   B_ICP_SC_KEYS, B_ICP_SC_KEYS2, B_ICP_SC_VALS, B_ICP_SC_VALS2, B_ICP_SC_START, B_ICP_SC_PTS,
@@ -140,6 +142,7 @@ struct ghicp_ctx {
   DevBuf buf[B_NUM];
   std::vector<DevBuf> pairbuf;  // per-pair outputs of the front end (batched API): 3 per pair slot
   void* pinned = nullptr;  // small pinned host scratch
+  void* fb_pinned = nullptr;  // descriptor block + report of the batched front end (batch.hip)
   size_t pinned_cap = 0;
   int num_cu = 256;
 

@@ -52,6 +52,7 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
   for (auto& b : ctx->pairbuf) b.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->fb_pinned) (void)hipHostFree(ctx->fb_pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return GHICP_OK;

@@ -5,6 +5,8 @@
 #pragma once
 #include "ctx.h"
 
+#include <cmath>
+
 struct GridDesc {
   float mn[3];
   float inv;       // 1 / cell
@@ -26,6 +28,34 @@ struct GridArgs {
   const float4* pts;
   const unsigned* start;
 };
+
+// Cell table over the box mm[0..2] .. mm[3..5] for a search radius `cell` (callers pass radius * 1.0001).  The float rounding of
+// (v - mn) * inv grows with the cell coordinate (ulp(1000) = 6e-5), so beyond a few hundred cells per axis the margin is widened with
+// the extent: two points closer than the radius never end up two cells apart (below 256 cells the cell size -- and with it every
+// enumeration order -- is what it always was).  Then the cell is coarsened until the dense table is affordable (a larger cell is
+// still exact: superset search).
+inline GridDesc gh_grid_desc(const float* mm, long long n, float cell) {
+  GridDesc g;
+  memset(&g, 0, sizeof(g));
+  g.n = (int)n;
+  float ext = 0.f;
+  for (int d = 0; d < 3; d++) ext = ext > mm[3 + d] - mm[d] ? ext : mm[3 + d] - mm[d];
+  const float dims = ext / cell;
+  if (dims > 256.f) cell *= 1.0f + 4e-7f * dims;
+  for (;;) {
+    g.inv = 1.0f / cell;
+    unsigned long long nc = 1;
+    for (int d = 0; d < 3; d++) {
+      g.mn[d] = mm[d];
+      g.dim[d] = (int)floorf((mm[3 + d] - mm[d]) * g.inv) + 1;
+      if (g.dim[d] < 1) g.dim[d] = 1;
+      nc *= (unsigned long long)g.dim[d];
+    }
+    if (nc <= (1ull << 26)) { g.ncell = (unsigned)nc; break; }
+    cell *= 1.5f;
+  }
+  return g;
+}
 
 struct GridSlots {
   BufSlot keys, keys2, vals, vals2, start, pts;

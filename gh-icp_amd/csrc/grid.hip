@@ -57,31 +57,9 @@ static int bits_for(unsigned long long maxv) {
 
 int gh_grid_build(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float cell, const GridSlots& sl, DeviceGrid* out) {
   hipStream_t s = ctx->stream;
-  GridDesc g;
-  memset(&g, 0, sizeof(g));
-  g.n = (int)n;
   float mm[6] = {0, 0, 0, 0, 0, 0};
   if (n > 0) GH_TRY(gh_bbox_dev(ctx, xyz, n, stride, mm));
-  {  // Callers pass radius * 1.0001; the float rounding of (v - mn) * inv grows with the cell coordinate (ulp(1000) = 6e-5), so beyond
-     // a few hundred cells per axis the margin is widened with the extent: two points closer than the radius never end up two
-     // cells apart.  (Below 256 cells the cell size -- and with it every enumeration order -- is what it always was.)
-    float ext = 0.f;
-    for (int d = 0; d < 3; d++) ext = std::max(ext, mm[3 + d] - mm[d]);
-    const float dims = ext / cell;
-    if (dims > 256.f) cell *= 1.0f + 4e-7f * dims;
-  }
-  for (;;) {  // coarsen until the dense cell table is affordable (a larger cell is still exact: superset search)
-    g.inv = 1.0f / cell;
-    unsigned long long nc = 1;
-    for (int d = 0; d < 3; d++) {
-      g.mn[d] = mm[d];
-      g.dim[d] = (int)std::floor((mm[3 + d] - mm[d]) * g.inv) + 1;
-      if (g.dim[d] < 1) g.dim[d] = 1;
-      nc *= (unsigned long long)g.dim[d];
-    }
-    if (nc <= (1ull << 26)) { g.ncell = (unsigned)nc; break; }
-    cell *= 1.5f;
-  }
+  const GridDesc g = gh_grid_desc(mm, n, cell);
   unsigned *keys, *keys2, *vals, *vals2, *start;
   float4* pts;
   GH_TRY(ctx->reserve(sl.keys, (size_t)n + 1, &keys));

@@ -146,28 +146,7 @@ int gh_nms_dev(ghicp_ctx* ctx, const float* xyz, int stride, const double* curva
     // ---- single-launch exact greedy NMS over a grid of SELECTED keypoints
     float mm[6];
     GH_TRY(gh_bbox_dev(ctx, cpts, c, 3, mm));
-    GridDesc g;
-    memset(&g, 0, sizeof(g));
-    float cell = radius * 1.0001f;
-    {  // same extent-dependent margin as gh_grid_build
-      float ext = 0.f;
-      for (int d = 0; d < 3; d++) ext = std::max(ext, mm[3 + d] - mm[d]);
-      const float dims = ext / cell;
-      if (dims > 256.f) cell *= 1.0f + 4e-7f * dims;
-    }
-    for (;;) {
-      g.inv = 1.0f / cell;
-      unsigned long long nc = 1;
-      for (int d = 0; d < 3; d++) {
-        g.mn[d] = mm[d];
-        g.dim[d] = (int)std::floor((mm[3 + d] - mm[d]) * g.inv) + 1;
-        if (g.dim[d] < 1) g.dim[d] = 1;
-        nc *= (unsigned long long)g.dim[d];
-      }
-      if (nc <= (1ull << 26)) { g.ncell = (unsigned)nc; break; }
-      cell *= 1.5f;
-    }
-    g.n = (int)c;
+    const GridDesc g = gh_grid_desc(mm, c, radius * 1.0001f);
     int *head, *next;
     GH_TRY(ctx->reserve(B_GRID_START, (size_t)g.ncell + 2, &head));
     GH_TRY(ctx->reserve(B_FE_STATE, (size_t)c + 1, &next));

@@ -280,6 +280,12 @@ int ghicp_cloud_from_features(ghicp_ctx* ctx, const ghicp_pair_config* cfg, cons
  * allocation in a steady-state pipeline).  Handles are synchronised when these calls return and may then be passed to
  * ghicp_register_clouds of ANY context on the same device. */
 int ghicp_cloud_recompute(ghicp_cloud* cloud, const float* xyz, int64_t n, int stride);
+/* The front ends of n_clouds raw clouds [device pointers xyz[i], n[i] points of `stride` floats] into existing handles of ONE
+ * front-end configuration, in one sequence of launches for the whole batch (one radix sort, one cell table, one select ... for all the
+ * clouds).  Same results as ghicp_cloud_recompute(clouds[i], xyz[i], n[i], stride) for every i, bit for bit.  (The reference has no
+ * counterpart: test/ghicp_main.cpp:86-127 runs the front end once per cloud.) */
+int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cloud* const* clouds, const float* const* xyz /*[host] array of device pointers*/,
+                           const int64_t* n /*[host]*/, int stride);
 int ghicp_cloud_destroy(ghicp_cloud* cloud);
 int ghicp_cloud_get_info(const ghicp_cloud* cloud, ghicp_cloud_info* info /*[host]*/);
 /* any destination may be NULL: ds_xyz m x 3 f32, kp_idx k, kp_xyz k x 3 f64, feat feature_bytes */
