@@ -125,6 +125,7 @@ def main():
                     "to its slowly converging pairs (ghicp_ctx_loop_progress), so the long tail of a step overlaps the next step's work")
     ap.add_argument("--tail-fraction", type=float, default=0.2, help="--pipeline 2: a group is in its tail when this fraction of its pairs is still iterating")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU (oracle) legs and the parity check")
+    ap.add_argument("--fe-batch", type=int, default=0, help="clouds per batched front-end launch sequence (ghicp_clouds_recompute; 0/1 = cloud by cloud)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(distinct, host CPUs))")
     args = ap.parse_args()
     CF = CONFIGS[args.config]
@@ -218,36 +219,53 @@ def main():
                 c = fe_ctxs[w]
                 for k in range(K):
                     buf = pool_h[k % NBUF]
-                    for i in range(w, nb, nstream):
-                        g = int(group_of[i])
-                        if not args.pipeline and k >= 1:  # strict schedule: the front ends of a step start when the previous step is complete
-                            with cv:
-                                cv.wait_for(lambda: all(done[k - 1]) or err)
-                        elif args.pipeline == 2 and k >= 1:
-                            # tail overlap: start when every group of the previous step is done or down to its slowly converging pairs
-                            # (while most pairs still iterate, the Kuhn-Munkres workgroups hold the CUs' LDS and front-end kernels starve)
-                            while not err:
+                    mine_w = list(range(w, nb, nstream))
+                    per = max(1, args.fe_batch // 2) if args.fe_batch > 1 else 1   # pairs per front-end launch sequence
+                    for c0 in range(0, len(mine_w), per):
+                        chunk = mine_w[c0:c0 + per]
+                        for i in chunk:
+                            g = int(group_of[i])
+                            if not args.pipeline and k >= 1:  # strict schedule: the front ends of a step start when the previous step is complete
                                 with cv:
-                                    ok = all(done[k - 1][gg] or (started[k - 1][gg] and tail_reached(k - 1, gg)) for gg in range(G))
-                                    if ok and k >= NBUF:
-                                        ok = done[k - NBUF][g]
-                                if ok:
-                                    break
-                                time.sleep(0.005)
-                        elif k >= NBUF:
-                            with cv:
-                                cv.wait_for(lambda: done[k - NBUF][g] or err)
+                                    cv.wait_for(lambda: all(done[k - 1]) or err)
+                            elif args.pipeline == 2 and k >= 1:
+                                # tail overlap: start when every group of the previous step is done or down to its slowly converging pairs
+                                # (while most pairs still iterate, the Kuhn-Munkres workgroups hold the CUs' LDS and front-end kernels starve)
+                                while not err:
+                                    with cv:
+                                        ok = all(done[k - 1][gg] or (started[k - 1][gg] and tail_reached(k - 1, gg)) for gg in range(G))
+                                        if ok and k >= NBUF:
+                                            ok = done[k - NBUF][g]
+                                    if ok:
+                                        break
+                                    time.sleep(0.005)
+                            elif k >= NBUF:
+                                with cv:
+                                    cv.wait_for(lambda: done[k - NBUF][g] or err)
                         t = time.perf_counter()
-                        S, T = dev[manifest[mine[i]]]
-                        if buf[i] is None:
-                            buf[i] = (c.cloud_create(cfg, S), c.cloud_create(cfg, T))
+                        if args.fe_batch > 1:
+                            # batched front end (ghicp_clouds_recompute): one launch sequence for the 2 * len(chunk) clouds of the chunk
+                            hs, raws = [], []
+                            for i in chunk:
+                                S, T = dev[manifest[mine[i]]]
+                                if buf[i] is None:
+                                    buf[i] = (c.cloud_create(cfg, S[:1]), c.cloud_create(cfg, T[:1]))
+                                hs += [buf[i][0], buf[i][1]]
+                                raws += [S, T]
+                            c.clouds_recompute(hs, raws)
                         else:
-                            buf[i][0].recompute(S)
-                            buf[i][1].recompute(T)
+                            for i in chunk:
+                                S, T = dev[manifest[mine[i]]]
+                                if buf[i] is None:
+                                    buf[i] = (c.cloud_create(cfg, S), c.cloud_create(cfg, T))
+                                else:
+                                    buf[i][0].recompute(S)
+                                    buf[i][1].recompute(T)
                         dt = time.perf_counter() - t
                         with cv:
                             thread_busy["front_end"] += dt
-                            ready[k][g] += 1
+                            for i in chunk:
+                                ready[k][int(group_of[i])] += 1
                             cv.notify_all()
             except Exception as e:  # noqa: BLE001
                 with cv:
@@ -463,10 +481,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": CF["scaling"], "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s, voxel %g m, r_pca %g, R_nms %g, %s + %s, %d-DoF; %d %s scenes per GPU cycled over %d pairs per step%s; "
-                               "%d front-end streams, then %d concurrent batched loop groups; pair manifest broadcast + one result all-gather per step"
+                               "%d front-end streams (%s), then %d concurrent batched loop groups; pair manifest broadcast + one result all-gather per step"
                                % (CF["name"], CF["voxel"], CF["r"], CF["R"], CF["feature"], CF["corr"], CF["dof"], len(by_scene), "distinct",
-                                  nb, " (whole job: %d, sharded over the ranks)" % n_job if strong else " per GPU", nstream, G),
-                   "config_id": args.config, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene), "raw_cloud_bytes_resident": int(sum(s.numel() * 4 + t.numel() * 4 for s, t in dev.values())),
+                                  nb, " (whole job: %d, sharded over the ranks)" % n_job if strong else " per GPU", nstream,
+                                  "%d clouds per batched launch sequence" % args.fe_batch if args.fe_batch > 1 else "cloud by cloud", G),
+                   "config_id": args.config, "fe_batch": args.fe_batch, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene), "raw_cloud_bytes_resident": int(sum(s.numel() * 4 + t.numel() * 4 for s, t in dev.values())),
                    "n_s": int(sts[0].n_s), "m_mean": round(m_mean), "k_mean": round(k_mean, 1), "n_km_max": int(max(max(s.k_s, s.k_t) for s in sts)),
                    "iterations_mean": round(it_mean, 1), "iterations_min_max": [int(min(s.iterations for s in sts)), int(max(s.iterations for s in sts))],
                    "parallelism": "pairs sharded over ranks (pair p -> rank p mod R), no data-path collective"},
