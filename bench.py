@@ -125,7 +125,10 @@ def main():
                     "to its slowly converging pairs (ghicp_ctx_loop_progress), so the long tail of a step overlaps the next step's work")
     ap.add_argument("--tail-fraction", type=float, default=0.2, help="--pipeline 2: a group is in its tail when this fraction of its pairs is still iterating")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU (oracle) legs and the parity check")
-    ap.add_argument("--fe-batch", type=int, default=0, help="clouds per batched front-end launch sequence (ghicp_clouds_recompute; 0/1 = cloud by cloud)")
+    ap.add_argument("--fe-batch", type=int, default=-1, help="clouds per batched front-end launch sequence (ghicp_clouds_recompute); 0/1 = cloud by cloud; "
+                    "-1 = calibrate: time both front ends on a sample before the warm-up and use the faster one")
+    ap.add_argument("--fe-batch-size", type=int, default=32, help="clouds per launch sequence when --fe-batch -1 picks the batched front end")
+    ap.add_argument("--fe-batch-streams", type=int, default=4, help="worker contexts of the batched front end")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(distinct, host CPUs))")
     args = ap.parse_args()
     CF = CONFIGS[args.config]
@@ -185,6 +188,77 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(nstream + G * LP)]
     ctxs = [api.Context(local_rank, stream=s) for s in streams]
     fe_ctxs, loop_ctxs = ctxs[:nstream], ctxs[nstream:]
+    # ---- which front end: cloud by cloud on `nstream` streams, or ghicp_clouds_recompute batches on a few.  Both give the same bits
+    # (tests/test_gpu_batch.py); the choice is a throughput calibration on a sample of this rank's pairs, before the warm-up.
+    def fe_sample_rate(batch, nthreads, sample):
+        """clouds/s of the front end alone: the sample's pairs over nthreads worker contexts, second of two passes timed"""
+        hs = {}
+        bar = threading.Barrier(nthreads + 1)
+        errs = []
+
+        def work(w):
+            try:
+                c = fe_ctxs[w]
+                mine_w = sample[w::nthreads]
+                for i in mine_w:
+                    S, T = dev[manifest[mine[i]]]
+                    hs[i] = (c.cloud_create(cfg, S[:0]), c.cloud_create(cfg, T[:0]))
+                for rep in range(2):
+                    if rep == 1:
+                        c.sync()
+                        bar.wait()
+                    if batch > 1:
+                        per = max(1, batch // 2)
+                        for c0 in range(0, len(mine_w), per):
+                            chunk = mine_w[c0:c0 + per]
+                            c.clouds_recompute([h for i in chunk for h in hs[i]], [x for i in chunk for x in dev[manifest[mine[i]]]])
+                    else:
+                        for i in mine_w:
+                            S, T = dev[manifest[mine[i]]]
+                            hs[i][0].recompute(S)
+                            hs[i][1].recompute(T)
+                c.sync()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+                bar.abort()
+
+        tw = [threading.Thread(target=work, args=(w,)) for w in range(nthreads)]
+        for x in tw:
+            x.start()
+        try:
+            bar.wait()
+        except threading.BrokenBarrierError:
+            pass
+        t = time.perf_counter()
+        for x in tw:
+            x.join()
+        dt = time.perf_counter() - t
+        for a, b in hs.values():
+            a.close()
+            b.close()
+        if errs:
+            raise errs[0]
+        return 2 * len(sample) / dt
+
+    fe_cal = None
+    if args.fe_batch < 0:
+        fe_cal = {"sample_pairs": min(nb, 64)}
+        sample = list(range(min(nb, 64)))
+        if feature == api.FEATURE_FPFH or nb == 0:
+            args.fe_batch = 0  # the batched front end covers BSC / no descriptors
+            fe_cal["chosen"] = "cloud by cloud (FPFH descriptors are not batched)"
+        else:
+            try:
+                fe_cal["cloud_by_cloud_clouds_per_s"] = round(fe_sample_rate(0, nstream, sample), 1)
+                fe_cal["batched_clouds_per_s"] = round(fe_sample_rate(args.fe_batch_size, min(nstream, args.fe_batch_streams), sample), 1)
+                args.fe_batch = args.fe_batch_size if fe_cal["batched_clouds_per_s"] > fe_cal["cloud_by_cloud_clouds_per_s"] else 0
+            except Exception as e:  # noqa: BLE001
+                fe_cal["error"] = repr(e)[:300]
+                args.fe_batch = 0
+            fe_cal["chosen"] = "%d clouds per launch sequence on %d streams" % (args.fe_batch, min(nstream, args.fe_batch_streams)) if args.fe_batch > 1 else "cloud by cloud on %d streams" % nstream
+        torch.cuda.synchronize()
+    fe_n = min(nstream, args.fe_batch_streams) if args.fe_batch > 1 else nstream  # front-end worker threads
+
     # Schedule of a step: every front end (16 worker streams), then the G batched loops concurrently.  `--pipeline 1` removes the
     # barriers (a group's loop starts when ITS front ends are done, groups of consecutive steps overlap, two sets of cloud handles).
     NBUF = 2 if args.pipeline else 1
@@ -219,7 +293,7 @@ def main():
                 c = fe_ctxs[w]
                 for k in range(K):
                     buf = pool_h[k % NBUF]
-                    mine_w = list(range(w, nb, nstream))
+                    mine_w = list(range(w, nb, fe_n))
                     per = max(1, args.fe_batch // 2) if args.fe_batch > 1 else 1   # pairs per front-end launch sequence
                     for c0 in range(0, len(mine_w), per):
                         chunk = mine_w[c0:c0 + per]
@@ -249,7 +323,7 @@ def main():
                             for i in chunk:
                                 S, T = dev[manifest[mine[i]]]
                                 if buf[i] is None:
-                                    buf[i] = (c.cloud_create(cfg, S[:1]), c.cloud_create(cfg, T[:1]))
+                                    buf[i] = (c.cloud_create(cfg, S[:0]), c.cloud_create(cfg, T[:0]))
                                 hs += [buf[i][0], buf[i][1]]
                                 raws += [S, T]
                             c.clouds_recompute(hs, raws)
@@ -296,7 +370,7 @@ def main():
                     err.append(e)
                     cv.notify_all()
 
-        th = [threading.Thread(target=fe_worker, args=(w,)) for w in range(nstream)] + [threading.Thread(target=loop_worker, args=(gp,)) for gp in range(G * LP)]
+        th = [threading.Thread(target=fe_worker, args=(w,)) for w in range(fe_n)] + [threading.Thread(target=loop_worker, args=(gp,)) for gp in range(G * LP)]
         for x in th:
             x.start()
         for k in range(K):  # the pair queue's only data exchange: ONE all-gather of the step's result records, as soon as the step is complete
@@ -483,7 +557,7 @@ def main():
         "config": {"workload": "%s, voxel %g m, r_pca %g, R_nms %g, %s + %s, %d-DoF; %d %s scenes per GPU cycled over %d pairs per step%s; "
                                "%d front-end streams (%s), then %d concurrent batched loop groups; pair manifest broadcast + one result all-gather per step"
                                % (CF["name"], CF["voxel"], CF["r"], CF["R"], CF["feature"], CF["corr"], CF["dof"], len(by_scene), "distinct",
-                                  nb, " (whole job: %d, sharded over the ranks)" % n_job if strong else " per GPU", nstream,
+                                  nb, " (whole job: %d, sharded over the ranks)" % n_job if strong else " per GPU", fe_n,
                                   "%d clouds per batched launch sequence" % args.fe_batch if args.fe_batch > 1 else "cloud by cloud", G),
                    "config_id": args.config, "fe_batch": args.fe_batch, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene), "raw_cloud_bytes_resident": int(sum(s.numel() * 4 + t.numel() * 4 for s, t in dev.values())),
                    "n_s": int(sts[0].n_s), "m_mean": round(m_mean), "k_mean": round(k_mean, 1), "n_km_max": int(max(max(s.k_s, s.k_t) for s in sts)),
@@ -493,7 +567,7 @@ def main():
         "ms_per_iteration_note": "ONE pair alone on the GPU: loop time / iterations (pair %d, %d iterations); in the batch every in-flight pair advances one "
                                  "iteration per %.1f ms (step time / mean iterations)" % (sid0, lat_it, ms_per_step / max(1.0, it_mean)),
         "single_pair_latency_s": round(single_latency, 4),
-        "batch_ms": {"front_end_thread_seconds_per_step": round(thread_busy["front_end"] / max(1, args.steps), 2), "front_end_threads": nstream,
+        "batch_ms": {"front_end_thread_seconds_per_step": round(thread_busy["front_end"] / max(1, args.steps), 2), "front_end_threads": fe_n, "front_end_calibration": fe_cal,
                      "loop_thread_seconds_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G,
                      "front_end_ms_per_cloud_on_its_stream": round(1e3 * thread_busy["front_end"] / max(1, args.steps) / max(1, 2 * nb), 4),
                      "note": "thread seconds are summed over the worker threads; --pipeline %d" % args.pipeline},

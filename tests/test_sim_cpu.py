@@ -39,3 +39,29 @@ def test_gpu_tests_on_the_host_simt_interpreter():
 
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 40 and "failed" not in r.stdout, tail
+
+
+def test_bench_py_on_the_host_simt_interpreter():
+    """bench.py itself (calibration of the two front ends, pipeline threads, batched front end, record gather, the JSON line) against the
+    simulated library: its host logic is exercised before it ever meets the GPU box.  The numbers mean nothing."""
+    import json
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hipsim import build
+
+    build.build()
+    env = dict(os.environ, HIPSIM_THREADS="4")
+    for extra, expect_batch in ((["--fe-batch", "-1"], None), (["--fe-batch", "4", "--fe-streams", "2"], 4), (["--fe-batch", "0", "--pipeline", "0"], 0)):
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "hipsim", "run_bench_sim.py"), "--config", "4", "--hits", "20000", "--distinct", "2",
+               "--pairs-per-step", "4", "--steps", "2", "--warmup", "1", "--cpu-baseline", "0"] + extra
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["metric"] == "registered_pairs_per_sec" and out["value"] > 0 and out["steps"] == 2 and out["n_gpus"] == 1
+        assert "roofline" in out and "cpu_baseline" in out and len(out["scenes"]) == 2
+        if expect_batch is None:
+            cal = out["batch_ms"]["front_end_calibration"]
+            assert cal["cloud_by_cloud_clouds_per_s"] > 0 and cal["batched_clouds_per_s"] > 0 and "error" not in cal
+        else:
+            assert out["config"]["fe_batch"] == expect_batch
