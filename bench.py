@@ -466,9 +466,17 @@ def main():
     b_alg = algorithmic_bytes(k_mean, m_mean, n2_mean, V, dom, km_batch if dom == "km_solve" else shard_b)
     achieved = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and b_alg == b_alg else 0.0
     per_kernel = {}
+    PER_CLOUD = ("pca_cells", "bsc", "nms_round", "voxel_sort")  # one launch per cloud, or per batch of clouds (ghicp_clouds_recompute)
+
+    def clouds_per_launch(k):
+        return (2.0 * nb * args.steps / max(1, ktimes[k][1])) if k in PER_CLOUD else 1.0
+
+    if dom in PER_CLOUD:
+        b_alg *= clouds_per_launch(dom)
+        achieved = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and b_alg == b_alg else 0.0
     for k, v in ktimes.items():
-        ba = algorithmic_bytes(k_mean, m_mean, n2_mean, V, k, km_batch if k == "km_solve" else shard_b)
-        per_kernel[k] = {"ms_total": round(v[0], 3), "launches": v[1],
+        ba = algorithmic_bytes(k_mean, m_mean, n2_mean, V, k, km_batch if k == "km_solve" else shard_b) * clouds_per_launch(k)
+        per_kernel[k] = {"ms_total": round(v[0], 3), "launches": v[1], "clouds_per_launch": round(clouds_per_launch(k), 2) if k in PER_CLOUD else None,
                          "GBps": round(ba / (v[0] / max(1, v[1]) * 1e-3) / 1e9, 2) if v[0] > 0 and ba == ba else None}
     traffic, traffic_note = None, None
     try:  # HBM-side traffic of the dominant kernel from the committed PMC passes (counters cannot be collected inside this run)
