@@ -57,6 +57,7 @@ static thread_local Worker* W = nullptr;
 static thread_local hipError_t last_error = hipSuccess;
 static std::atomic<long long> n_divergent{0}, n_launches{0}, n_blocks{0};
 static int trace_div = -1;
+static bool policy_max = false;
 static std::atomic<long long> api_calls[C_NUM];
 void count(int what) { api_calls[what]++; }
 
@@ -106,9 +107,9 @@ static Worker* worker() {
 // resolve the pending collective of wave [l0, l1): the group at the smallest source line goes first (lanes that took a divergent
 // branch are behind the lanes already waiting at the reconvergence point)
 static void resolve(Lane* L, int l0, int l1, int n_live) {
-  int site = INT32_MAX, op = 0;
+  int site = policy_max ? -1 : INT32_MAX, op = 0;  // HIPSIM_POLICY=max: the opposite order, to expose results that depend on it
   for (int i = l0; i < l1; i++)
-    if (L[i].state == S_WAVE && L[i].site < site) { site = L[i].site; op = L[i].op; }
+    if (L[i].state == S_WAVE && (policy_max ? L[i].site > site : L[i].site < site)) { site = L[i].site; op = L[i].op; }
   uint64_t mask = 0, ball = 0;
   int first = -1, n = 0;
   for (int i = l0; i < l1; i++)
@@ -283,6 +284,7 @@ static void install_segv_trace() {
 void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure) {
   if (trace_div < 0) {
     trace_div = getenv("HIPSIM_TRACE_DIVERGENCE") ? 1 : 0;
+    policy_max = getenv("HIPSIM_POLICY") && !strcmp(getenv("HIPSIM_POLICY"), "max");
     if (getenv("HIPSIM_SEGV_TRACE")) install_segv_trace();
   }
   const unsigned long long total = (unsigned long long)grid.x * grid.y * grid.z;
