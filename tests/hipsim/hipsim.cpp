@@ -58,6 +58,8 @@ static thread_local hipError_t last_error = hipSuccess;
 static std::atomic<long long> n_divergent{0}, n_launches{0}, n_blocks{0};
 static int trace_div = -1;
 static bool policy_max = false;
+static int lane_order = 0;  // HIPSIM_ORDER: 0 ascending, 1 reverse, 2 pseudo-random (waves and lanes): results must not depend on it
+static unsigned order_seed = 1;
 static std::atomic<long long> api_calls[C_NUM];
 void count(int what) { api_calls[what]++; }
 
@@ -158,15 +160,26 @@ static void run_block(const dim3& grid, const dim3& block, unsigned long long b)
   }
   const int nw = (nt + 63) / 64;
   long long idle_rounds = 0;
+  unsigned rng_state = order_seed + (unsigned)b * 747796405u;
   for (;;) {
     bool progressed = false;
-    for (int wv = 0; wv < nw; wv++) {
+    for (int wq = 0; wq < nw; wq++) {
+      int wv = wq;
+      if (lane_order == 1) wv = nw - 1 - wq;
+      else if (lane_order == 2) wv = (int)((wq + (rng_state >> 8)) % (unsigned)nw);
       const int l0 = wv * 64, l1 = std::min(nt, l0 + 64);
       for (;;) {
         int ran = 0;
         w->yielded = false;
-        for (int i = l0; i < l1; i++)
+        const int nl = l1 - l0;
+        unsigned rot = 0, step = 1;
+        if (lane_order == 2) { rng_state = rng_state * 1664525u + 1013904223u; rot = rng_state >> 10; step = (rng_state >> 4) | 1u; }  // odd step: a permutation of 64
+        for (int q = 0; q < nl; q++) {
+          int i = l0 + q;
+          if (lane_order == 1) i = l1 - 1 - q;
+          else if (lane_order == 2 && nl == 64) i = l0 + (int)((rot + (unsigned)q * step) & 63u);
           if (L[i].state == S_RUN) { cur = &L[i]; hipsim_swap(&w->sched_sp, L[i].sp); ran++; }
+        }
         cur = nullptr;
         int n_run = 0, n_wave = 0, n_live = 0;
         for (int i = l0; i < l1; i++) { n_run += L[i].state == S_RUN; n_wave += L[i].state == S_WAVE; n_live += L[i].state != S_DONE; }
@@ -285,6 +298,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* clo
   if (trace_div < 0) {
     trace_div = getenv("HIPSIM_TRACE_DIVERGENCE") ? 1 : 0;
     policy_max = getenv("HIPSIM_POLICY") && !strcmp(getenv("HIPSIM_POLICY"), "max");
+    if (const char* o = getenv("HIPSIM_ORDER")) {
+      if (!strcmp(o, "reverse")) lane_order = 1;
+      else if (!strncmp(o, "random", 6)) { lane_order = 2; if (o[6] == ':') order_seed = (unsigned)atoi(o + 7) * 2654435761u + 1u; }
+    }
     if (getenv("HIPSIM_SEGV_TRACE")) install_segv_trace();
   }
   const unsigned long long total = (unsigned long long)grid.x * grid.y * grid.z;
