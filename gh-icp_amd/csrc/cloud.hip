@@ -249,6 +249,50 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
   return GHICP_OK;
 }
 
+// ghicp_register_pairs through the batched front end: the 2 n raw clouds become (context-owned, reused) cloud handles filled by
+// ghicp_clouds_recompute -- one launch sequence per 64 clouds instead of ~100 operations per cloud --, then the pairs are registered
+// from the handles.  Same results as the pair-by-pair front end (the target's strings are variant 0 of its handle, bfe:648-660).
+// Returns GHICP_OK with *handled = 0 when the configuration is not covered by the batch (FPFH, no down-sampling).
+int gh_register_pairs_batched(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const float* const* xyzS, const int64_t* nS,
+                              const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats, int* handled) {
+  *handled = 0;
+  if (cfg->reg.feature == GHICP_FEATURE_FPFH || !(cfg->voxel > 0.f) || ctx->host_ptrs || n_pairs <= 0) return GHICP_OK;
+  hipStream_t s = ctx->stream;
+  std::vector<ghicp_cloud*>& pool = ctx->pair_clouds;
+  while (pool.size() < (size_t)n_pairs * 2) {
+    ghicp_cloud* c = new ghicp_cloud();
+    c->ctx = ctx;
+    pool.push_back(c);
+  }
+  std::vector<ghicp_cloud*> h((size_t)n_pairs * 2);
+  std::vector<const float*> xyz((size_t)n_pairs * 2);
+  std::vector<int64_t> n((size_t)n_pairs * 2);
+  for (int i = 0; i < n_pairs; i++) {
+    h[(size_t)i * 2] = pool[(size_t)i * 2]; h[(size_t)i * 2 + 1] = pool[(size_t)i * 2 + 1];
+    xyz[(size_t)i * 2] = xyzS[i]; xyz[(size_t)i * 2 + 1] = xyzT[i];
+    n[(size_t)i * 2] = nS[i]; n[(size_t)i * 2 + 1] = nT[i];
+  }
+  for (ghicp_cloud* c : h) c->cfg = *cfg;
+  hipEvent_t e0, e1;
+  GH_HIP(hipEventCreate(&e0)); GH_HIP(hipEventCreate(&e1));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
+  GH_HIP(hipEventRecord(e0, s));
+  GH_TRY(ghicp_clouds_recompute(ctx, n_pairs * 2, h.data(), xyz.data(), n.data(), stride));
+  GH_HIP(hipEventRecord(e1, s));
+  std::vector<const ghicp_cloud*> S(n_pairs), T(n_pairs);
+  for (int i = 0; i < n_pairs; i++) { S[i] = h[(size_t)i * 2]; T[i] = h[(size_t)i * 2 + 1]; }
+  GH_TRY(ghicp_register_clouds(ctx, cfg, n_pairs, S.data(), T.data(), stats));
+  float tf = 0;
+  GH_HIP(hipEventElapsedTime(&tf, e0, e1));
+  for (int i = 0; i < n_pairs; i++) {
+    stats[i].ms_keypoints = tf / n_pairs + stats[i].ms_fd;  // whole front end (voxel + keypoints + feature + FD), batch average
+    stats[i].ms_fd = 0.f;
+    stats[i].ms_total = stats[i].ms_keypoints + stats[i].ms_loop;
+  }
+  *handled = 1;
+  return GHICP_OK;
+}
+
 // ---- StereoBinaryFeature::writeFeatures / readFeatures (src/stereo_binary_feature.cpp:107-148): u32 bit count, u32 byte
 // count, i32 number of features, then byte_ bytes per feature.  Host memory, no context.
 extern "C" int ghicp_sbf_write(const char* path, const uint8_t* feat, int64_t k) {

@@ -143,6 +143,7 @@ struct ghicp_ctx {
   std::vector<DevBuf> pairbuf;  // per-pair outputs of the front end (batched API): 3 per pair slot
   void* pinned = nullptr;  // small pinned host scratch
   void* fb_pinned = nullptr;  // descriptor block + report of the batched front end (batch.hip)
+  std::vector<struct ghicp_cloud*> pair_clouds;  // cloud handles behind ghicp_register_pairs (2 per pair slot; cloud.hip)
   size_t pinned_cap = 0;
   int num_cu = 256;
 

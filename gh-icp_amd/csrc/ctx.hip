@@ -49,6 +49,8 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   (void)hipDeviceSynchronize();
   ctx->kt_collect();
   for (hipEvent_t e : ctx->kt_pool) (void)hipEventDestroy(e);
+  for (ghicp_cloud* c : ctx->pair_clouds) (void)ghicp_cloud_destroy(c);
+  ctx->pair_clouds.clear();
   for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
   for (auto& b : ctx->pairbuf) b.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

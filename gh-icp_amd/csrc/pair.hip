@@ -14,6 +14,8 @@ int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float
 int gh_fpfh_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float* normals_opt, float* hist);
 int gh_gather_rows33_dev(ghicp_ctx* ctx, const float* hist, const int32_t* idx, long long k, float* out);
 int gh_fd_fpfh_dev(ghicp_ctx* ctx, const float* histS, int ks, const float* histT, int kt, float* FD);
+int gh_register_pairs_batched(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const float* const* xyzS, const int64_t* nS,
+                              const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats, int* handled);  // cloud.hip
 
 namespace {
 
@@ -193,6 +195,12 @@ extern "C" int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg
   GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_register_pairs: device-pointer mode only");
   if (n_pairs == 0) return GHICP_OK;
+  for (int i = 0; i < n_pairs; i++) GH_ARG(nS[i] >= 0 && nT[i] >= 0 && nS[i] < (1ll << 31) - 2 && nT[i] < (1ll << 31) - 2);
+  if (n_pairs > 1 && !getenv("GHICP_PAIRS_ONE_BY_ONE")) {  // the batched front end (batch.hip) when the configuration allows it
+    int handled = 0;
+    GH_TRY(gh_register_pairs_batched(ctx, cfg, n_pairs, xyzS, nS, xyzT, nT, stride, stats, &handled));
+    if (handled) return GHICP_OK;
+  }
   hipStream_t s = ctx->stream;
   if (ctx->pairbuf.size() < (size_t)n_pairs * 3) ctx->pairbuf.resize((size_t)n_pairs * 3);
   std::vector<PairFront> F(n_pairs);
