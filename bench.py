@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-KERNELS = ("pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort")
+KERNELS = ("pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort",
+           "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out")  # fb_*: the other stages of the batched front end (ghicp_clouds_recompute)
 
 # per BASELINE config: generator, hits, voxel, r_pca, R_nms, feature, matcher, dof, est_IoU, default pairs/step, default distinct, scaling
 CONFIGS = {

@@ -353,6 +353,7 @@ int build_grid(ghicp_ctx* ctx, const FbBlock* D, int which, const float4* dsg, i
   GH_TRY(ctx->reserve(sl.vals2, (size_t)M + 1, &vals2));
   GH_TRY(ctx->reserve(sl.start, (size_t)total_cells + 2, &start));
   GH_TRY(ctx->reserve(sl.pts, (size_t)M + 1, &pts));
+  hipEvent_t kg = ctx->kt_begin(KT_FB_GRID);
   hipLaunchKernelGGL(k_fb_cell_keys, dim3(cdiv(M, 256)), dim3(256), 0, s, D, which, dsg, M, keys, vals);
   size_t tb = 0;
   const int eb = bits_for(total_cells);
@@ -362,6 +363,7 @@ int build_grid(ghicp_ctx* ctx, const FbBlock* D, int which, const float4* dsg, i
   GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)M, 0u, (unsigned)eb, s)));
   hipLaunchKernelGGL(k_fb_gather_sorted, dim3(cdiv(M, 256)), dim3(256), 0, s, dsg, vals2, M, pts);
   hipLaunchKernelGGL(k_fb_cell_start, dim3(cdiv((long long)total_cells + 1, 256)), dim3(256), 0, s, keys2, (unsigned)M, total_cells, start);
+  ctx->kt_end(KT_FB_GRID, kg);
   GH_HIP(hipGetLastError());
   *pts_out = pts; *start_out = start; *keys_out = keys2;
   return GHICP_OK;
@@ -469,7 +471,9 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
   GH_TRY(ctx->reserve(B_FB_DS, (size_t)N + nb + 1, &dsg));
   GH_HIP(upload());
+  hipEvent_t kv0 = ctx->kt_begin(KT_FB_VOXEL);
   hipLaunchKernelGGL(k_fb_voxel_keys, dim3(cdiv(N, 256)), dim3(256), 0, s, (const FbBlock*)D, (int)N, ebmax, vkeys, vvals);
+  ctx->kt_end(KT_FB_VOXEL, kv0);
   size_t tb = 0, tb2 = 0;
   hipcub::CountingInputIterator<int> iota(0);
   const unsigned sort_bits = (unsigned)(ebmax + cloud_bits);
@@ -481,12 +485,14 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));  // stable: lowest index leads its voxel
   ctx->kt_end(KT_VOXEL_SORT, kev);
   const unsigned long long vmask = ebmax >= 64 ? ~0ull : ((1ull << ebmax) - 1ull);
+  hipEvent_t kv1 = ctx->kt_begin(KT_FB_VOXEL);
   hipLaunchKernelGGL(k_fb_voxel_flags, dim3(cdiv(N, 256)), dim3(256), 0, s, vkeys2, (int)N, vmask, flags);
   GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, iota, flags, headpos, misc, (int)N, s));
   hipLaunchKernelGGL(k_fb_voxel_bounds, dim3(1), dim3(128), 0, s, headpos, misc, D, O);
   hipLaunchKernelGGL(k_fb_gather_ds, dim3(cdiv(N + nb, 256)), dim3(256), 0, s, (const FbBlock*)D, headpos, vvals2, dsg);
   hipLaunchKernelGGL(k_fb_bbox_init, dim3(cdiv(nb * 6, 256)), dim3(256), 0, s, O->bb, nb);
   hipLaunchKernelGGL(k_fb_bbox, dim3(64, nb), dim3(256), 0, s, (const FbBlock*)D, reinterpret_cast<const float*>(dsg), 1, O->bb);
+  ctx->kt_end(KT_FB_VOXEL, kv1);
   GH_HIP(hipGetLastError());
   GH_HIP(report());
   const float r_pca = cfg.neighborhood_radius, r_nms = cfg.reg.radius_nonmax;
@@ -534,19 +540,23 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   tb = 0;
   GH_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, keys1, cells, misc, M, s));
   GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+  hipEvent_t ku = ctx->kt_begin(KT_FB_GRID);
   GH_HIP(hipcub::DeviceSelect::Unique(tmp, tb, keys1, cells, misc, M, s));
   GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
+  ctx->kt_end(KT_FB_GRID, ku);
   const float r2_pca = (float)((double)r_pca * (double)r_pca);  // pcl radiusSearch: static_cast<float>(radius*radius)
   hipEvent_t kt = ctx->kt_begin(KT_PCA);
   hipLaunchKernelGGL(k_fb_pca_cells, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells, (const int*)misc, misc + 1,
                      r2_pca, lambda, curv, count);
   ctx->kt_end(KT_PCA, kt);
+  hipEvent_t kp = ctx->kt_begin(KT_FB_PRUNE);
   hipLaunchKernelGGL(k_fb_prune_flags, dim3(cdiv(M, 256)), dim3(256), 0, s, lambda, count, M, cfg.ratio_max, cfg.min_neighbors, flags);
   tb = 0;
   GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, iota, flags, cand, misc + 2, M, s));
   GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb, iota, flags, cand, misc + 2, M, s));
   hipLaunchKernelGGL(k_fb_cand_bounds, dim3(1), dim3(128), 0, s, (const int*)cand, (const int*)(misc + 2), D, O);
+  ctx->kt_end(KT_FB_PRUNE, kp);
   GH_HIP(hipGetLastError());
   GH_HIP(report());
   for (int b = 0; b <= nb; b++) H->coff[b] = HO->coff[b];
@@ -570,6 +580,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     GH_TRY(ctx->reserve(B_FE_KP, (size_t)Ctot + 1, &kpg));
     GH_TRY(ctx->reserve(B_GRID2_KEYS, (size_t)std::max(Ctot, M) + 1, &ckeys));   // grid 2 is built after the sweep: its buffers are free here
     GH_TRY(ctx->reserve(B_GRID2_KEYS2, (size_t)std::max(Ctot, M) + 1, &ckeys2));
+    hipEvent_t kr = ctx->kt_begin(KT_FB_RANK);
     hipLaunchKernelGGL(k_fb_nms_keys, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const double*)curv, (const int*)cand, Ctot, nkeys, nvals);
     tb = 0; tb2 = 0;
     GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, nkeys, nkeys2, nvals, ord1, Ctot, 0, 64, s));
@@ -585,6 +596,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     hipLaunchKernelGGL(k_fb_nms_points, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const float4*)dsg, (const int*)cand, (const int*)ordg, Ctot, cpts);
     hipLaunchKernelGGL(k_fb_bbox_init, dim3(cdiv(nb * 6, 256)), dim3(256), 0, s, O->bb, nb);
     hipLaunchKernelGGL(k_fb_bbox, dim3(16, nb), dim3(256), 0, s, (const FbBlock*)D, (const float*)cpts, 2, O->bb);
+    ctx->kt_end(KT_FB_RANK, kr);
     GH_HIP(hipGetLastError());
     GH_HIP(report());
     unsigned long long t3 = 0;
@@ -625,22 +637,26 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     H->c[b].ds = c->ds.as<float4>(); H->c[b].kp = c->kp.as<int>(); H->c[b].kpx = c->kpx.as<double>(); H->c[b].feat = c->feat.as<uint8_t>();
   }
   GH_HIP(upload());
+  hipEvent_t ko = ctx->kt_begin(KT_FB_OUT);
   hipLaunchKernelGGL(k_fb_copy_ds, dim3(cdiv(M, 256)), dim3(256), 0, s, (const FbBlock*)D, (const float4*)dsg, M);
   if (Ktot > 0) {
     float* lcs = nullptr;
     if (bsc) GH_TRY(ctx->reserve(B_P_LCS, (size_t)Ktot * 12 + 12, &lcs));
     hipLaunchKernelGGL(k_fb_keypoints_out, dim3(cdiv(Ktot, 256)), dim3(256), 0, s, (const FbBlock*)D, (const float4*)dsg, (const int*)kpg, Ktot, lcs);
+    if (bsc) hipLaunchKernelGGL(k_fb_zero_feat, dim3(cdiv((long long)Ktot * 56, 256)), dim3(256), 0, s, (const FbBlock*)D, Ktot);
+    ctx->kt_end(KT_FB_OUT, ko);
+    ko = nullptr;
     if (bsc) {
       const float4* pts2;
       const unsigned *start2, *keys2;
       const GridSlots sl2 = {B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS};
       GH_TRY(build_grid(ctx, D, 1, dsg, M, (unsigned)t2, sl2, &pts2, &start2, &keys2));
-      hipLaunchKernelGGL(k_fb_zero_feat, dim3(cdiv((long long)Ktot * 56, 256)), dim3(256), 0, s, (const FbBlock*)D, Ktot);
       hipEvent_t kb = ctx->kt_begin(KT_BSC);
       hipLaunchKernelGGL(k_fb_bsc, dim3((unsigned)Ktot), dim3(BT), 0, s, (const FbBlock*)D, pts2, start2, BC, lcs);
       ctx->kt_end(KT_BSC, kb);
     }
   }
+  if (ko) ctx->kt_end(KT_FB_OUT, ko);
   GH_HIP(hipGetLastError());
   GH_HIP(hipStreamSynchronize(s));
   return GHICP_OK;

@@ -81,8 +81,11 @@ enum BufSlot {
   B_NUM
 };
 
-enum KtSlot { KT_PCA = 0, KT_BSC, KT_KM_SOLVE, KT_CD_ROWMIN, KT_KM_WEIGHTS, KT_FD_BSC, KT_NMS_ROUND, KT_VOXEL_SORT, KT_NUM };
-static const char* const kKtNames[KT_NUM] = {"pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort"};
+enum KtSlot { KT_PCA = 0, KT_BSC, KT_KM_SOLVE, KT_CD_ROWMIN, KT_KM_WEIGHTS, KT_FD_BSC, KT_NMS_ROUND, KT_VOXEL_SORT,
+              KT_FB_VOXEL, KT_FB_GRID, KT_FB_PRUNE, KT_FB_RANK, KT_FB_OUT,  // stages of the batched front end (batch.hip) around the kernels above
+              KT_NUM };
+static const char* const kKtNames[KT_NUM] = {"pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort",
+                                             "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out"};
 
 struct ghicp_ctx {
   // optional per-kernel timing
