@@ -287,7 +287,8 @@ __global__ __launch_bounds__(NMS_T) void k_fb_nms_greedy(const FbBlock* __restri
     if (threadIdx.x == 0) kcount[b] = 0;
     return;
   }
-  gh_nms_greedy_cloud(cpts + (size_t)c0 * 3, c, D->g3[b], r2, head + D->hb[b], next + c0, cand, ord + c0, kpg + c0, kcount + b, D->moff[b]);
+  const GridDesc g = D->g3[b];  // by value: the sweep reads it for every candidate
+  gh_nms_greedy_cloud(cpts + (size_t)c0 * 3, c, g, r2, head + D->hb[b], next + c0, cand, ord + c0, kpg + c0, kcount + b, D->moff[b]);
 }
 
 __global__ __launch_bounds__(256) void k_fb_copy_ds(const FbBlock* __restrict__ D, const float4* __restrict__ dsg, int M) {
