@@ -219,10 +219,11 @@ __global__ __launch_bounds__(256) void k_fb_cell_start(const unsigned* __restric
 }
 
 // pca.hip:k_pca_cells over the occupied cells of all clouds of the batch
+template <int CHUNK>
 __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__ D, const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                       const unsigned* __restrict__ cells, const int* __restrict__ ncells, int* __restrict__ counter,
                                                       float r2, float* __restrict__ lambda, double* __restrict__ curvature, int* __restrict__ count) {
-  __shared__ float4 sC[PCA_CHUNK];
+  __shared__ float4 sC[CHUNK];
   __shared__ int s_cell;
   const int lane = threadIdx.x;
   const int nc = *ncells;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__
     const int b = fb_find_u(D->cb1, D->nb, gkey);
     GridArgs G;
     G.d = D->g1[b]; G.pts = pts; G.start = start + D->cb1[b];
-    gh_pca_cell(G, gkey - D->cb1[b], r2, lambda, curvature, count, sC, lane);
+    gh_pca_cell<CHUNK>(G, gkey - D->cb1[b], r2, lambda, curvature, count, sC, lane);
   }
 }
 
@@ -547,8 +548,12 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   ctx->kt_end(KT_FB_GRID, ku);
   const float r2_pca = (float)((double)r_pca * (double)r_pca);  // pcl radiusSearch: static_cast<float>(radius*radius)
   hipEvent_t kt = ctx->kt_begin(KT_PCA);
-  hipLaunchKernelGGL(k_fb_pca_cells, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells, (const int*)misc, misc + 1,
-                     r2_pca, lambda, curv, count);
+  if (gh_pca_chunk() == 256)
+    hipLaunchKernelGGL(k_fb_pca_cells<256>, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells, (const int*)misc,
+                       misc + 1, r2_pca, lambda, curv, count);
+  else
+    hipLaunchKernelGGL(k_fb_pca_cells<PCA_CHUNK>, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells,
+                       (const int*)misc, misc + 1, r2_pca, lambda, curv, count);
   ctx->kt_end(KT_PCA, kt);
   hipEvent_t kp = ctx->kt_begin(KT_FB_PRUNE);
   hipLaunchKernelGGL(k_fb_prune_flags, dim3(cdiv(M, 256)), dim3(256), 0, s, lambda, count, M, cfg.ratio_max, cfg.min_neighbors, flags);

@@ -17,10 +17,11 @@
 
 namespace {
 
+template <int CHUNK>
 __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __restrict__ cells, const int* __restrict__ ncells,
                                                    int* __restrict__ counter, float r2, float* __restrict__ lambda,
                                                    double* __restrict__ curvature, int* __restrict__ count) {
-  __shared__ float4 sC[PCA_CHUNK];
+  __shared__ float4 sC[CHUNK];
   __shared__ int s_cell;
   const int lane = threadIdx.x;
   const int nc = *ncells;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __
     const int c = __builtin_amdgcn_readfirstlane(s_cell);
     __syncthreads();
     if (c >= nc) break;
-    gh_pca_cell(G, cells[c], r2, lambda, curvature, count, sC, lane);
+    gh_pca_cell<CHUNK>(G, cells[c], r2, lambda, curvature, count, sC, lane);
   }
 }
 
@@ -67,7 +68,8 @@ int gh_pca_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float 
   const float r2 = (float)((double)radius * (double)radius);  // pcl radiusSearch: static_cast<float>(radius*radius)
   const int blocks = ctx->num_cu * 20;
   hipEvent_t kt = ctx->kt_begin(KT_PCA);
-  hipLaunchKernelGGL(k_pca_cells, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, lambda, curvature, count);
+  if (gh_pca_chunk() == 256) hipLaunchKernelGGL(k_pca_cells<256>, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, lambda, curvature, count);
+  else hipLaunchKernelGGL(k_pca_cells<PCA_CHUNK>, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, lambda, curvature, count);
   ctx->kt_end(KT_PCA, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;

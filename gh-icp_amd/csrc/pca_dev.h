@@ -4,8 +4,16 @@
 #include "grid.h"
 #include "devmath.h"
 
-constexpr int PCA_CHUNK = 512;
+#include <cstdlib>
 
+constexpr int PCA_CHUNK = 512;  // default LDS tile (8 KB: 5 waves per SIMD); 256 (4 KB: 8 waves per SIMD) behind GHICP_PCA_CHUNK=256 for timing
+inline int gh_pca_chunk() {
+  static const int v = [] { const char* e = getenv("GHICP_PCA_CHUNK"); return (e && atoi(e) == 256) ? 256 : PCA_CHUNK; }();
+  return v;
+}
+
+// CHUNK only sets how many neighbour points are staged per barrier pair: every lane still meets the points of a run in the same order
+template <int CHUNK>
 __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, float* __restrict__ lambda, double* __restrict__ curvature,
                                    int* __restrict__ count, float4* sC, int lane) {
   const int cz = key % G.d.dim[2];
@@ -21,8 +29,8 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
     int k = 0;
     double sx = 0, sy = 0, sz = 0;
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
-      for (unsigned base = rb; base < re; base += PCA_CHUNK) {
-        const int cnt = min((unsigned)PCA_CHUNK, re - base);
+      for (unsigned base = rb; base < re; base += CHUNK) {
+        const int cnt = min((unsigned)CHUNK, re - base);
         for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
         __syncthreads();
         if (live)
@@ -41,8 +49,8 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
     // ---- sweep 2: de-meaned scatter
     double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
-      for (unsigned base = rb; base < re; base += PCA_CHUNK) {
-        const int cnt = min((unsigned)PCA_CHUNK, re - base);
+      for (unsigned base = rb; base < re; base += CHUNK) {
+        const int cnt = min((unsigned)CHUNK, re - base);
         for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
         __syncthreads();
         if (live && k >= 3)

@@ -19,6 +19,7 @@ run tail40 --fe-batch 32 --fe-streams 4 --tail-fraction 0.4
 run tail60 --fe-batch 32 --fe-streams 4 --tail-fraction 0.6
 run pipeline1 --fe-batch 32 --fe-streams 4 --pipeline 1
 run groups6 --fe-batch 32 --fe-streams 4 --loop-groups 6
+GHICP_PCA_CHUNK=256 run pca_chunk256 --fe-batch 32 --fe-streams 4   # 4 KB PCA tile: 8 instead of 5 waves per SIMD (same results)
 python - <<'PY'
 import glob, json
 for f in sorted(glob.glob("gpurun_out/r03_sweep_*.json")):
