@@ -245,9 +245,9 @@ def main():
     if args.fe_batch < 0:
         fe_cal = {"sample_pairs": min(nb, 64)}
         sample = list(range(min(nb, 64)))
-        if feature == api.FEATURE_FPFH or nb == 0:
-            args.fe_batch = 0  # the batched front end covers BSC / no descriptors
-            fe_cal["chosen"] = "cloud by cloud (FPFH descriptors are not batched)"
+        if nb == 0:
+            args.fe_batch = 0
+            fe_cal["chosen"] = "cloud by cloud (no pairs on this rank)"
         else:
             try:
                 fe_cal["cloud_by_cloud_clouds_per_s"] = round(fe_sample_rate(0, nstream, sample), 1)

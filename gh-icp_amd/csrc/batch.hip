@@ -1,5 +1,5 @@
 // Batched per-cloud front end (gfx950): nb clouds go through down-sampling, keypoint detection and BSC encoding
-// (test/ghicp_main.cpp:86-127 per cloud) with ONE sequence of launches.
+// (test/ghicp_main.cpp:86-127 per cloud; FPFH rows instead of BSC strings for Ft = F) with ONE sequence of launches.
 //
 // Why: one cloud's front end is ~100 device operations (24 kernels, 3 radix sorts, 4 selects, copies, 7 host synchronisations that size
 // the next stage) and the host issues them at ~8 us each, so a cloud costs 0.85 ms however many streams submit clouds.
@@ -9,6 +9,7 @@
 //   * voxel keys carry the cloud id above the voxel key's bits  -> one stable radix sort keeps clouds apart and ordered;
 //   * grid cells are numbered globally (cell base of the cloud + cell) -> one sort / one cell table per grid for all clouds;
 //   * NMS ranks: one 64-bit descending sort of all candidates by curvature, then one stable pass over the cloud id.
+// FPFH clouds: the kNN grid is the batch's second grid and the normal / SPFH / FPFH kernels of fpfh.hip run once over the concatenated cloud.
 // Results are bit-identical to ghicp_cloud_recompute() cloud by cloud: same per-cloud boxes, same grids, same orders inside a cell,
 // same reduction trees (tests/test_gpu_batch.py).
 #include "cloud.h"
@@ -24,6 +25,10 @@
 #include <vector>
 
 typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096> GhSortConfig;  // see grid.hip
+
+float gh_fpfh_cell(const float* mm, long long m);  // fpfh.hip
+int gh_fpfh_batch_dev(ghicp_ctx* ctx, const float4* dsg, int M, const float4* pts, const unsigned* start, const GridDesc* gd_dev, const unsigned* cell_base_dev,
+                      const int* moff_dev, int nb, float* hist);
 
 namespace {
 
@@ -321,6 +326,15 @@ __global__ __launch_bounds__(256) void k_fb_zero_feat(const FbBlock* __restrict_
   reinterpret_cast<unsigned*>(D->c[b].feat)[((size_t)v * kb + j) * 14 + w] = 0u;
 }
 
+// keyfpfh (fpfh.hpp:93-115): the histogram rows of every cloud's keypoints into the cloud handle
+__global__ __launch_bounds__(256) void k_fb_gather_rows33(const FbBlock* __restrict__ D, const float* __restrict__ hist, int K) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K * 33) return;
+  const int q = t / 33, r = t % 33;
+  const int b = fb_find(D->koff, D->nb, q), j = q - D->koff[b];
+  reinterpret_cast<float*>(D->c[b].feat)[(size_t)j * 33 + r] = hist[((size_t)D->moff[b] + D->c[b].kp[j]) * 33 + r];
+}
+
 __global__ __launch_bounds__(BT) void k_fb_bsc(const FbBlock* __restrict__ D, const float4* __restrict__ pts, const unsigned* __restrict__ start, BscConst C,
                                                float* __restrict__ lcs) {
   const int q = blockIdx.x;
@@ -388,8 +402,8 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     N += n[i];
   }
   const ghicp_pair_config cfg = clouds[0]->cfg;
-  // what the batch does not cover goes cloud by cloud: FPFH descriptors, no down-sampling, host pointers
-  if (cfg.reg.feature == GHICP_FEATURE_FPFH || !(cfg.voxel > 0.f) || ctx->host_ptrs) {
+  // what the batch does not cover goes cloud by cloud: no down-sampling, host pointers
+  if (!(cfg.voxel > 0.f) || ctx->host_ptrs) {
     for (int i = 0; i < n_clouds; i++) GH_TRY(ghicp_cloud_recompute(clouds[i], xyz[i], n[i], stride));
     return GHICP_OK;
   }
@@ -500,7 +514,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   const float r_pca = cfg.neighborhood_radius, r_nms = cfg.reg.radius_nonmax;
   BscConst BC;
   float r_search = 0.f;
-  const bool bsc = cfg.reg.feature == GHICP_FEATURE_BSC;
+  const bool bsc = cfg.reg.feature == GHICP_FEATURE_BSC, fpfh = cfg.reg.feature == GHICP_FEATURE_FPFH;
   if (bsc) GH_TRY(gh_bsc_make_const(ctx, r_nms, cfg.reg.dof, cfg.pattern, &BC, &r_search));
   unsigned long long t1 = 0, t2 = 0;
   for (int b = 0; b <= nb; b++) { H->hoff[b] = HO->hoff[b]; H->moff[b] = HO->moff[b]; }
@@ -514,8 +528,8 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     H->g1[b] = gh_grid_desc(mm, c->m, r_pca * 1.0001f);
     H->cb1[b] = (unsigned)t1;
     t1 += H->g1[b].ncell;
-    if (bsc) {
-      H->g2[b] = gh_grid_desc(mm, c->m, r_search * 1.0001f);
+    if (bsc || fpfh) {  // the feature's grid: sqrt(3) R search of the BSC encoder, or the kNN grid of the FPFH estimation
+      H->g2[b] = gh_grid_desc(mm, c->m, bsc ? r_search * 1.0001f : gh_fpfh_cell(mm, c->m));
       H->cb2[b] = (unsigned)t2;
       t2 += H->g2[b].ncell;
     }
@@ -640,6 +654,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     GH_HIP(c->kp.reserve(((size_t)c->m + 1) * sizeof(int)));
     GH_HIP(c->kpx.reserve(((size_t)c->k * 3 + 3) * sizeof(double)));
     if (bsc) GH_HIP(c->feat.reserve((size_t)4 * c->k * 56 + 64));
+    if (fpfh) GH_HIP(c->feat.reserve(((size_t)c->k * 33 + 33) * sizeof(float)));
     H->c[b].ds = c->ds.as<float4>(); H->c[b].kp = c->kp.as<int>(); H->c[b].kpx = c->kpx.as<double>(); H->c[b].feat = c->feat.as<uint8_t>();
   }
   GH_HIP(upload());
@@ -663,6 +678,16 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     }
   }
   if (ko) ctx->kt_end(KT_FB_OUT, ko);
+  if (fpfh && Ktot > 0) {  // compute_fpfh_feature over ALL down-sampled points, then the keypoints' rows (main:122-127)
+    const float4* pts2;
+    const unsigned *start2, *keys2;
+    const GridSlots sl2 = {B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS};
+    GH_TRY(build_grid(ctx, D, 1, dsg, M, (unsigned)t2, sl2, &pts2, &start2, &keys2));
+    float* hist;
+    GH_TRY(ctx->reserve(B_P_FEAT_S, (size_t)M * 33 * sizeof(float) + 64, (char**)&hist));
+    GH_TRY(gh_fpfh_batch_dev(ctx, dsg, M, pts2, start2, D->g2, D->cb2, D->moff, nb, hist));
+    hipLaunchKernelGGL(k_fb_gather_rows33, dim3(cdiv((long long)Ktot * 33, 256)), dim3(256), 0, s, (const FbBlock*)D, (const float*)hist, Ktot);
+  }
   GH_HIP(hipGetLastError());
   GH_HIP(hipStreamSynchronize(s));
   return GHICP_OK;

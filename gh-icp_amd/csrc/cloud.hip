@@ -252,11 +252,11 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
 // ghicp_register_pairs through the batched front end: the 2 n raw clouds become (context-owned, reused) cloud handles filled by
 // ghicp_clouds_recompute -- one launch sequence per 64 clouds instead of ~100 operations per cloud --, then the pairs are registered
 // from the handles.  Same results as the pair-by-pair front end (the target's strings are variant 0 of its handle, bfe:648-660).
-// Returns GHICP_OK with *handled = 0 when the configuration is not covered by the batch (FPFH, no down-sampling).
+// Returns GHICP_OK with *handled = 0 when the configuration is not covered by the batch (no down-sampling, host pointers).
 int gh_register_pairs_batched(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const float* const* xyzS, const int64_t* nS,
                               const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats, int* handled) {
   *handled = 0;
-  if (cfg->reg.feature == GHICP_FEATURE_FPFH || !(cfg->voxel > 0.f) || ctx->host_ptrs || n_pairs <= 0) return GHICP_OK;
+  if (!(cfg->voxel > 0.f) || ctx->host_ptrs || n_pairs <= 0) return GHICP_OK;
   hipStream_t s = ctx->stream;
   std::vector<ghicp_cloud*>& pool = ctx->pair_clouds;
   while (pool.size() < (size_t)n_pairs * 2) {

@@ -18,10 +18,7 @@ constexpr int KNN = 20;
 __device__ inline bool pair_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
 // `kk` <= KNN neighbours are kept (rows of nn/nd stay KNN wide; slots >= kk are never filled)
-__global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int kk, int* __restrict__ nn, float* __restrict__ nd, int* __restrict__ nk) {
-  const int p = blockIdx.x * 128 + threadIdx.x;
-  if (p >= G.d.n) return;
-  const float4 P = G.pts[p];
+__device__ inline void knn_point(const GridArgs& G, float cell, int kk, const float4 P, int* __restrict__ nn, float* __restrict__ nd, int* __restrict__ nk) {
   const int self = (int)__float_as_uint(P.w);
   const int cx = gh_cell_coord(P.x, G.d.mn[0], G.d.inv, G.d.dim[0]);
   const int cy = gh_cell_coord(P.y, G.d.mn[1], G.d.inv, G.d.dim[1]);
@@ -106,6 +103,32 @@ __global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int kk, int
 #pragma unroll
   for (int t = 0; t < KNN; t++) { nn[(size_t)self * KNN + t] = bi[t]; nd[(size_t)self * KNN + t] = bd[t]; }
   nk[self] = cnt;
+}
+
+__global__ __launch_bounds__(128) void k_knn(GridArgs G, float cell, int kk, int* __restrict__ nn, float* __restrict__ nd, int* __restrict__ nk) {
+  const int p = blockIdx.x * 128 + threadIdx.x;
+  if (p >= G.d.n) return;
+  knn_point(G, cell, kk, G.pts[p], nn, nd, nk);
+}
+
+// the same over the concatenated clouds of a batch (batch.hip): globally numbered cells, one GridDesc per cloud; a point's neighbours are
+// indices into the concatenated array and never leave its cloud
+__global__ __launch_bounds__(128) void k_knn_batch(const float4* __restrict__ pts, const unsigned* __restrict__ start, const GridDesc* __restrict__ gd,
+                                                   const unsigned* __restrict__ cell_base, const int* __restrict__ moff, int nb, int M, int kk,
+                                                   int* __restrict__ nn, float* __restrict__ nd, int* __restrict__ nk) {
+  const int p = blockIdx.x * 128 + threadIdx.x;
+  if (p >= M) return;
+  const float4 P = pts[p];
+  const int self = (int)__float_as_uint(P.w);
+  int lo = 0, hi = nb - 1;  // cloud of the point: largest b with moff[b] <= self
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (moff[mid] <= self) lo = mid;
+    else hi = mid - 1;
+  }
+  GridArgs G;
+  G.d = gd[lo]; G.pts = pts; G.start = start + cell_base[lo];
+  knn_point(G, 1.0f / G.d.inv, kk, P, nn, nd, nk);
 }
 
 __global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, int stride, long long m, const int* __restrict__ nn,
@@ -233,14 +256,14 @@ __global__ __launch_bounds__(256) void k_gather_rows33(const float* __restrict__
 
 }  // namespace
 
+float gh_fpfh_cell(const float* mm, long long m);
+
 int gh_fpfh_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float* normals_opt, float* hist) {
   if (m <= 0) return GHICP_OK;
   hipStream_t s = ctx->stream;
   float mm[6];
   GH_TRY(gh_bbox_dev(ctx, xyz, m, stride, mm));
-  const double vol = fmax(1e-9, (double)(mm[3] - mm[0] + 1e-3) * (mm[4] - mm[1] + 1e-3) * (mm[5] - mm[2] + 1e-3));
-  float cell = (float)cbrt(vol / (double)m * 8.0);
-  if (cell < 0.05f) cell = 0.05f;
+  const float cell = gh_fpfh_cell(mm, m);
   DeviceGrid G;
   const GridSlots sl = {B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS};
   GH_TRY(gh_grid_build(ctx, xyz, m, stride, cell, sl, &G));
@@ -258,6 +281,34 @@ int gh_fpfh_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float
   hipLaunchKernelGGL(k_normals, dim3(cdiv(m, 256)), dim3(256), 0, s, xyz, stride, m, nn, nk, nrm, 0);
   hipLaunchKernelGGL(k_spfh, dim3(cdiv(m, 128)), dim3(128), 0, s, xyz, stride, m, nn, nk, nrm, spfh);
   hipLaunchKernelGGL(k_fpfh, dim3(cdiv(m, 128)), dim3(128), 0, s, m, nn, nd, nk, spfh, hist);
+  GH_HIP(hipGetLastError());
+  return GHICP_OK;
+}
+
+// FPFH of every point of a batch's concatenated down-sampled clouds (float4 rows, M points) over the batch's kNN grid (batch.hip builds it:
+// per-cloud cell size as in gh_fpfh_dev, globally numbered cells).  The normal / SPFH / FPFH kernels are the single-cloud ones: neighbour
+// indices are indices into the concatenated array.
+float gh_fpfh_cell(const float* mm, long long m) {  // cell size of the kNN grid of one cloud (gh_fpfh_dev)
+  const double vol = fmax(1e-9, (double)(mm[3] - mm[0] + 1e-3) * (mm[4] - mm[1] + 1e-3) * (mm[5] - mm[2] + 1e-3));
+  float cell = (float)cbrt(vol / (double)(m > 0 ? m : 1) * 8.0);
+  return cell < 0.05f ? 0.05f : cell;
+}
+int gh_fpfh_batch_dev(ghicp_ctx* ctx, const float4* dsg, int M, const float4* pts, const unsigned* start, const GridDesc* gd_dev, const unsigned* cell_base_dev,
+                      const int* moff_dev, int nb, float* hist) {
+  if (M <= 0) return GHICP_OK;
+  hipStream_t s = ctx->stream;
+  int *nn, *nk;
+  float *nd, *spfh, *nrm;
+  GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)M * KNN + 1, &nn));
+  GH_TRY(ctx->reserve(B_FE_SORTK2, (size_t)M * KNN + 1, &nd));
+  GH_TRY(ctx->reserve(B_FE_COUNT, (size_t)M + 1, &nk));
+  GH_TRY(ctx->reserve(B_FE_CPTS, (size_t)M * 33 + 1, &spfh));
+  GH_TRY(ctx->reserve(B_FE_LAMBDA, (size_t)M * 3 + 3, &nrm));
+  const float* xyz = reinterpret_cast<const float*>(dsg);
+  hipLaunchKernelGGL(k_knn_batch, dim3(cdiv(M, 128)), dim3(128), 0, s, pts, start, gd_dev, cell_base_dev, moff_dev, nb, M, KNN, nn, nd, nk);
+  hipLaunchKernelGGL(k_normals, dim3(cdiv(M, 256)), dim3(256), 0, s, xyz, 4, (long long)M, nn, nk, nrm, 0);
+  hipLaunchKernelGGL(k_spfh, dim3(cdiv(M, 128)), dim3(128), 0, s, xyz, 4, (long long)M, nn, nk, nrm, spfh);
+  hipLaunchKernelGGL(k_fpfh, dim3(cdiv(M, 128)), dim3(128), 0, s, (long long)M, nn, nd, nk, spfh, hist);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
 }

@@ -19,10 +19,10 @@ def _same(a, b):
             np.testing.assert_array_equal(da[key].cpu().numpy(), db[key].cpu().numpy(), err_msg=key)
 
 
-@pytest.mark.parametrize("feature,dof", [("bsc", 6), ("bsc", 4), ("none", 6)])
+@pytest.mark.parametrize("feature,dof", [("bsc", 6), ("bsc", 4), ("none", 6), ("fpfh", 6)])
 def test_batch_equals_cloud_by_cloud(ctx, api, synth, feature, dof):
-    feat = dict(bsc=api.FEATURE_BSC, none=api.FEATURE_NONE)[feature]
-    cfg = api.pair_config(feat, api.CORR_NN, dof=dof, voxel=0.2, pattern=synth.bsc_pattern_glibc(), max_iter=40)
+    feat = dict(bsc=api.FEATURE_BSC, none=api.FEATURE_NONE, fpfh=api.FEATURE_FPFH)[feature]
+    cfg = api.pair_config(feat, api.CORR_NNR if feature == "fpfh" else api.CORR_NN, dof=dof, voxel=0.2, pattern=synth.bsc_pattern_glibc(), max_iter=40)
     a = synth.tls_pair(40_000, pair_id=21)
     b = synth.tls_pair(25_000, pair_id=22)
     g = synth.gauss_pair(3000)
@@ -46,7 +46,7 @@ def test_batch_equals_cloud_by_cloud(ctx, api, synth, feature, dof):
     ctx.clouds_recompute([batch[3]], [raws[0]])
     single[3].recompute(raws[0])
     _same(single[3], batch[3])
-    if feature == "bsc":  # and the registrations from the batched handles are the registrations from the others
+    if feature in ("bsc", "fpfh"):  # and the registrations from the batched handles are the registrations from the others
         pairs = [(0, 1), (2, 1)]
         got = ctx.register_clouds(cfg, [(batch[i], batch[j]) for i, j in pairs])
         ref = ctx.register_clouds(cfg, [(single[i], single[j]) for i, j in pairs])
