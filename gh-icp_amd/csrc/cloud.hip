@@ -256,7 +256,8 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
 int gh_register_pairs_batched(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const float* const* xyzS, const int64_t* nS,
                               const float* const* xyzT, const int64_t* nT, int stride, ghicp_pair_stats* stats, int* handled) {
   *handled = 0;
-  if (!(cfg->voxel > 0.f) || ctx->host_ptrs || n_pairs <= 0) return GHICP_OK;
+  // (FPFH batches go cloud by cloud here until the FPFH branch of the batched front end has been through the GPU suite once)
+  if (cfg->reg.feature == GHICP_FEATURE_FPFH || !(cfg->voxel > 0.f) || ctx->host_ptrs || n_pairs <= 0) return GHICP_OK;
   hipStream_t s = ctx->stream;
   std::vector<ghicp_cloud*>& pool = ctx->pair_clouds;
   while (pool.size() < (size_t)n_pairs * 2) {

@@ -28,3 +28,11 @@ def test_batch_of_full_size_clouds(ctx, api, synth):
             np.testing.assert_array_equal(da[key].cpu().numpy(), db[key].cpu().numpy(), err_msg=key)
     i0 = batch[0].info()
     assert i0.n == CF["hits"] and 150_000 < i0.m < 500_000 and i0.k > 300
+
+
+def test_batch_equals_cloud_by_cloud_fpfh(ctx, api, synth):
+    """The FPFH branch of the batched front end (written on the host SIMT interpreter after the round's GPU minutes were spent): same
+    comparison as tests/test_gpu_batch.py, kept in this last file until it has passed on the MI355X once."""
+    import test_gpu_batch as B
+
+    B.check_batch_equals_cloud_by_cloud(ctx, api, synth, "fpfh", 6)
