@@ -62,6 +62,10 @@ static int lane_order = 0;  // HIPSIM_ORDER: 0 ascending, 1 reverse, 2 pseudo-ra
 static unsigned order_seed = 1;
 static std::atomic<long long> api_calls[C_NUM];
 void count(int what) { api_calls[what]++; }
+int poison_byte() {
+  static const int v = [] { const char* e = getenv("HIPSIM_POISON"); return e ? (atoi(e) & 0xff) : -1; }();
+  return v;
+}
 
 hipError_t take_last_error(bool clear) {
   const hipError_t e = last_error;

@@ -229,7 +229,14 @@ namespace hipsim { hipError_t take_last_error(bool clear); }
 static inline hipError_t hipGetLastError() { return hipsim::take_last_error(true); }
 static inline hipError_t hipPeekAtLastError() { return hipsim::take_last_error(false); }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : e == hipErrorInvalidConfiguration ? "hipErrorInvalidConfiguration (hipsim)" : "hipsim error"; }
-static inline hipError_t hipMalloc(void** p, size_t n) { hipsim::count(hipsim::C_MALLOC); *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+namespace hipsim { int poison_byte(); }  // HIPSIM_POISON=<byte>: fresh device memory is filled with it (results must not depend on what hipMalloc returns)
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  hipsim::count(hipsim::C_MALLOC);
+  const size_t bytes = (n + 255) / 256 * 256 + 256;
+  *p = aligned_alloc(256, bytes);
+  if (*p && hipsim::poison_byte() >= 0) memset(*p, hipsim::poison_byte(), bytes);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
