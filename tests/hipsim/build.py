@@ -9,10 +9,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "gh-icp_amd", "csrc")
 ASAN = os.environ.get("HIPSIM_ASAN") == "1"  # LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0
-OUT_DIR = os.path.join(HERE, "_build_asan" if ASAN else "_build")
+TSAN = os.environ.get("HIPSIM_TSAN") == "1"  # LD_PRELOAD=$(gcc -print-file-name=libtsan.so): lanes are TSan fibers, barriers / collectives are its sync points
+OUT_DIR = os.path.join(HERE, "_build_asan" if ASAN else ("_build_tsan" if TSAN else "_build"))
 LIB = os.path.join(OUT_DIR, "libghicp_sim.so")
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-pthread", "-w", "-fno-extern-tls-init",
-         "-I", os.path.join(HERE, "include"), "-I", CSRC] + (["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if ASAN else [])
+         "-I", os.path.join(HERE, "include"), "-I", CSRC] + (["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if ASAN else []) + (["-fsanitize=thread", "-fno-omit-frame-pointer", "-g", "-O1"] if TSAN else [])
 
 
 def _newer(target, deps):
@@ -52,7 +53,7 @@ def build(verbose=False):
     if failed:
         raise RuntimeError("hipsim build failed")
     if jobs or not os.path.exists(LIB):
-        subprocess.run(["g++", "-shared", "-pthread"] + (["-fsanitize=address"] if ASAN else []) + ["-o", LIB] + objs, check=True)
+        subprocess.run(["g++", "-shared", "-pthread"] + (["-fsanitize=address"] if ASAN else []) + (["-fsanitize=thread"] if TSAN else []) + ["-o", LIB] + objs, check=True)
     return LIB
 
 

@@ -13,6 +13,16 @@
 #include <thread>
 #include <vector>
 
+#if defined(__SANITIZE_THREAD__)
+// HIPSIM_TSAN=1 build: every lane is a ThreadSanitizer fiber; __syncthreads, wave collectives and workgroup boundaries are release /
+// acquire points, so TSan reports LDS / global accesses of two lanes that no barrier or collective orders (a data race on the GPU
+// unless the code relies on wave lock-step without saying so).
+#include <sanitizer/tsan_interface.h>
+#define HIPSIM_TSAN_ON 1
+#else
+#define HIPSIM_TSAN_ON 0
+#endif
+
 extern "C" void hipsim_swap(void** save_sp, void* load_sp);
 asm(R"(
 .text
@@ -39,10 +49,15 @@ hipsim_swap:
 
 namespace hipsim {
 enum { S_RUN = 0, S_SYNC = 1, S_WAVE = 2, S_DONE = 3 };
-static const size_t STACK_BYTES = 256 * 1024;
+static const size_t STACK_BYTES = (HIPSIM_TSAN_ON ? 2048 : 256) * 1024;  // per lane (virtual; instrumented frames are larger)
 static const int MAX_LANES = 1024;
 
 struct Worker {
+#if HIPSIM_TSAN_ON
+  void* lane_fiber[1024] = {nullptr};
+  void* sched_fiber = nullptr;
+  char sync_block = 0, sync_wave[16] = {0}, sync_launch = 0;  // addresses TSan's release / acquire are keyed on
+#endif
   char* stacks = nullptr;
   Lane lanes[MAX_LANES];
   void* sched_sp = nullptr;
@@ -73,10 +88,21 @@ hipError_t take_last_error(bool clear) {
   return e;
 }
 
-static void to_scheduler() { hipsim_swap(&cur->sp, W->sched_sp); }
+static void to_scheduler() {
+#if HIPSIM_TSAN_ON
+  __tsan_switch_to_fiber(W->sched_fiber, 0);
+#endif
+  hipsim_swap(&cur->sp, W->sched_sp);
+}
 
 static void fiber_main() {
+#if HIPSIM_TSAN_ON
+  __tsan_acquire(&W->sync_launch);  // after everything the previous workgroup on this worker did
+#endif
   W->tramp(W->closure);
+#if HIPSIM_TSAN_ON
+  __tsan_release(&W->sync_launch);
+#endif
   cur->state = S_DONE;
   to_scheduler();
   fprintf(stderr, "hipsim: a finished lane was resumed\n");
@@ -87,12 +113,24 @@ uint64_t wave_collective(int op, int site, uint64_t payload, int src) {
   Lane* me = cur;
   me->op = op; me->site = site; me->payload = payload; me->src = src;
   me->state = S_WAVE;
+#if HIPSIM_TSAN_ON
+  __tsan_release(&W->sync_wave[me->wave]);
+#endif
   to_scheduler();
+#if HIPSIM_TSAN_ON
+  __tsan_acquire(&W->sync_wave[me->wave]);
+#endif
   return me->result;
 }
 void sync_threads() {
   cur->state = S_SYNC;
+#if HIPSIM_TSAN_ON
+  __tsan_release(&W->sync_block);
+#endif
   to_scheduler();
+#if HIPSIM_TSAN_ON
+  __tsan_acquire(&W->sync_block);
+#endif
 }
 void yield() {
   if (!cur) return;  // host code
@@ -162,6 +200,10 @@ static void run_block(const dim3& grid, const dim3& block, unsigned long long b)
     for (int k = 3; k <= 8; k++) top[-k] = nullptr;      // rbp rbx r12 r13 r14 r15
     l.sp = top - 8;
   }
+#if HIPSIM_TSAN_ON
+  w->sched_fiber = __tsan_get_current_fiber();
+  __tsan_release(&w->sync_launch);  // the host side of the launch happens before the lanes
+#endif
   const int nw = (nt + 63) / 64;
   long long idle_rounds = 0;
   unsigned rng_state = order_seed + (unsigned)b * 747796405u;
@@ -182,7 +224,15 @@ static void run_block(const dim3& grid, const dim3& block, unsigned long long b)
           int i = l0 + q;
           if (lane_order == 1) i = l1 - 1 - q;
           else if (lane_order == 2 && nl == 64) i = l0 + (int)((rot + (unsigned)q * step) & 63u);
-          if (L[i].state == S_RUN) { cur = &L[i]; hipsim_swap(&w->sched_sp, L[i].sp); ran++; }
+          if (L[i].state == S_RUN) {
+            cur = &L[i];
+#if HIPSIM_TSAN_ON
+            if (!w->lane_fiber[i]) w->lane_fiber[i] = __tsan_create_fiber(0);
+            __tsan_switch_to_fiber(w->lane_fiber[i], 0);
+#endif
+            hipsim_swap(&w->sched_sp, L[i].sp);
+            ran++;
+          }
         }
         cur = nullptr;
         int n_run = 0, n_wave = 0, n_live = 0;
@@ -195,7 +245,12 @@ static void run_block(const dim3& grid, const dim3& block, unsigned long long b)
     }
     int n_run = 0, n_sync = 0, n_done = 0;
     for (int i = 0; i < nt; i++) { n_run += L[i].state == S_RUN; n_sync += L[i].state == S_SYNC; n_done += L[i].state == S_DONE; }
-    if (n_done == nt) return;
+    if (n_done == nt) {
+#if HIPSIM_TSAN_ON
+      __tsan_acquire(&w->sync_launch);
+#endif
+      return;
+    }
     if (n_run == 0) {
       if (n_sync + n_done != nt) { fprintf(stderr, "hipsim: scheduler inconsistency\n"); abort(); }
       for (int i = 0; i < nt; i++)
