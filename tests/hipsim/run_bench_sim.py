@@ -41,6 +41,15 @@ def main():
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.zeros = _cpu_device(torch.zeros)
     torch.tensor = _cpu_device(torch.tensor)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # one process per "GPU": RCCL becomes gloo, everything else of the N > 1 path is bench.py's own
+        import torch.distributed as dist
+
+        real_init = dist.init_process_group
+
+        def init_gloo(backend=None, device_id=None, **kw):
+            return real_init(backend="gloo", **kw)
+
+        dist.init_process_group = init_gloo
     sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 
