@@ -272,7 +272,7 @@ def main():
     rec_dev = torch.zeros((nb_max, pq.RECORD_WIDTH), dtype=torch.float64, device="cuda")
     job_records = {}
     last_results = [None] * G
-    thread_busy = {"front_end": 0.0, "loop": 0.0}
+    thread_busy = {"front_end": 0.0, "loop": 0.0, "gather_wait": 0.0}
 
     def run_pipeline(K):
         """K steps through the pipeline; returns when every pair of every step is registered and its records are gathered."""
@@ -381,8 +381,10 @@ def main():
                 break
             flat = [st for r in res[k] for st in r]
             rec_dev.copy_(torch.from_numpy(pq.pack_records(mine, [(st.iterations, st.converged, st.Rt[:]) for st in flat], nb_max)))
+            tg = time.perf_counter()
             job_records.clear()
             job_records.update(pq.gather_records(rec_dev, dist))  # every rank holds every pair's record of the step
+            thread_busy["gather_wait"] += time.perf_counter() - tg  # waiting for the slowest rank of the step (+ the transfer itself)
         for x in th:
             x.join()
         if err:
@@ -401,13 +403,16 @@ def main():
         run_pipeline(NBUF)
     for c in ctxs:
         c.kernel_timing(True)
-    thread_busy["front_end"] = thread_busy["loop"] = 0.0
+    thread_busy["front_end"] = thread_busy["loop"] = thread_busy["gather_wait"] = 0.0
     barrier()
     t0 = time.perf_counter()
     run_pipeline(args.steps)
+    time_own = time.perf_counter() - t0  # before the closing barrier
     barrier()
     elapsed = time.perf_counter() - t0
-    busy_mine = elapsed  # this rank's own wall time for its share (before the max over ranks)
+    # this rank's own wall time for its share: the timed region minus what it spent waiting in the per-step all-gathers for slower
+    # ranks (the closing barrier is inside `elapsed`, so elapsed itself is the same on every rank)
+    busy_mine = max(0.0, time_own - thread_busy["gather_wait"])
     busy_all = [busy_mine]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
