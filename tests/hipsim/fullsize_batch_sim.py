@@ -2,7 +2,7 @@
 path on the host SIMT interpreter (tests/hipsim) -- checks the batch's index arithmetic at the size bench.py runs it; no GPU needed (~3 min)."""
 import sys, importlib, time
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 api = importlib.import_module("gh-icp_amd.api")

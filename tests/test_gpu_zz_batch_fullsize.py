@@ -1,6 +1,6 @@
 """Batched front end at the size bench.py runs it (BASELINE.json configs[1]: 1 M-point scans): ghicp_clouds_recompute of several full-size
 clouds == ghicp_cloud_recompute cloud by cloud, bit for bit.  (The same comparison for 32 clouds = 32 M points runs on the host SIMT
-interpreter: scripts/sim_fullsize_batch.py, profiles/r02_sim_fullsize_batch.txt.)  Sorted last on purpose."""
+interpreter: tests/hipsim/fullsize_batch_sim.py, profiles/r02_sim_fullsize_batch.txt.)  Sorted last on purpose."""
 import numpy as np
 import pytest
 
