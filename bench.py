@@ -251,8 +251,21 @@ def main():
         else:
             try:
                 fe_cal["cloud_by_cloud_clouds_per_s"] = round(fe_sample_rate(0, nstream, sample), 1)
-                fe_cal["batched_clouds_per_s"] = round(fe_sample_rate(args.fe_batch_size, min(nstream, args.fe_batch_streams), sample), 1)
-                args.fe_batch = args.fe_batch_size if fe_cal["batched_clouds_per_s"] > fe_cal["cloud_by_cloud_clouds_per_s"] else 0
+                # batched candidates: the given size / streams, and the same clouds in flight split the other ways
+                cands = [(args.fe_batch_size, args.fe_batch_streams), (max(2, args.fe_batch_size // 2), args.fe_batch_streams * 2),
+                         (min(64, args.fe_batch_size * 2), max(1, args.fe_batch_streams // 2))]
+                rates = {}
+                for size, streams in cands:
+                    streams = max(1, min(nstream, streams))
+                    if (size, streams) not in rates:
+                        rates[(size, streams)] = round(fe_sample_rate(size, streams, sample), 1)
+                fe_cal["batched_clouds_per_s_by_size_x_streams"] = {"%dx%d" % k: v for k, v in rates.items()}
+                (best_size, best_streams), best = max(rates.items(), key=lambda kv: kv[1])
+                fe_cal["batched_clouds_per_s"] = best
+                if best > fe_cal["cloud_by_cloud_clouds_per_s"]:
+                    args.fe_batch, args.fe_batch_streams = best_size, best_streams
+                else:
+                    args.fe_batch = 0
             except Exception as e:  # noqa: BLE001
                 fe_cal["error"] = repr(e)[:300]
                 args.fe_batch = 0

@@ -14,11 +14,12 @@ pairs = [synth.tls_pair(1_000_000, pair_id=i) for i in range(4)]
 print("gen", time.time()-t, flush=True)
 cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, dof=6, voxel=0.1, pattern=synth.bsc_pattern_glibc(), max_iter=200)
 base = [x for p in pairs for x in (p.source, p.target)]
-raws = [base[i % len(base)] for i in range(32)]
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+raws = [base[i % len(base)] for i in range(NB)]
 batch = [ctx.cloud_create(cfg, base[0][:0]) for _ in raws]
 t=time.time()
 ctx.clouds_recompute(batch, raws)
-print("batch of 32 x 1M", time.time()-t, flush=True)
+print("batch of %d x 1M" % NB, time.time()-t, flush=True)
 single = [ctx.cloud_create(cfg, base[0][:0]) for _ in base]
 for c, r in zip(single, base): c.recompute(r)
 for i, d in enumerate(batch):
@@ -28,4 +29,4 @@ for i, d in enumerate(batch):
     da, db = c.download(), d.download()
     for key in ("ds", "kp", "kp_xyz", "feat"):
         assert np.array_equal(da[key].cpu().numpy(), db[key].cpu().numpy()), (i, key)
-print("32 x 1M BATCH == SINGLE", [b.info().k for b in batch[:8]], simctx.counters(ctx.lib))
+print("%d x 1M BATCH == SINGLE" % NB, [b.info().k for b in batch[:8]], simctx.counters(ctx.lib))
