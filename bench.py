@@ -66,7 +66,7 @@ def _gen_worker(a):
 
 def _oracle_worker(a):
     """One distinct pair through the CPU restatement (spawned process: no HIP in here)."""
-    config_id, pair_id, hits, native, start_at = a
+    config_id, pair_id, hits, native, start_at, check = a
     from oracle import oracle as O  # baseline / checker only
 
     if native:
@@ -81,7 +81,7 @@ def _oracle_worker(a):
     t0 = time.time()
     r = O.register_pair(*a, max_iter=200)  # timed: the -O3 -march=native build
     t1 = time.time()
-    if native:  # parity: the contract build (-O2, the one the tests pin; -O3 vectorisation changes the f32 rigid solve by an ulp)
+    if native and check:  # parity: the contract build (-O2, the one the tests pin; -O3 vectorisation changes the f32 rigid solve by an ulp)
         O.use_library(os.path.join(ROOT, "oracle", "libghicp_oracle.so"))
         r = O.register_pair(*a, max_iter=200)
     r["t0"], r["t1"], r["pair_id"] = t0, t1, pair_id
@@ -91,10 +91,6 @@ def _oracle_worker(a):
 def algorithmic_bytes(k, m, n2, V, kernel, batch):
     """SURVEY.md §8(d) compulsory traffic of ONE launch of `kernel` (bytes).  k = mean keypoints per cloud, m = mean down-sampled
     points per cloud, n2 = mean n^2 of the KM graph, V = source BSC variants, batch = pairs per batched launch."""
-    if kernel == "pca_cells":  # S1: 16 B in + 24 B out (lambda 3xf32, curvature f64, count i32) per point; one launch per cloud
-        return (16 + 24) * m
-    if kernel == "bsc":  # S3: 16*M in + 56*V*K + 48*K out, per cloud (average of source: V variants and target: 1)
-        return 16 * m + 56 * 0.5 * (V + 1) * k + 48 * k
     if kernel == "km_solve":  # S5 KM: the n x n f64 weight matrix must be seen at least once per pair (dense-equivalent)
         return 8.0 * n2 * batch
     if kernel == "cd_rowmin":  # S5 sweep: keypoints + u16 FD in, row minima out
@@ -103,11 +99,55 @@ def algorithmic_bytes(k, m, n2, V, kernel, batch):
         return (24.0 * 2 * k + 4.0 * k * k) * batch
     if kernel == "fd_bsc":
         return 56.0 * (V + 1) * k + 2.0 * k * k
-    if kernel == "nms_round":  # S2: 20 B per down-sampled point in (xyz + curvature), 4 B per keypoint out; one launch per cloud
-        return 20.0 * m + 4.0 * k
-    if kernel == "voxel_sort":  # S0: 16 B per raw point in + 16 B per kept point out; one launch per cloud
-        return float("nan")
     return float("nan")
+
+
+def front_end_bytes_per_cloud(kernel, n, m, c, k, V, grids):
+    """Compulsory traffic of one front-end STAGE for one cloud (every input of the stage read once, every output written once; raw
+    points 12 B, float4 points 16 B; the stage's own intermediates -- sort keys, flags, index lists -- count because the next stage
+    consumes them).  n raw points, m down-sampled points, c NMS candidates, k keypoints; `grids` = cell grids built per cloud."""
+    if kernel == "voxel_sort":   # stable radix sort of (u64 voxel key, u32 index): read once, write once
+        return 24.0 * n
+    if kernel == "fb_voxel":     # keys (12 n in, 12 n out); run-head flags (8 n in, n out) + select (n in, 4 m out); gather (8 m + 12 m in, 16 m out); box (16 m)
+        return 34.0 * n + 56.0 * m
+    if kernel == "fb_grid":      # per grid: cell keys (16 m in, 8 m out), sort of (u32, u32) (16 m), points in cell order (20 m in, 16 m out), cell table (4 m in, ~4 m out); + the occupied-cell list of the PCA grid (8 m)
+        return grids * 84.0 * m + 8.0 * m
+    if kernel == "pca_cells":    # S1: 16 B in + 24 B out (lambda 3 x f32, curvature f64, count i32) per point
+        return 40.0 * m
+    if kernel == "fb_prune":     # lambda + count in (16 m), flag out + in (2 m), candidate ids out (4 c)
+        return 18.0 * m + 4.0 * c
+    if kernel == "fb_rank":      # curvature keys (12 c in, 12 c out), 64-bit sort (24 c), cloud-id pass (8 c + 16 c), candidate points (24 c in, 12 c out), box (12 c)
+        return 120.0 * c
+    if kernel == "nms_round":    # S2 sweep: 12 B per candidate in, ranks 4 c in, keypoint ids 4 k out (SURVEY's S2 = this + fb_prune + fb_rank)
+        return 16.0 * c + 4.0 * k
+    if kernel == "fb_out":       # down-sampled cloud into its handle (16 m in, 16 m out), keypoint ids / f64 coordinates / LCS origins (40 k), zeroed strings (224 k)
+        return 32.0 * m + 264.0 * k
+    if kernel == "bsc":          # S3: 16 m in + 56 V k + 48 k out (average of source: V variants, target: 1)
+        return 16.0 * m + 56.0 * 0.5 * (V + 1) * k + 48.0 * k
+    return float("nan")
+
+
+def pair_bytes(n, m, c, k_s, k_t, V, iters, corr_km, cor):
+    """B_pair of SURVEY.md §8(d) without S7 (the final transform of the raw source cloud, main:153, is not part of a step):
+    both clouds' S0-S3, S4 once, `iters` x (S5 + S6)."""
+    per_cloud = (16.0 * n + 16.0 * m) + 36.0 * m + (20.0 * m + 4.0 * 0.5 * (k_s + k_t)) + (16.0 * m + 56.0 * 0.5 * (V + 1) * 0.5 * (k_s + k_t) + 48.0 * 0.5 * (k_s + k_t))
+    s4 = 56.0 * (V * k_s + k_t) + 2.0 * k_s * k_t
+    nn = float(max(k_s, k_t))
+    s5 = 24.0 * (k_s + k_t) + 2.0 * k_s * k_t + 12.0 * (k_s + k_t) + (16.0 * nn * nn if corr_km else 0.0)
+    s6 = 48.0 * cor + 48.0 * k_s
+    return 2.0 * per_cloud + s4 + iters * (s5 + s6)
+
+
+def compact(d, limit=5000):
+    """The driver keeps an 8 KB tail of stdout: the ONE JSON line must stay far below that."""
+    line = json.dumps(d, separators=(",", ":"))
+    if len(line) <= limit:
+        return line
+    for key in ("batch_ms", "km_launch_stats", "rank_wall_s", "notes"):
+        if key in d and len(line) > limit:
+            d = {k: v for k, v in d.items() if k != key}
+            line = json.dumps(d, separators=(",", ":"))
+    return line
 
 
 def main():
@@ -130,7 +170,9 @@ def main():
                     "-1 = calibrate: time both front ends on a sample before the warm-up and use the faster one")
     ap.add_argument("--fe-batch-size", type=int, default=32, help="clouds per launch sequence when --fe-batch -1 picks the batched front end")
     ap.add_argument("--fe-batch-streams", type=int, default=4, help="worker contexts of the batched front end")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(distinct, host CPUs))")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = every logical CPU of the host; the distinct scenes are cycled)")
+    ap.add_argument("--queue", default="static", choices=["static", "dynamic"], help="pair queue across ranks: static p mod R, or chunks claimed from a shared counter")
+    ap.add_argument("--detail-dir", default=os.path.join(ROOT, "gpurun_out"), help="where the per-scene / per-kernel side file goes")
     args = ap.parse_args()
     CF = CONFIGS[args.config]
     hits = args.hits or CF["hits"]
@@ -446,15 +488,26 @@ def main():
         return
 
     flat = [st for r in results for st in r]
-    by_scene = {}
+    by_scene, cand_of = {}, {}
+    last_buf = pool_h[(args.steps - 1) % NBUF] if args.steps > 0 else pool_h[0]
     for i, st in enumerate(flat):
-        by_scene.setdefault(manifest[mine[i]], st)
+        sid = manifest[mine[i]]
+        if sid not in by_scene:
+            by_scene[sid] = st
+            try:  # NMS candidates of the two clouds (recorded by the batched front end; 0 otherwise)
+                cand_of[sid] = 0.5 * (last_buf[i][0].info().candidates + last_buf[i][1].info().candidates)
+            except Exception:  # noqa: BLE001
+                cand_of[sid] = 0.0
     pairs_total = args.steps * n_job
     value = pairs_total / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     sts = list(by_scene.values())
     k_mean = float(np.mean([0.5 * (s.k_s + s.k_t) for s in sts]))
     m_mean = float(np.mean([0.5 * (s.m_s + s.m_t) for s in sts]))
+    n_mean = float(np.mean([0.5 * (s.n_s + s.n_t) for s in sts]))
+    c_mean = float(np.mean(list(cand_of.values()))) if cand_of else 0.0
+    if c_mean <= 0:
+        c_mean = 0.1 * m_mean  # cloud-by-cloud front end does not record it: typical share of the down-sampled points
     n2_mean = float(np.mean([max(s.k_s, s.k_t) ** 2 for s in sts]))
     it_mean = float(np.mean([s.iterations for s in sts]))
     V = 4 if CF["dof"] > 4 else 2
@@ -474,46 +527,43 @@ def main():
     single_latency = float(np.median(lat))
     ms_iter_single = float(np.median(lat_loop)) / lat_it
 
-    # ---- roofline of the dominant kernel (largest share of HIP-event kernel time over the timed region)
-    dom = max((k for k in ktimes if not k.startswith("fb_")), key=lambda k: ktimes[k][0])  # fb_*: glue stages of the batched front end, reported below only
-    dom_ms, dom_n = ktimes[dom]
-    avg_ms = dom_ms / max(1, dom_n)
-    # solves per Kuhn-Munkres launch, measured: a batch is launched per LDS-occupancy class and converged pairs drop out, so a launch
-    # holds far fewer solves than the group has pairs (the launch records count the solves that actually ran)
+    # ---- roofline: per kernel / stage (HIP events on the kernel's own stream, summed over the timed region), the dominant kernel,
+    # and the whole pair (SURVEY §8d asks for both)
+    clouds_total = 2.0 * nb * args.steps
+    grids = 2 if CF["feature"] in ("BSC", "FPFH") else 1
+    FE_STAGES = ("voxel_sort", "fb_voxel", "fb_grid", "pca_cells", "fb_prune", "fb_rank", "nms_round", "fb_out", "bsc")
     km_solves = sum(s["solves"] for s in kml) if kml else 0
     km_batch = km_solves / max(1, ktimes["km_solve"][1]) if km_solves else shard_b
-    b_alg = algorithmic_bytes(k_mean, m_mean, n2_mean, V, dom, km_batch if dom == "km_solve" else shard_b)
-    achieved = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and b_alg == b_alg else 0.0
     per_kernel = {}
-    PER_CLOUD = ("pca_cells", "bsc", "nms_round", "voxel_sort")  # one launch per cloud, or per batch of clouds (ghicp_clouds_recompute)
-
-    def clouds_per_launch(k):
-        return (2.0 * nb * args.steps / max(1, ktimes[k][1])) if k in PER_CLOUD else 1.0
-
-    if dom in PER_CLOUD:
-        b_alg *= clouds_per_launch(dom)
-        achieved = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and b_alg == b_alg else 0.0
-    for k, v in ktimes.items():
-        ba = algorithmic_bytes(k_mean, m_mean, n2_mean, V, k, km_batch if k == "km_solve" else shard_b) * clouds_per_launch(k)
-        per_kernel[k] = {"ms_total": round(v[0], 3), "launches": v[1], "clouds_per_launch": round(clouds_per_launch(k), 2) if k in PER_CLOUD else None,
-                         "GBps": round(ba / (v[0] / max(1, v[1]) * 1e-3) / 1e9, 2) if v[0] > 0 and ba == ba else None}
-    traffic, traffic_note = None, None
+    for k, (ms_tot, cnt) in ktimes.items():
+        if k in FE_STAGES:
+            total_bytes = front_end_bytes_per_cloud(k, n_mean, m_mean, c_mean, k_mean, V, grids) * clouds_total
+        else:
+            total_bytes = algorithmic_bytes(k_mean, m_mean, n2_mean, V, k, km_batch if k == "km_solve" else shard_b) * cnt
+        per_kernel[k] = {"ms_total": round(ms_tot, 3), "launches": cnt, "alg_bytes_total": int(total_bytes) if total_bytes == total_bytes else None,
+                         "GBps": round(total_bytes / (ms_tot * 1e-3) / 1e9, 2) if ms_tot > 0 and total_bytes == total_bytes else None}
+    dom = max(ktimes, key=lambda k: ktimes[k][0])
+    dom_ms, dom_n = ktimes[dom]
+    avg_ms = dom_ms / max(1, dom_n)
+    b_alg = (per_kernel[dom]["alg_bytes_total"] or 0) / max(1, dom_n)
+    achieved = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    cor_mean = 0.5 * k_mean  # correspondences per iteration are not part of the result record: half the keypoints (S6 is < 0.1 % of B_pair)
+    b_pair = float(np.mean([pair_bytes(0.5 * (s.n_s + s.n_t), 0.5 * (s.m_s + s.m_t), c_mean, s.k_s, s.k_t, V, s.iterations, CF["corr"] == "KM", cor_mean) for s in sts]))
+    whole_pair_gbs = b_pair * value / 1e9
+    traffic, traffic_src = None, None
     try:  # HBM-side traffic of the dominant kernel from the committed PMC passes (counters cannot be collected inside this run)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if dom in pmc:
             units = (km_batch if dom == "km_solve" else shard_b) if pmc[dom]["per"] in ("solve", "pair") else 1
             traffic = int(pmc[dom]["bytes"] * units)
-            traffic_note = "%d B per %s x %.1f (%s)" % (pmc[dom]["bytes"], pmc[dom]["per"], units, pmc["source"])
+            traffic_src = "%d B per %s x %.1f, %s" % (pmc[dom]["bytes"], pmc[dom]["per"], units, pmc["source"])
     except (OSError, ValueError, KeyError):
         pass
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 4),
-                "launches": dom_n, "alg_bytes_per_launch": int(b_alg) if b_alg == b_alg else None,
-                "note": ("km_solve reproduces an order-dependent sequential solver (exact result of the reference's DFS): latency-, not "
-                         "bandwidth-bound; %.1f solves per launch on average (launches per LDS-occupancy class; converged pairs drop out), %d solves in the run"
-                         % (km_batch, km_solves)) if dom == "km_solve" else
-                        ("%s has the largest summed HIP-event time over all streams (launches of different streams overlap in wall time)" % dom),
-                "per_kernel": per_kernel}
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,
+                "alg_bytes_per_launch": int(b_alg),
+                "whole_pair_frac": round(whole_pair_gbs / HBM_PEAK_GBS, 6), "whole_pair_GBps": round(whole_pair_gbs, 2), "alg_bytes_per_pair": int(b_pair),
+                "per_kernel_GBps": {k: v["GBps"] for k, v in per_kernel.items() if v["launches"]}}
     km_stats = None
     if kml and sum(s["launches"] for s in kml) > 0:
         L = sum(s["launches"] for s in kml)
@@ -522,11 +572,10 @@ def main():
                     "mean_longest_solve_per_launch_ms": round(sum(s["mean_longest_solve_ms"] * s["launches"] for s in kml) / L, 3),
                     "mean_launch_span_ms": round(sum(s["mean_launch_span_ms"] * s["launches"] for s in kml) / L, 3),
                     "solve_slots_on_chip": int(max(s["slots"] for s in kml)),
-                    "idle_slot_fraction_per_group": [round(s["idle_slot_fraction"], 4) for s in kml],
-                    "worst_longest_over_mean": round(max(s["worst_longest_over_mean"] for s in kml), 2)}
+                    "idle_slot_fraction": round(float(np.mean([s["idle_slot_fraction"] for s in kml])), 4)}
 
     # ---- CPU legs (oracle = faithful PCL-free restatement of the reference path) + parity of EVERY distinct pair
-    cpu, check, workload_stats = None, None, None
+    cpu, check, workload_stats, cpu_detail = None, None, None, None
     if world == 1 and args.cpu_baseline:
         from oracle import oracle as O  # checker / baseline only
 
@@ -543,26 +592,33 @@ def main():
             one.append(r1["seconds"])
         t_pair = float(np.median([o["total"] for o in one]))
         stage_med = {k: round(float(np.median([o[k] for o in one])), 3) for k in one[0]}
-        # (ii) all host cores: every distinct scene in its own process, started together
+        # (ii) all host cores: the distinct scenes cycled over min(host CPUs, --cpu-procs) processes, started together
         ids = sorted(by_scene)
-        procs = max(1, min(args.cpu_procs or len(ids), len(ids), (os.cpu_count() or 2)))
-        start_at = time.time() + (25.0 if big else 12.0) + 0.2 * len(ids)
+        ncpu = os.cpu_count() or 2
+        procs = max(1, min(args.cpu_procs or ncpu, ncpu))
+        jobs_cpu = [ids[i % len(ids)] for i in range(max(procs, len(ids)))]
+        start_at = time.time() + (25.0 if big else 12.0) + 0.1 * len(jobs_cpu)
         with mp.get_context("spawn").Pool(procs) as pool:
-            ora = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at) for sid in ids], chunksize=1)
-        wall = max(r["t1"] for r in ora) - min(r["t0"] for r in ora)
+            ora_all = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at, j < len(ids)) for j, sid in enumerate(jobs_cpu)], chunksize=1)
+        wall = max(r["t1"] for r in ora_all) - min(r["t0"] for r in ora_all)
+        ora = ora_all[:len(ids)]  # one checked result per distinct scene (the repeats only load the other cores)
+        cpu_model = ""
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except (OSError, IndexError):
+            pass
         cpu = {"value": round(1.0 / t_pair, 5), "unit": "pairs/s", "cores": 1, "kind": "port",
-               "sample": "pair %d of the batch, complete (front end + loop), %s; stages (s): %s; oracle = PCL-free restatement of the "
-                         "reference path (the reference needs PCL/Eigen/FLANN, not installable here), g++ -O3 -march=native, 1 thread"
-                         % (sid0, "single run (5 M / 10 M points)" if big else "median of 3 runs", json.dumps(stage_med)),
-               "all_cores": {"value": round(len(ids) / wall, 4), "unit": "pairs/s", "cores": procs, "host_logical_cpus": os.cpu_count(),
-                             "sample": "%d distinct pairs of the batch, one process each, started together; wall %.1f s" % (len(ids), wall)}}
+               "sample": "pair %d complete (front end + loop), %s, g++ -O3 -march=native" % (sid0, "1 run" if big else "median of 3"),
+               "stages_s": stage_med, "host": "%d logical CPUs, %s" % (ncpu, cpu_model),
+               "all_cores": {"value": round(len(jobs_cpu) / wall, 4), "cores": procs, "pairs": len(jobs_cpu), "wall_s": round(wall, 1)}}
         workload_stats = {"k_bar": round(float(np.mean([r["k_bar"] for r in ora])), 1), "m_bar": round(float(np.mean([r["m_bar"] for r in ora])), 1)}
-        rot, tra, it_ok, kp_ok, bad = [], [], 0, 0, []
+        rot, tra, it_ok, kp_ok, ok_ok, bad = [], [], 0, 0, 0, []
         for r in ora:
             st = by_scene[r["pair_id"]]
             Rg = np.array(st.Rt[:]).reshape(4, 4)
             it_ok += int(st.iterations == r["iters"])
             kp_ok += int((st.k_s, st.k_t) == (r["k_s"], r["k_t"]))
+            ok_ok += int(int(st.registered_ok) == int(r["registered_ok"]))
             if np.isfinite(r["Rt"]).all() and np.isfinite(Rg).all():
                 rot.append(synth.rot_err(Rg, r["Rt"]))
                 tra.append(synth.trans_err(Rg, r["Rt"]))
@@ -570,47 +626,68 @@ def main():
                     bad.append(r["pair_id"])
             elif np.isfinite(r["Rt"]).all() != np.isfinite(Rg).all():
                 bad.append(r["pair_id"])
-        check = {"pairs_checked": len(ora), "iterations_match": it_ok, "keypoints_match": kp_ok,
+        check = {"pairs_checked": len(ora), "iterations_match": it_ok, "keypoints_match": kp_ok, "registered_ok_match": ok_ok,
                  "max_rot_err_vs_oracle": round(max(rot), 9) if rot else None, "max_trans_err_vs_oracle_m": round(max(tra), 9) if tra else None,
-                 "tolerance": "1e-4 rotation (||R_gpu R_cpu^T - I||_F), 1e-3 m translation", "pairs_outside_tolerance": bad,
-                 "all_ok": (not bad) and it_ok == len(ora) and kp_ok == len(ora)}
+                 "tolerance": "1e-4 rot (||R_gpu R_cpu^T - I||_F), 1e-3 m", "pairs_outside_tolerance": bad[:16],
+                 "all_ok": (not bad) and it_ok == len(ora) and kp_ok == len(ora) and ok_ok == len(ora)}
 
-    gts = [synth.rot_err(np.array(by_scene[sid].Rt[:]).reshape(4, 4), scene[sid][2]) for sid in by_scene if sid in scene]
-    gtt = [synth.trans_err(np.array(by_scene[sid].Rt[:]).reshape(4, 4), scene[sid][2]) for sid in by_scene if sid in scene]
+    # ---- success accounting: the reference's own verdict (ghicp_reg.cpp:918-924) and the distance from ground truth
+    gt = {sid: (synth.rot_err(np.array(st.Rt[:]).reshape(4, 4), scene[sid][2]), synth.trans_err(np.array(st.Rt[:]).reshape(4, 4), scene[sid][2]))
+          for sid, st in by_scene.items() if sid in scene}
+    # every pair of a step cycles the distinct scenes, so the step's counts follow from the distinct ones
+    scene_count = {}
+    for p in mine:
+        scene_count[manifest[p]] = scene_count.get(manifest[p], 0) + 1
+    reg_ok_pairs = sum(scene_count[sid] for sid, st in by_scene.items() if st.registered_ok)
+    gt_ok_pairs = sum(scene_count[sid] for sid, e in gt.items() if np.isfinite(e).all() and e[0] <= 0.05 and e[1] <= 0.5)
+    gt_fail = sorted(sid for sid, e in gt.items() if not (np.isfinite(e).all() and e[0] <= 0.05 and e[1] <= 0.5))
+    nb_eff = max(1, len(mine))
     out = {
         "metric": "registered_pairs_per_sec", "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": CF["scaling"], "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s, voxel %g m, r_pca %g, R_nms %g, %s + %s, %d-DoF; %d %s scenes per GPU cycled over %d pairs per step%s; "
-                               "%d front-end streams (%s), then %d concurrent batched loop groups; pair manifest broadcast + one result all-gather per step"
-                               % (CF["name"], CF["voxel"], CF["r"], CF["R"], CF["feature"], CF["corr"], CF["dof"], len(by_scene), "distinct",
-                                  nb, " (whole job: %d, sharded over the ranks)" % n_job if strong else " per GPU", fe_n,
-                                  "%d clouds per batched launch sequence" % args.fe_batch if args.fe_batch > 1 else "cloud by cloud", G),
-                   "config_id": args.config, "fe_batch": args.fe_batch, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene), "raw_cloud_bytes_resident": int(sum(s.numel() * 4 + t.numel() * 4 for s, t in dev.values())),
+        "config": {"workload": "%s, voxel %g m, r_pca %g, R_nms %g, %s+%s, %d-DoF; %d distinct scenes/GPU cycled over %d pairs/step%s; front end: %s; loops: %d group(s)"
+                               % (CF["name"], CF["voxel"], CF["r"], CF["R"], CF["feature"], CF["corr"], CF["dof"], len(by_scene),
+                                  nb, " (job: %d over the ranks)" % n_job if strong else "/GPU",
+                                  "%d clouds/launch sequence x %d streams" % (args.fe_batch, fe_n) if args.fe_batch > 1 else "cloud by cloud x %d streams" % fe_n, G),
+                   "config_id": args.config, "fe_batch": args.fe_batch, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene),
                    "n_s": int(sts[0].n_s), "m_mean": round(m_mean), "k_mean": round(k_mean, 1), "n_km_max": int(max(max(s.k_s, s.k_t) for s in sts)),
                    "iterations_mean": round(it_mean, 1), "iterations_min_max": [int(min(s.iterations for s in sts)), int(max(s.iterations for s in sts))],
-                   "parallelism": "pairs sharded over ranks (pair p -> rank p mod R), no data-path collective"},
-        "ms_per_iteration": round(ms_iter_single, 4),
-        "ms_per_iteration_note": "ONE pair alone on the GPU: loop time / iterations (pair %d, %d iterations); in the batch every in-flight pair advances one "
-                                 "iteration per %.1f ms (step time / mean iterations)" % (sid0, lat_it, ms_per_step / max(1.0, it_mean)),
+                   "parallelism": "pairs sharded over ranks (%s), no data-path collective" % args.queue},
+        "registered_ok": {"pairs_per_step_rank0": nb_eff, "reference_verdict_ok": int(reg_ok_pairs), "gt_ok": int(gt_ok_pairs),
+                          "gt_tolerance": "0.05 rot (||R R_gt^T - I||_F), 0.5 m", "distinct_scenes_gt_failed": gt_fail[:24],
+                          "value_gt_ok": round(value * gt_ok_pairs / nb_eff, 4), "value_reference_verdict_ok": round(value * reg_ok_pairs / nb_eff, 4),
+                          "max_rot_vs_gt": round(max(e[0] for e in gt.values()), 4) if gt else None,
+                          "max_trans_vs_gt_m": round(max(e[1] for e in gt.values()), 3) if gt else None},
+        "ms_per_iteration": round(ms_iter_single, 4), "ms_per_iteration_in_batch": round(ms_per_step / max(1.0, it_mean), 2),
         "single_pair_latency_s": round(single_latency, 4),
-        "batch_ms": {"front_end_thread_seconds_per_step": round(thread_busy["front_end"] / max(1, args.steps), 2), "front_end_threads": fe_n, "front_end_calibration": fe_cal,
-                     "loop_thread_seconds_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G,
-                     "front_end_ms_per_cloud_on_its_stream": round(1e3 * thread_busy["front_end"] / max(1, args.steps) / max(1, 2 * nb), 4),
-                     "note": "thread seconds are summed over the worker threads; --pipeline %d" % args.pipeline},
+        "batch_ms": {"front_end_thread_s_per_step": round(thread_busy["front_end"] / max(1, args.steps), 2), "front_end_threads": fe_n,
+                     "loop_thread_s_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G, "pipeline": args.pipeline,
+                     "front_end_ms_per_cloud_on_its_stream": round(1e3 * thread_busy["front_end"] / max(1, args.steps) / max(1, 2 * nb), 4)},
         "km_launch_stats": km_stats,
-        "scenes": [{"pair_id": int(sid), "k_s": int(st.k_s), "k_t": int(st.k_t), "m_s": int(st.m_s), "m_t": int(st.m_t), "iterations": int(st.iterations),
-                    "converged": int(st.converged), "Rt": [float(v) for v in st.Rt[:]]} for sid, st in sorted(by_scene.items())][:(64 if args.config == 2 else 256)],
         "rank_wall_s": {"per_rank": [round(b, 3) for b in busy_all], "imbalance_max_over_mean": round(max(busy_all) / max(1e-9, float(np.mean(busy_all))), 4)},
-        "gt_error": {"max_rot": round(max(gts), 6) if gts else None, "max_trans_m": round(max(gtt), 5) if gtt else None},
-        "roofline": roofline, "cpu_baseline": cpu, "parity_check": check, "gen_seconds": round(gen_s, 1),
+        "roofline": roofline, "cpu_baseline": cpu, "parity_check": check,
     }
     if workload_stats:
         out["config"].update(workload_stats)  # measured on the CPU leg: mean neighbours per PCA query / points per BSC sphere
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(value / cpu["value"], 2)
         out["speedup_vs_cpu_all_cores"] = round(value / cpu["all_cores"]["value"], 2)
-    print(json.dumps(out))
+    # ---- everything that does not fit an 8 KB tail goes to a side file: per-scene records (4x4s), per-kernel table, calibration
+    detail = {"scenes": [{"pair_id": int(sid), "k_s": int(st.k_s), "k_t": int(st.k_t), "m_s": int(st.m_s), "m_t": int(st.m_t), "iterations": int(st.iterations),
+                          "converged": int(st.converged), "registered_ok": int(st.registered_ok), "rmse_after": float(st.rmse_after),
+                          "rot_vs_gt": float(gt[sid][0]) if sid in gt else None, "trans_vs_gt_m": float(gt[sid][1]) if sid in gt else None,
+                          "Rt": [float(v) for v in st.Rt[:]]} for sid, st in sorted(by_scene.items())],
+              "per_kernel": per_kernel, "front_end_calibration": fe_cal, "traffic_source": traffic_src, "gen_seconds": round(gen_s, 1),
+              "roofline_models": "per-stage bytes: bench.py front_end_bytes_per_cloud / algorithmic_bytes; whole pair: pair_bytes (SURVEY 8d without S7)",
+              "line": out}
+    try:
+        os.makedirs(args.detail_dir, exist_ok=True)
+        with open(os.path.join(args.detail_dir, "bench_detail_cfg%d.json" % args.config), "w") as f:
+            json.dump(detail, f)
+    except OSError:
+        pass
+    print(compact(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -40,7 +40,8 @@ class PairConfig(C.Structure):
 class PairStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_s", "n_t", "m_s", "m_t", "k_s", "k_t")] + [
         ("iterations", C.c_int32), ("converged", C.c_int32), ("Rt", C.c_double * 16), ("bbx_magnitude", C.c_float)] + [
-        (k, C.c_float) for k in ("ms_voxel", "ms_keypoints", "ms_feature", "ms_fd", "ms_loop", "ms_total")]
+        (k, C.c_float) for k in ("ms_voxel", "ms_keypoints", "ms_feature", "ms_fd", "ms_loop", "ms_total", "pad_")] + [
+        ("rmse_after", C.c_double), ("registered_ok", C.c_int32), ("pad2_", C.c_int32)]
 
 
 EXPORTS = [
@@ -457,7 +458,7 @@ Context.register_pairs = _register_pairs
 # ---------------------------------------------------------------- per-cloud front-end cache
 class CloudInfo(C.Structure):
     _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("k", C.c_int64), ("variants", C.c_int32), ("feature", C.c_int32),
-                ("bbx_magnitude", C.c_float), ("pad_", C.c_float), ("feature_bytes", C.c_int64)]
+                ("bbx_magnitude", C.c_float), ("candidates", C.c_int32), ("feature_bytes", C.c_int64)]
 
 
 class Cloud:

@@ -430,7 +430,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   H->nb = nb;
   for (int b = 0; b < nb; b++) {
     ghicp_cloud* c = clouds[b];
-    c->n = n[b]; c->m = 0; c->k = 0; c->bbx = 0.f;
+    c->n = n[b]; c->m = 0; c->k = 0; c->cand = 0; c->bbx = 0.f;
     c->V = cfg.reg.dof > 4 ? 4 : (cfg.reg.dof > 0 ? 2 : 1);
     H->c[b].xyz = xyz[b]; H->c[b].n = (int)n[b]; H->c[b].stride = stride;
     H->roff[b + 1] = H->roff[b] + (int)n[b];
@@ -580,6 +580,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   GH_HIP(hipGetLastError());
   GH_HIP(report());
   for (int b = 0; b <= nb; b++) H->coff[b] = HO->coff[b];
+  for (int b = 0; b < nb; b++) clouds[b]->cand = H->coff[b + 1] - H->coff[b];
   const int Ctot = H->coff[nb];
 
   // ------------------------------------------------------------------ NMS: ranks, candidate boxes (sync 4), greedy sweep (sync 5)

@@ -5,7 +5,7 @@
 struct ghicp_cloud {
   ghicp_ctx* ctx = nullptr;
   ghicp_pair_config cfg;
-  long long n = 0, m = 0, k = 0;
+  long long n = 0, m = 0, k = 0, cand = 0;
   float bbx = 0.f;
   int V = 1;
   DevBuf ds;    // m float4 (down-sampled points; empty for handles rebuilt from stored features)

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_cl_kpxyz(const float4* __restrict__ pts
 static int cloud_fill(ghicp_ctx* ctx, ghicp_cloud* c, const float* d, long long n, int stride) {
   hipStream_t s = ctx->stream;
   const ghicp_pair_config* cfg = &c->cfg;
-  c->n = n; c->m = 0; c->k = 0;
+  c->n = n; c->m = 0; c->k = 0; c->cand = 0;
   c->V = cfg->reg.dof > 4 ? 4 : (cfg->reg.dof > 0 ? 2 : 1);
   // down-sampling (main:89-90)
   if (cfg->voxel > 0.f) {
@@ -161,6 +161,7 @@ extern "C" int ghicp_cloud_get_info(const ghicp_cloud* c, ghicp_cloud_info* info
   info->variants = c->V;
   info->feature = c->cfg.reg.feature;
   info->bbx_magnitude = c->bbx;
+  info->candidates = (int32_t)c->cand;
   info->feature_bytes = c->cfg.reg.feature == GHICP_FEATURE_BSC ? (int64_t)c->V * c->k * 56
                         : (c->cfg.reg.feature == GHICP_FEATURE_FPFH ? (int64_t)c->k * 33 * 4 : 0);
   return GHICP_OK;
@@ -230,7 +231,7 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
     gh_loop_job& J = jobs[i];
     memset(&J, 0, sizeof(J));
     J.p = &reg[i]; J.kpS = a->kpx.as<double>(); J.ks = (int)a->k; J.kpT = b->kpx.as<double>(); J.kt = (int)b->k; J.FD = FD; J.Rt16 = stats[i].Rt;
-    J.n_iter = &iters[i]; J.converged = &conv[i];
+    J.n_iter = &iters[i]; J.converged = &conv[i]; J.rmse_after = &stats[i].rmse_after;
   }
   GH_HIP(hipEventRecord(e1, s));
   GH_TRY(gh_register_batch_dev(ctx, n_pairs, jobs.data()));
@@ -242,6 +243,7 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
   for (int i = 0; i < n_pairs; i++) {
     stats[i].iterations = iters[i];
     stats[i].converged = conv[i];
+    stats[i].registered_ok = gh_registered_ok(conv[i], stats[i].rmse_after, cfg->reg.radius_nonmax);
     stats[i].ms_fd = tf / n_pairs;
     stats[i].ms_loop = tl / n_pairs;
     stats[i].ms_total = (tf + tl) / n_pairs;

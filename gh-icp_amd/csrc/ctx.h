@@ -221,8 +221,14 @@ struct gh_loop_job {
   int32_t* n_iter;
   int32_t* converged;
   int32_t* matchlist;
+  double* rmse_after;  // host, optional: RMSEafter of the last iteration (ghicp_reg.cpp:905, the value behind "Registration Succeed.")
 };
 int gh_register_batch_dev(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs);
+// the reference's own verdict at convergence (src/ghicp_reg.cpp:918-924): "Registration Succeed." iff RMSEafter < 1.5 * nonmax
+// (`nonmax` is the double copy of the float ctor argument, ghicp_reg.h:91,187); a loop stopped by the max_iter guard printed neither line
+static inline int gh_registered_ok(int converged, double rmse_after, float radius_nonmax) {
+  return (converged && rmse_after < 1.5 * (double)radius_nonmax) ? 1 : 0;
+}
 
 // ---- internal (device-pointer) entry points shared between translation units
 int gh_fd_bsc_dev(ghicp_ctx* ctx, const uint8_t* featS, int ks, int V, const uint8_t* featT, int kt, uint16_t* FD);

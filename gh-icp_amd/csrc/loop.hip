@@ -27,6 +27,7 @@ struct LoopState {
   int it, done, cor, converged_flag;
   double RMS, FDM, FDstd, IoU, para1, para2, penalty, CDmean, CDstd, energy;
   double Rt_till[16];
+  double rmse_after;
 };
 
 struct LoopConst {
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ pro
     for (int d = 0; d < 16; d++) rec.Rt[d] = Rt16[d];
     P.trace[it] = rec;
     st->RMS = RMSE; st->FDM = FDM; st->FDstd = FDstd; st->IoU = IoU; st->para1 = p1; st->para2 = p2; st->cor = cor;
+    st->rmse_after = RMSEafter;
     st->it = it + 1;
     if (conv || it + 1 >= C.max_iter) { st->done = 1; st->converged_flag = conv ? 1 : 0; }
   }
@@ -691,6 +693,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         for (int d = 0; d < 16; d++) J.Rt16[d] = hst[b].Rt_till[d];
         if (J.n_iter) *J.n_iter = hst[b].it;
         if (J.converged) *J.converged = hst[b].converged_flag;
+        if (J.rmse_after) *J.rmse_after = hst[b].rmse_after;
         if (J.trace && hst[b].it > 0) GH_HIP(hipMemcpyAsync(J.trace, hp[b].trace, (size_t)hst[b].it * sizeof(ghicp_iter), hipMemcpyDeviceToHost, s));
       }
       GH_HIP(hipStreamSynchronize(s));

@@ -169,12 +169,13 @@ extern "C" int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg,
   gh_loop_job J;
   memset(&J, 0, sizeof(J));
   J.p = &F.reg; J.kpS = F.kpx[0]; J.ks = (int)F.k[0]; J.kpT = F.kpx[1]; J.kt = (int)F.k[1]; J.FD = F.FD; J.Rt16 = stats->Rt; J.trace = trace;
-  J.n_iter = &n_iter; J.converged = &conv;
+  J.n_iter = &n_iter; J.converged = &conv; J.rmse_after = &stats->rmse_after;
   GH_TRY(gh_register_batch_dev(ctx, 1, &J));
   GH_HIP(hipEventRecord(raw[5], s));
   GH_HIP(hipEventSynchronize(raw[5]));
   stats->iterations = n_iter;
   stats->converged = conv;
+  stats->registered_ok = gh_registered_ok(conv, stats->rmse_after, F.reg.radius_nonmax);
   float t;
   GH_HIP(hipEventElapsedTime(&t, raw[0], raw[1])); stats->ms_voxel = t;
   GH_HIP(hipEventElapsedTime(&t, raw[1], raw[2])); stats->ms_keypoints = t;
@@ -219,7 +220,7 @@ extern "C" int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg
     gh_loop_job& J = jobs[i];
     memset(&J, 0, sizeof(J));
     J.p = &F[i].reg; J.kpS = F[i].kpx[0]; J.ks = (int)F[i].k[0]; J.kpT = F[i].kpx[1]; J.kt = (int)F[i].k[1]; J.FD = F[i].FD; J.Rt16 = stats[i].Rt;
-    J.n_iter = &iters[i]; J.converged = &conv[i];
+    J.n_iter = &iters[i]; J.converged = &conv[i]; J.rmse_after = &stats[i].rmse_after;
   }
   GH_HIP(hipEventRecord(e1.e, s));
   GH_TRY(gh_register_batch_dev(ctx, n_pairs, jobs.data()));
@@ -231,6 +232,7 @@ extern "C" int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg
   for (int i = 0; i < n_pairs; i++) {
     stats[i].iterations = iters[i];
     stats[i].converged = conv[i];
+    stats[i].registered_ok = gh_registered_ok(conv[i], stats[i].rmse_after, cfg->reg.radius_nonmax);
     stats[i].ms_keypoints = tf / n_pairs;  // whole front end (voxel + keypoints + feature + FD), batch average
     stats[i].ms_loop = tl / n_pairs;
     stats[i].ms_total = (tf + tl) / n_pairs;

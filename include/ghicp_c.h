@@ -182,6 +182,12 @@ typedef struct ghicp_pair_stats {
   double Rt[16];
   float bbx_magnitude;
   float ms_voxel, ms_keypoints, ms_feature, ms_fd, ms_loop, ms_total; /* hipEvent timings */
+  float pad_;
+  /* src/ghicp_reg.cpp:918-924: at convergence the reference prints "Registration Succeed." iff RMSEafter < 1.5 * nonmax
+   * (RMSE of the last iteration's correspondences after its transform), else "Registration Failed.".  registered_ok is that
+   * verdict (0 when the loop stopped at the max_iter guard); rmse_after is the value it was taken from. */
+  double rmse_after;
+  int32_t registered_ok, pad2_;
 } ghicp_pair_stats;
 
 /* voxel -> keypoints -> feature -> FD -> loop for one (S,T); raw clouds are device (or host) xyz. */
@@ -268,7 +274,7 @@ typedef struct ghicp_cloud_info {
   int32_t variants;       /* V: BSC strings per keypoint (1, 2 or 4; binary_feature_extraction.hpp:648-660) */
   int32_t feature;        /* GHICP_FEATURE_* */
   float bbx_magnitude;    /* of the down-sampled cloud (main:91-93) */
-  float pad_;
+  int32_t candidates;     /* points that passed pruneUnstablePoints (keypoint_detect.hpp:132-147) = input of the NMS; 0 when not recorded */
   int64_t feature_bytes;  /* BSC: V*k*56, FPFH: k*33*4, None: 0 */
 } ghicp_cloud_info;
 

@@ -426,7 +426,17 @@ def register_pair(S, T, voxel, r_pca, R_nms, dof, feature, corr, est_iou, patter
     sec["total"] = sum(sec.values())
     return dict(Rt=ro["Rt"], iters=ro["iters"], m_s=int(ds["S"].shape[0]), m_t=int(ds["T"].shape[0]), k_s=int(kp["S"].size), k_t=int(kp["T"].size),
                 k_bar=0.5 * (kbar["S"] + kbar["T"]), m_bar=mbar, seconds=sec, km_seconds=ro["km_seconds"],
-                cor=[tr["cor"] for tr in ro["trace"]])
+                cor=[tr["cor"] for tr in ro["trace"]], **registration_verdict(ro["trace"], R_nms))
+
+
+def registration_verdict(trace, R_nms):
+    """src/ghicp_reg.cpp:918-924: at convergence the reference prints "Registration Succeed." iff RMSEafter < 1.5 * nonmax."""
+    if not trace:
+        return dict(converged=0, rmse_after=float("nan"), registered_ok=0)
+    last = trace[-1]
+    conv = int(last["converged"])
+    return dict(converged=conv, rmse_after=float(last["rmse_after"]),
+                registered_ok=int(bool(conv) and last["rmse_after"] < 1.5 * float(np.float32(R_nms))))
 
 
 # ---------------------------------------------------------------- the reference's own code (oracle/_ref/libghicp_ref.so)
