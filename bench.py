@@ -41,7 +41,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KERNELS = ("pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort",
-           "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out")  # fb_*: the other stages of the batched front end (ghicp_clouds_recompute)
+           "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out",  # fb_*: the other stages of the batched front end (ghicp_clouds_recompute)
+           "pair_loop")  # the persistent pair loop of the Kuhn-Munkres configurations: a batch's whole GH-ICP loops in one launch per LDS class
 
 # per BASELINE config: generator, hits, voxel, r_pca, R_nms, feature, matcher, dof, est_IoU, default pairs/step, default distinct, scaling
 CONFIGS = {
@@ -102,6 +103,11 @@ def algorithmic_bytes(k, m, n2, V, kernel, batch):
     return float("nan")
 
 
+def pair_loop_bytes(k, n2, iters, cor):
+    """One pair's whole loop inside the persistent kernel: iters x (S5 sweep + KM graph seen once, written once + S6), SURVEY.md §8(d)."""
+    return iters * (24.0 * 2 * k + 2.0 * k * k + 12.0 * 2 * k + 16.0 * n2 + 48.0 * cor + 48.0 * k)
+
+
 def front_end_bytes_per_cloud(kernel, n, m, c, k, V, grids):
     """Compulsory traffic of one front-end STAGE for one cloud (every input of the stage read once, every output written once; raw
     points 12 B, float4 points 16 B; the stage's own intermediates -- sort keys, flags, index lists -- count because the next stage
@@ -143,7 +149,7 @@ def compact(d, limit=5000):
     line = json.dumps(d, separators=(",", ":"))
     if len(line) <= limit:
         return line
-    for key in ("batch_ms", "km_launch_stats", "rank_wall_s", "notes"):
+    for key in ("batch_ms", "km_launch_stats", "pair_loop_stats", "rank_wall_s", "notes"):
         if key in d and len(line) > limit:
             d = {k: v for k, v in d.items() if k != key}
             line = json.dumps(d, separators=(",", ":"))
@@ -160,11 +166,12 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=0, help="independent pairs per GPU per step (0 = the config's default; cfg4: pairs of the WHOLE job)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic scenes per rank, cycled inside the batch (0 = the config's default)")
     ap.add_argument("--fe-streams", type=int, default=16, help="front-end worker contexts/streams")
-    ap.add_argument("--loop-groups", type=int, default=3, help="the step's pairs are registered by this many concurrent batched loops (own context and stream each)")
+    ap.add_argument("--loop-groups", type=int, default=0, help="the step's pairs are registered by this many concurrent batched loops (own context and stream each); "
+                    "0 = 1 for the Kuhn-Munkres configurations (the persistent pair loop balances a batch through its own queue), 3 otherwise")
     ap.add_argument("--pipeline", type=int, default=2, help="0: barrier between front ends and loops and between steps; 1: no barriers at all (measured slower: "
                     "front-end kernels queue behind Kuhn-Munkres workgroups that hold the CUs' LDS); 2: the front ends of step k+1 start when step k is down "
                     "to its slowly converging pairs (ghicp_ctx_loop_progress), so the long tail of a step overlaps the next step's work")
-    ap.add_argument("--tail-fraction", type=float, default=0.2, help="--pipeline 2: a group is in its tail when this fraction of its pairs is still iterating")
+    ap.add_argument("--tail-fraction", type=float, default=0.15, help="--pipeline 2: a group is in its tail when this fraction of its pairs is still iterating")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU (oracle) legs and the parity check")
     ap.add_argument("--fe-batch", type=int, default=-1, help="clouds per batched front-end launch sequence (ghicp_clouds_recompute); 0/1 = cloud by cloud; "
                     "-1 = calibrate: time both front ends on a sample before the warm-up and use the faster one")
@@ -226,7 +233,7 @@ def main():
     cfg = api.pair_config(feature, corr, CF["dof"], CF["iou"], CF["voxel"], CF["r"], CF["R"], synth.bsc_pattern_glibc(), max_iter=200)
     nb = len(mine)  # pairs this rank registers per step
     nstream = max(1, min(args.fe_streams, max(1, nb)))
-    G = max(1, min(args.loop_groups, max(1, nb)))
+    G = max(1, min(args.loop_groups or (1 if CF["corr"] == "KM" else 3), max(1, nb)))
     LP = 2 if args.pipeline == 2 else 1  # loop contexts per group: consecutive steps of a group overlap in --pipeline 2
     streams = [torch.cuda.Stream() for _ in range(nstream + G * LP)]
     ctxs = [api.Context(local_rank, stream=s) for s in streams]
@@ -479,6 +486,7 @@ def main():
     results = last_results
     ktimes = {k: (sum(c.kernel_time(k)[0] for c in ctxs), sum(c.kernel_time(k)[1] for c in ctxs)) for k in KERNELS}
     kml = [c.km_launch_stats() for c in loop_ctxs]
+    pls = [c.pair_loop_stats() for c in loop_ctxs]
     for c in ctxs:
         c.kernel_timing(False)
 
@@ -538,6 +546,8 @@ def main():
     for k, (ms_tot, cnt) in ktimes.items():
         if k in FE_STAGES:
             total_bytes = front_end_bytes_per_cloud(k, n_mean, m_mean, c_mean, k_mean, V, grids) * clouds_total
+        elif k == "pair_loop":
+            total_bytes = pair_loop_bytes(k_mean, n2_mean, it_mean, 0.5 * k_mean) * nb * args.steps
         else:
             total_bytes = algorithmic_bytes(k_mean, m_mean, n2_mean, V, k, km_batch if k == "km_solve" else shard_b) * cnt
         per_kernel[k] = {"ms_total": round(ms_tot, 3), "launches": cnt, "alg_bytes_total": int(total_bytes) if total_bytes == total_bytes else None,
@@ -564,6 +574,16 @@ def main():
                 "alg_bytes_per_launch": int(b_alg),
                 "whole_pair_frac": round(whole_pair_gbs / HBM_PEAK_GBS, 6), "whole_pair_GBps": round(whole_pair_gbs, 2), "alg_bytes_per_pair": int(b_pair),
                 "per_kernel_GBps": {k: v["GBps"] for k, v in per_kernel.items() if v["launches"]}}
+    pl_stats = None
+    if pls and sum(s["launches"] for s in pls) > 0:
+        Lp = sum(s["launches"] for s in pls)
+        Sv = max(1.0, sum(s["solves"] for s in pls))
+        pl_stats = {"launches": int(Lp), "slots_run": int(sum(s["slots"] for s in pls)), "solves": int(Sv),
+                    "mean_solve_ms": round(sum(s["mean_solve_ms"] * s["solves"] for s in pls) / Sv, 3),
+                    "longest_solve_ms": round(max(s["longest_solve_ms"] for s in pls), 2),
+                    "mean_launch_span_ms": round(sum(s["mean_launch_span_ms"] * s["launches"] for s in pls) / Lp, 1),
+                    "idle_slot_fraction": round(float(np.mean([s["idle_slot_fraction"] for s in pls if s["launches"]])), 4),
+                    "solve_share_of_slot_time": round(float(np.mean([s["solve_share_of_slot_time"] for s in pls if s["launches"]])), 4)}
     km_stats = None
     if kml and sum(s["launches"] for s in kml) > 0:
         L = sum(s["launches"] for s in kml)
@@ -664,7 +684,7 @@ def main():
         "batch_ms": {"front_end_thread_s_per_step": round(thread_busy["front_end"] / max(1, args.steps), 2), "front_end_threads": fe_n,
                      "loop_thread_s_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G, "pipeline": args.pipeline,
                      "front_end_ms_per_cloud_on_its_stream": round(1e3 * thread_busy["front_end"] / max(1, args.steps) / max(1, 2 * nb), 4)},
-        "km_launch_stats": km_stats,
+        "km_launch_stats": km_stats, "pair_loop_stats": pl_stats,
         "rank_wall_s": {"per_rank": [round(b, 3) for b in busy_all], "imbalance_max_over_mean": round(max(busy_all) / max(1e-9, float(np.mean(busy_all))), 4)},
         "roofline": roofline, "cpu_baseline": cpu, "parity_check": check,
     }

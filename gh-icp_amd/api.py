@@ -46,7 +46,7 @@ class PairStats(C.Structure):
 
 EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_set_cu_mask",
-    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_loop_progress", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
+    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_progress", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
@@ -191,6 +191,13 @@ class Context:
         out = (C.c_double * 8)()
         self._check(self.lib.ghicp_ctx_km_launch_stats(self.h, out))
         keys = ("launches", "solves", "mean_solve_ms", "mean_longest_solve_ms", "mean_launch_span_ms", "slots", "idle_slot_fraction", "worst_longest_over_mean")
+        return dict(zip(keys, (float(v) for v in out)))
+
+    def pair_loop_stats(self):
+        """dict of the persistent pair loop's launch records collected since kernel_timing(True) (ghicp_ctx_pair_loop_stats)."""
+        out = (C.c_double * 8)()
+        self._check(self.lib.ghicp_ctx_pair_loop_stats(self.h, out))
+        keys = ("launches", "slots", "solves", "mean_solve_ms", "longest_solve_ms", "mean_launch_span_ms", "idle_slot_fraction", "solve_share_of_slot_time")
         return dict(zip(keys, (float(v) for v in out)))
 
     def loop_progress(self):

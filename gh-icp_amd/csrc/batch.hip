@@ -482,7 +482,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   GH_TRY(ctx->reserve(B_GRID_KEYS2, (size_t)N * 2 + 2, (unsigned**)&vkeys2));
   GH_TRY(ctx->reserve(B_GRID_VALS, (size_t)N + 1, &vvals));
   GH_TRY(ctx->reserve(B_GRID_VALS2, (size_t)N + 1, &vvals2));
-  GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)N + 16, &flags));
+  GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)N + nb + 16, &flags));  // also the prune flags of the M <= N + nb down-sampled rows (a phantom row per cloud)
   GH_TRY(ctx->reserve(B_FB_HEADPOS, (size_t)N + 1, &headpos));
   GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
   GH_TRY(ctx->reserve(B_FB_DS, (size_t)N + nb + 1, &dsg));
@@ -535,7 +535,16 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     }
   }
   H->cb1[nb] = (unsigned)t1; H->cb2[nb] = (unsigned)t2;
-  if (t1 >= (1ull << 31) || t2 >= (1ull << 31)) return ctx->fail(GHICP_ERR_CAPACITY, "ghicp_clouds_recompute: the cell tables of the batch exceed 2^31 cells");
+  // the cell tables of all clouds are summed into one: when that gets large (clouds of large extent), halve the batch instead of
+  // failing -- whatever the cloud-by-cloud path handles must work here too (a single cloud is limited to 2^26 cells by gh_grid_desc)
+  auto split = [&]() -> int {
+    if (n_clouds == 1) return ghicp_cloud_recompute(clouds[0], xyz[0], n[0], stride);
+    const int half = n_clouds / 2;
+    GH_TRY(ghicp_clouds_recompute(ctx, half, clouds, xyz, n, stride));
+    return ghicp_clouds_recompute(ctx, n_clouds - half, clouds + half, xyz + half, n + half, stride);
+  };
+  constexpr unsigned long long FB_CELL_BUDGET = 1ull << 28;  // 1 GB of cell table per grid
+  if (t1 >= FB_CELL_BUDGET || t2 >= FB_CELL_BUDGET) return split();
   if (M <= 0) return GHICP_OK;
 
   // ------------------------------------------------------------------ PCA grid, PCA, prune                              (sync 3)
@@ -630,7 +639,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
       if (cb > 0) t3 += H->g3[b].ncell;
     }
     H->hb[nb] = (unsigned)t3;
-    if (t3 >= (1ull << 31)) return ctx->fail(GHICP_ERR_CAPACITY, "ghicp_clouds_recompute: the NMS cell tables of the batch exceed 2^31 cells");
+    if (t3 >= FB_CELL_BUDGET) return split();
     GH_TRY(ctx->reserve(B_GRID_START, (size_t)std::max<unsigned long long>(t3, t1) + 2, &head));  // the PCA cell table is dead by now
     GH_HIP(hipMemsetAsync(head, 0xff, (size_t)t3 * sizeof(int), s));
     GH_HIP(upload());

@@ -83,9 +83,10 @@ enum BufSlot {
 
 enum KtSlot { KT_PCA = 0, KT_BSC, KT_KM_SOLVE, KT_CD_ROWMIN, KT_KM_WEIGHTS, KT_FD_BSC, KT_NMS_ROUND, KT_VOXEL_SORT,
               KT_FB_VOXEL, KT_FB_GRID, KT_FB_PRUNE, KT_FB_RANK, KT_FB_OUT,  // stages of the batched front end (batch.hip) around the kernels above
+              KT_PAIR_LOOP,                                                  // the persistent pair loop (loop.hip): all classes of a batch, fork -> join
               KT_NUM };
 static const char* const kKtNames[KT_NUM] = {"pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort",
-                                             "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out"};
+                                             "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out", "pair_loop"};
 
 struct ghicp_ctx {
   // optional per-kernel timing
@@ -124,8 +125,10 @@ struct ghicp_ctx {
     kt_pending.clear();
   }
   // per-launch statistics of the Kuhn-Munkres solve launches (collected while kernel timing is on): device records of
-  // KM_LSTAT_MAX launches x 5 words, and the solve slots (resident workgroups) each launch had
+  // KM_LSTAT_MAX launches x KM_LSTAT_W words, and the solve slots (resident workgroups) each launch had.  Words: first start, last end,
+  // sum and max of the solve times, solves; persistent pair loop only: sum of the slot lifetimes, slots that ran
   static constexpr int KM_LSTAT_MAX = 8192;
+  static constexpr int KM_LSTAT_W = 8;
   long long km_launches = 0;
   std::vector<int> km_slots;
   // progress of the batched loop that is running on this context (pairs still iterating / pairs of the batch), readable from
@@ -140,6 +143,11 @@ struct ghicp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;  // created by ghicp_ctx_set_cu_mask
+  // persistent pair loop: one launch per LDS-occupancy class, concurrently, on these streams (forked from / joined into `stream`)
+  std::vector<hipStream_t> aux_streams;
+  std::vector<hipEvent_t> aux_events;  // [0] fork, [1 + c] join of class c
+  int* progress_host = nullptr;        // mapped pinned counter: pairs completed by the running persistent loop
+  std::atomic<bool> progress_live{false};
   bool host_ptrs = false;
   std::string err;
   DevBuf buf[B_NUM];

@@ -56,6 +56,9 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->fb_pinned) (void)hipHostFree(ctx->fb_pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  for (hipStream_t a : ctx->aux_streams) (void)hipStreamDestroy(a);
+  for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
+  if (ctx->progress_host) (void)hipHostFree(ctx->progress_host);
   delete ctx;
   return GHICP_OK;
 }
@@ -100,8 +103,8 @@ extern "C" int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on) {
   for (int i = 0; i < KT_NUM; i++) { ctx->kt_ms[i] = 0; ctx->kt_count[i] = 0; }
   if (on) {  // Kuhn-Munkres launch records start over (they stay readable after timing is switched off)
     unsigned long long* lstat;
-    GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * 5, &lstat));
-    GH_HIP(hipMemsetAsync(lstat, 0, (size_t)ghicp_ctx::KM_LSTAT_MAX * 5 * sizeof(unsigned long long), ctx->stream));
+    GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W, &lstat));
+    GH_HIP(hipMemsetAsync(lstat, 0, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W * sizeof(unsigned long long), ctx->stream));
     ctx->km_launches = 0;
     ctx->km_slots.clear();
   }
@@ -109,8 +112,13 @@ extern "C" int ghicp_ctx_kernel_timing(ghicp_ctx* ctx, int on) {
 }
 extern "C" int ghicp_ctx_loop_progress(const ghicp_ctx* ctx, int64_t* active, int64_t* total) {  // no device work: callable from any thread
   if (!ctx || !active || !total) return GHICP_ERR_ARG;
-  *active = ctx->loop_active.load(std::memory_order_relaxed);
   *total = ctx->loop_total.load(std::memory_order_relaxed);
+  if (ctx->progress_live.load(std::memory_order_acquire) && ctx->progress_host) {  // persistent pair loop: the device counts completed pairs
+    const long long done = *(volatile int*)ctx->progress_host;
+    *active = *total > done ? *total - done : 0;
+  } else {
+    *active = ctx->loop_active.load(std::memory_order_relaxed);
+  }
   return GHICP_OK;
 }
 extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {

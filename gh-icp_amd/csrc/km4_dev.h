@@ -1,0 +1,743 @@
+// Kuhn-Munkres, fourth-generation kernel (gfx950): the reference's result (src/km.cpp:13-126) WITHOUT stepping through the
+// reference's depth-first search wherever its outcome is order independent.  One 256-thread workgroup per problem, all
+// solver state in LDS (61.75 B per row), the CSR of the explicit entries streamed from global memory only by the bulk
+// passes of failed phases.  Rules (oracle/km4_model.inc states them sequentially and is fuzzed against the reference
+// traversal; R1 = E1-E3 of km2.hip):
+//   R2  per row a list of <= 3 (column, weight) pairs in LDS, ascending column, a SUPERSET of the row's tight explicit entries;
+//       members are re-tested with fl(fl(lx+ly) - w) < eps at every use.  An explicit entry can only become tight when its
+//       row label drops, i.e. for rows visited by a failed phase: those lists are rebuilt after the relabelling.  Rows with
+//       more than 3 tight entries are flagged (scanned from the CSR row, never pruned).
+//   R3  every phase starts with an order-free flood from the root (wave 0; lists + one sweep of
+//       T_L = {y : fl(fl(L+ly[y]) - bg) < eps} for the smallest label met -- T_L is nested in L).  No free column reached:
+//       the phase FAILS and the visited sets are the reference's (a failed findpath() visits exactly the reachable set).
+//   R4  failed phase: the slack minima of the visited rows' non-tight explicit entries are order free (min is exact) and
+//       are pushed by 4 waves streaming the CSR rows (LDS ds_min_u64: every contribution is >= eps > 0, so the bit pattern
+//       orders like the value); background entries contribute through the minimum visited label (E4).  The list rebuild
+//       after the relabelling pushes the same rows' minima for the NEXT phase of the root (same labels), so a row is streamed
+//       once per failed phase.  Minima pushed for columns that end up visited are never read provided visited columns stay
+//       visited in later phases of the root; that is CHECKED after every failed phase, and a violation (only possible when
+//       an edge sits within an ulp of eps) sends the problem to the literal single-lane solver at the end of this file.
+//   R5  augmenting phase: good = rows that reach a free column in the tight graph.  findpath() of a row that is not good
+//       fails whatever has been visited and visits only rows that are not good, so the reference's DFS may skip columns
+//       whose owner lies outside any superset S of good without changing its path.  S = fixed point of "background-tight to
+//       the good column of smallest ly, or a listed tight entry in a good column" (256 threads, one row each per round,
+//       ~4 rounds), flagged rows included.  Wave 0 then runs the reference's DFS restricted to S: E7 pointer, E9 march
+//       (km2.hip), all in LDS; what is left of the search is essentially the augmenting path itself.
+// (device code; included by km4.hip -- the stand-alone solve kernel -- and by loop.hip -- the persistent pair loop)
+#pragma once
+#include "ctx.h"
+#include "devmath.h"
+#include "km_prob.h"
+
+#include <climits>
+
+namespace {
+
+
+constexpr int K4_CAP = 3;
+constexpr int K4_OVER = 255;  // tln: 0..3 = entries in the row's own slots; 4 + blk*5 + (cnt-4) = cnt in 4..8, entries 3.. in pool block blk; 255 = flagged
+constexpr int K4_BLK = 5;     // entries per pool block
+constexpr int K4_MAXBLK = 48;
+constexpr int K4_T = 256;
+constexpr int K4_NONE = 0xFFFF;
+constexpr double K4_INF = 1000.0;  // km.cpp:42
+
+typedef __attribute__((address_space(1))) const int* k4_gint;
+typedef __attribute__((address_space(1))) const double* k4_gf64;
+typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
+
+enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NUM = 16 };
+
+struct K4 {
+  double *lx, *ly, *slack, *tlv, *red, *pval;
+  unsigned *visx, *visy, *prevy, *pushed, *good, *goody, *freey, *ovf;
+  int* sh;
+  unsigned short *match, *stx, *sty, *tlc, *pcol;
+  unsigned* fb;  // free pool blocks (2 words)
+  int nblk;
+  unsigned char* tln;
+  int n, nw;
+  double bg, eps;
+  k4_gu32 rptr;
+  k4_gint cols;
+  k4_gf64 vals;
+};
+
+__device__ inline bool k4_bit(const unsigned* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
+__device__ inline int k4_cnt(int tn) { return tn < 4 ? tn : (tn == K4_OVER ? 0 : 4 + (tn - 4) % K4_BLK); }  // listed entries (0 for flagged rows)
+__device__ inline int k4_blk(int tn) { return (tn >= 4 && tn != K4_OVER) ? (tn - 4) / K4_BLK : -1; }
+
+// pool blocks: lock-free bitmap allocator (bit set = free)
+__device__ inline int k4_blk_alloc(const K4& s) {
+  for (int w = 0; w < 2; w++)
+    for (;;) {
+      const unsigned m = *(volatile unsigned*)&s.fb[w];
+      if (!m) break;
+      const int b = __ffs((int)m) - 1;
+      if (atomicAnd(&s.fb[w], ~(1u << b)) & (1u << b)) return w * 32 + b;
+    }
+  return -1;
+}
+__device__ inline void k4_blk_free(const K4& s, int b) { atomicOr(&s.fb[b >> 5], 1u << (b & 31)); }
+
+// Bulk pass over rows list[0..count), all 4 waves: REBUILD writes the rows' lists (R2), PUSH sends the slack minima of their
+// non-tight entries (R4), ONLY_UNPUSHED skips rows whose minima are already in slack.  16 lanes per row, so a wave instruction works
+// on four rows and every lane has four entries (64 per row) in flight per round: the pass is bound by the latency of the CSR
+// loads (L2), not by their volume, and 16 rows per workgroup in flight is what hides it.
+template <bool REBUILD, bool PUSH, bool ONLY_UNPUSHED>
+__device__ inline void k4_bulk(const K4& s, const unsigned short* list, int count, int wave, int lane) {
+  const int grp = lane >> 4, lig = lane & 15;
+  unsigned long long* sl = reinterpret_cast<unsigned long long*>(s.slack);
+  for (int base = 0; base < count; base += 16) {
+    const int i = base + wave * 4 + grp;
+    int x = -1;
+    if (i < count) {
+      x = list[i];
+      if (ONLY_UNPUSHED && k4_bit(s.pushed, x)) x = -1;
+    }
+    unsigned cb = 0, ce = 0;
+    double lxr = 0.0;
+    if (x >= 0) { cb = s.rptr[x]; ce = s.rptr[x + 1]; lxr = s.lx[x]; }
+    int cnt = 0, blk = -1;
+    if (REBUILD && x >= 0) blk = k4_blk(s.tln[x]);  // a row that had a pool block keeps it for its new list
+    for (unsigned off = 0; __ballot(cb + off < ce); off += 64) {
+      int col[4];
+      double val[4];
+      unsigned c[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        c[j] = cb + off + 16u * j + lig;
+        col[j] = 0; val[j] = 0.0;  // a lane without a row, or with an empty row, loads nothing (found by tests/hipsim: cols[cb] may lie past the CSR)
+        if (ce > cb) { const unsigned cc = min(c[j], ce - 1u); col[j] = s.cols[cc]; val[j] = s.vals[cc]; }
+      }
+      double lyv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) lyv[j] = s.ly[col[j]];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool in = c[j] < ce;
+        const double d = (lxr + lyv[j]) - val[j];
+        const bool td = d < s.eps;
+        if (PUSH && in && !td) atomicMin(&sl[col[j]], (unsigned long long)__double_as_longlong(d));
+        if (REBUILD) {
+          const unsigned gb = (unsigned)(__ballot(in && td) >> (grp * 16)) & 0xffffu;
+          const int after = cnt + __popc(gb);
+          if (after > K4_CAP && blk == -1) {  // first entry beyond the row's own slots: take a pool block (asked for once per row)
+            int b = -2;
+            if (lig == 0) b = k4_blk_alloc(s);
+            blk = __shfl(b, grp * 16, 64);
+            if (blk < 0) blk = -2;  // none free: the row ends up flagged
+          }
+          if (in && td) {
+            const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
+            if (rk < K4_CAP) { s.tlc[x * K4_CAP + rk] = (unsigned short)col[j]; s.tlv[x * K4_CAP + rk] = val[j]; }
+            else if (rk < K4_CAP + K4_BLK && blk >= 0) { s.pcol[blk * K4_BLK + rk - K4_CAP] = (unsigned short)col[j]; s.pval[blk * K4_BLK + rk - K4_CAP] = val[j]; }
+          }
+          cnt = after;
+        }
+      }
+    }
+    if (REBUILD && lig == 0 && x >= 0) {
+      int tn = cnt;
+      if (cnt > K4_CAP) {
+        if (cnt <= K4_CAP + K4_BLK && blk >= 0) tn = 4 + blk * K4_BLK + (cnt - 4);
+        else { tn = K4_OVER; if (blk >= 0) k4_blk_free(s, blk); }
+      } else if (blk >= 0) k4_blk_free(s, blk);
+      const bool over = tn == K4_OVER, was = s.tln[x] == K4_OVER;
+      s.tln[x] = (unsigned char)tn;
+      if (over != was) {
+        if (over) atomicOr(&s.ovf[x >> 5], 1u << (x & 31));
+        else atomicAnd(&s.ovf[x >> 5], ~(1u << (x & 31)));
+      }
+    }
+  }
+}
+
+__device__ inline double k4_wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- R3: the flood (wave 0), level by level.  Returns true when a free column is reachable; the visited rows are stx[0 .. *qt_out).
+// A column is claimed by the returning ds_or on its visited bit (two rows reaching it in the same instruction are serialised by
+// the LDS); every matched row owns exactly one column, so the claim of a column is also the one enqueue of its owner, and the
+// queue tail lives in a register (ballot ranks, no LDS counter).
+#define K4_CLAIM(WANT, COL, OWNER)                                                          \
+  do {                                                                                      \
+    unsigned old_ = 0u;                                                                     \
+    const unsigned bit_ = 1u << ((COL) & 31);                                               \
+    if (WANT) old_ = atomicOr(&s.visy[(COL) >> 5], bit_);                                   \
+    const bool fresh_ = (WANT) && !(old_ & bit_);                                           \
+    free_l |= fresh_ && (OWNER) == K4_NONE;                                                 \
+    const bool enq_ = fresh_ && (OWNER) != K4_NONE;                                         \
+    const unsigned long long eb_ = __ballot(enq_);                                          \
+    if (enq_) {                                                                             \
+      s.stx[qt + __popcll(eb_ & ((1ull << lane) - 1ull))] = (unsigned short)(OWNER);        \
+      atomicOr(&s.visx[(OWNER) >> 5], 1u << ((OWNER) & 31));                                \
+    }                                                                                       \
+    qt += __popcll(eb_);                                                                    \
+  } while (0)
+
+template <bool PROF>
+__device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, long long* pc) {
+  const int n = s.n;
+  if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); }
+  __builtin_amdgcn_wave_barrier();
+  int qh = 0, qt = 1;
+  bool free_l = false;
+  double lflood = INFINITY;
+  while (qh < qt) {
+    const int qe = qt;
+    double lcand = INFINITY;
+    const long long tl0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    if (PROF) pc[0]++;
+    for (int base = qh; base < qe; base += 64) {
+      const int i = base + lane;
+      const bool act = i < qe;
+      const int xr = s.stx[min(i, qe - 1)];
+      const double lxr = s.lx[xr];
+      const int tn = s.tln[xr];
+      int lc[K4_CAP], mc[K4_CAP];
+      double lv[K4_CAP], lyc[K4_CAP];
+      unsigned vw[K4_CAP];
+#pragma unroll
+      for (int k = 0; k < K4_CAP; k++) { lc[k] = s.tlc[xr * K4_CAP + k]; lv[k] = s.tlv[xr * K4_CAP + k]; }
+#pragma unroll
+      for (int k = 0; k < K4_CAP; k++) { lyc[k] = s.ly[lc[k]]; vw[k] = s.visy[lc[k] >> 5]; mc[k] = s.match[lc[k]]; }
+      const int cntv = act ? k4_cnt(tn) : 0, blkv = k4_blk(tn);
+      const int t = min(cntv, K4_CAP);
+#pragma unroll
+      for (int k = 0; k < K4_CAP; k++) {
+        const bool want = (int)(k < t) & (int)(((lxr + lyc[k]) - lv[k]) < s.eps) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
+        K4_CLAIM(want, lc[k], mc[k]);
+      }
+      for (int e = K4_CAP; __ballot(e < cntv); e++) {  // entries in pool blocks
+        const int pi = blkv * K4_BLK + e - K4_CAP;
+        int col = 0, m = K4_NONE;
+        bool want = false;
+        if (e < cntv) {
+          col = s.pcol[pi];
+          m = s.match[col];
+          want = (int)(((lxr + s.ly[col]) - s.pval[pi]) < s.eps) & (int)!k4_bit(s.visy, col);
+        }
+        K4_CLAIM(want, col, m);
+      }
+      if (act && (lxr - s.bg) < s.eps) lcand = fmin(lcand, lxr);
+      unsigned long long ob = __ballot(act && tn == K4_OVER);
+      if (PROF) pc[1] += __popcll(ob);
+      while (ob) {  // flagged rows: every tight entry of the CSR row
+        const int l = (int)__ffsll((long long)ob) - 1;
+        ob &= ob - 1ull;
+        const int xo = __builtin_amdgcn_readlane(xr, l);
+        const double lxo = s.lx[xo];
+        const unsigned cb = s.rptr[xo], ce = s.rptr[xo + 1];
+        for (unsigned c0 = cb; c0 < ce; c0 += 64) {
+          const unsigned c = c0 + lane, cc = min(c, ce - 1u);
+          const int col = s.cols[cc];
+          const double val = s.vals[cc];
+          const int m = s.match[col];
+          const bool want = (int)(c < ce) & (int)(((lxo + s.ly[col]) - val) < s.eps) & (int)!k4_bit(s.visy, col);
+          K4_CLAIM(want, col, m);
+        }
+      }
+    }
+    lcand = k4_wave_min(lcand);
+    const long long tl1 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    if (PROF) pc[2] += tl1 - tl0;
+    if (lcand < lflood) {  // T_L of the smallest label so far contains T_L of every larger one
+      lflood = lcand;
+      if (PROF) pc[3]++;
+      for (int y0 = 0; y0 < n; y0 += 256) {  // four independent windows per round
+        bool c[4];
+        int m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int y = y0 + k * 64 + lane, yc = min(y, n - 1);
+          const unsigned vw = s.visy[yc >> 5];
+          const double lv = s.ly[yc];
+          m[k] = s.match[yc];
+          c[k] = (int)(y < n) & (int)(((vw >> (yc & 31)) & 1u) == 0u) & (int)(((lcand + lv) - s.bg) < s.eps);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (y0 + k * 64 >= n) break;
+          const int y = min(y0 + k * 64 + lane, n - 1);
+          K4_CLAIM(c[k], y, m[k]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (PROF) pc[4] += (long long)__builtin_readcyclecounter() - tl1;
+    qh = qe;
+    if (__ballot(free_l)) { *qt_out = qt; return true; }
+  }
+  *qt_out = qt;
+  return false;
+}
+#undef K4_CLAIM
+
+// ---- R5: the reference's DFS restricted to S (wave 0).  Returns false only on an internal error.
+// One iteration == one findpath() activation or resumption (km.cpp:13-37) and costs two dependent LDS round trips: (1) the
+// row record (label, list), (2) everything the verdict needs -- for the <= 3 listed entries and for a 64-column window of
+// background candidates at the E7 pointer of the row's label: ly, the visited / S words and the owner of every candidate.
+template <bool PROF>
+__device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter, long long* q_act) {
+  const int n = s.n;
+  const double bg = s.bg, eps = s.eps;
+  if (lane == 0) { s.stx[0] = (unsigned short)root; s.sty[0] = (unsigned short)K4_NONE; }
+  __builtin_amdgcn_wave_barrier();
+  int sp = 0, x = root, ystart = 0;
+  double ck = __longlong_as_double(0x7ff8000000000000ll);  // E7 cache, one label per lane: NaN never matches
+  int cp = 0, cnext = 0;
+  const int lk = min(lane, K4_CAP - 1);
+  for (;;) {
+    if (PROF) { ++*q_iter; ++*q_act; }
+    // ---- round trip 1: the row record
+    const double lxv = s.lx[x];
+    const int tn = s.tln[x];
+    int lc = s.tlc[x * K4_CAP + lk];
+    double lv = s.tlv[x * K4_CAP + lk];
+    const int ncnt = k4_cnt(tn);
+    if (ncnt > K4_CAP && lane >= K4_CAP) {  // entries 3.. of a row with a pool block
+      const int pi = k4_blk(tn) * K4_BLK + min(lane, K4_CAP + K4_BLK - 1) - K4_CAP;
+      lc = s.pcol[pi]; lv = s.pval[pi];
+    }
+    const bool bgt = (lxv - bg) < eps;
+    int slot = 0, p = n;
+    if (bgt) {  // E7: one scan pointer per distinct label value; everything below ystart is dead for this label as well
+      const unsigned long long hit = __ballot(ck == lxv);
+      p = ystart;
+      if (hit) {
+        slot = (int)__ffsll((long long)hit) - 1;
+        p = max(p, __builtin_amdgcn_readlane(cp, slot));
+      } else {
+        slot = cnext;
+        cnext = (cnext + 1) & 63;
+        if (lane == slot) ck = lxv;
+      }
+    }
+    // ---- round trip 2: listed entries and the first window, issued together
+    const double lyL = s.ly[lc];
+    const unsigned vwL = s.visy[lc >> 5], gwL = s.goody[lc >> 5];
+    const int mL = s.match[lc];
+    int yw = p + lane, ywc = min(yw, n - 1);
+    unsigned vwW = s.visy[ywc >> 5], gwW = s.goody[ywc >> 5];
+    double lyW = s.ly[ywc];
+    int mW = s.match[ywc];
+    int best = INT_MAX, mbest = K4_NONE;
+    if (tn == K4_OVER) {  // flagged row: lowest tight unvisited good column of the CSR row
+      const unsigned cb = s.rptr[x], ce = s.rptr[x + 1];
+      for (unsigned c0 = cb; c0 < ce; c0 += 64) {
+        const unsigned c = c0 + lane, cc = min(c, ce - 1u);
+        const int col = s.cols[cc];
+        const double val = s.vals[cc];
+        const bool t = (int)(c < ce) & (int)(((lxv + s.ly[col]) - val) < eps) & (int)(col >= ystart) & (int)!k4_bit(s.visy, col) & (int)k4_bit(s.goody, col);
+        const unsigned long long b = __ballot(t);
+        if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); mbest = s.match[best]; break; }
+      }
+    } else {
+      const bool t = (int)(lane < ncnt) & (int)(((lxv + lyL) - lv) < eps) & (int)(lc >= ystart) & (int)((((~vwL & gwL) >> (lc & 31)) & 1u) != 0u);
+      const unsigned long long b = __ballot(t);
+      if (b) {
+        const int l = (int)__ffsll((long long)b) - 1;
+        best = __builtin_amdgcn_readlane(lc, l);
+        mbest = __builtin_amdgcn_readlane(mL, l);
+      }
+    }
+    bool augment = false;
+    if (bgt) {
+      const int lim = min(n, best);
+      bool cand = (int)(yw < lim) & (int)((((~vwW & gwW) >> (ywc & 31)) & 1u) != 0u) & (int)(((lxv + lyW) - bg) < eps);
+      unsigned long long bw = __ballot(cand);
+      while (!bw && p + 64 < lim) {  // windows without a candidate
+        p += 64;
+        yw = p + lane; ywc = min(yw, n - 1);
+        vwW = s.visy[ywc >> 5]; gwW = s.goody[ywc >> 5]; lyW = s.ly[ywc]; mW = s.match[ywc];
+        cand = (int)(yw < lim) & (int)((((~vwW & gwW) >> (ywc & 31)) & 1u) != 0u) & (int)(((lxv + lyW) - bg) < eps);
+        bw = __ballot(cand);
+      }
+      if (tn != 0) {
+        if (bw) {
+          const int l = (int)__ffsll((long long)bw) - 1;
+          best = p + l;
+          mbest = __builtin_amdgcn_readlane(mW, l);
+          if (lane == slot) cp = best;
+        } else if (lane == slot) cp = max(p, lim);
+      } else {
+        // ---- E9 march (km2.hip): a chain of rows without tight explicit entries that share the label L picks the members of
+        // T_L in column order, up to 64 activations per window (lim == n here: the row has no listed entry)
+        int outcome = bw ? 3 : 0;
+        if (!bw) p = n;  // the skip loop above has covered every column below n
+        while (outcome == 3) {
+          bool cont = false;
+          if (cand && mW != K4_NONE) cont = (int)(s.tln[mW] == 0) & (int)(s.lx[mW] == lxv);
+          const unsigned long long stop = __ballot(cand && !cont);
+          const int jstar = stop ? (int)__ffsll((long long)stop) - 1 : 63;
+          const unsigned long long R = bw & (~0ull >> (63 - jstar));  // the picks of this window, in column order
+          const unsigned long long below = R & ((1ull << lane) - 1ull);
+          const int rank = __popcll(below);
+          const int pm = __shfl(mW, below ? 63 - __clzll((long long)below) : 0, 64);
+          if ((R >> lane) & 1ull) {
+            atomicOr(&s.visy[yw >> 5], 1u << (yw & 31));
+            s.sty[sp + rank] = (unsigned short)yw;
+            if (rank > 0) s.stx[sp + rank] = (unsigned short)pm;  // the row that picked this column (frame sp holds x)
+          }
+          const int k = __popcll(R), lastlane = 63 - __clzll((long long)R);
+          const int mlast = __builtin_amdgcn_readlane(mW, lastlane);
+          if (PROF) *q_act += k - 1;
+          sp += k - 1;  // frame of the row that made the last pick
+          p += lastlane + 1;
+          if (mlast == K4_NONE) { outcome = 1; break; }
+          sp++;
+          if (lane == 0) { s.stx[sp] = (unsigned short)mlast; s.sty[sp] = (unsigned short)K4_NONE; }
+          x = mlast; ystart = 0;
+          if (stop) { outcome = 2; break; }  // the owner of the last pick is not part of the chain
+          if (PROF) ++*q_act;                // ... it is: its activation continues the march
+          bw = 0;
+          while (!bw && p < n) {
+            yw = p + lane; ywc = min(yw, n - 1);
+            vwW = s.visy[ywc >> 5]; gwW = s.goody[ywc >> 5]; lyW = s.ly[ywc]; mW = s.match[ywc];
+            cand = (int)(yw < n) & (int)((((~vwW & gwW) >> (ywc & 31)) & 1u) != 0u) & (int)(((lxv + lyW) - bg) < eps);
+            bw = __ballot(cand);
+            if (!bw) p += 64;
+          }
+          if (!bw) outcome = 0;
+        }
+        if (lane == slot) cp = min(p, n);
+        __builtin_amdgcn_wave_barrier();
+        if (outcome == 1) { augment = true; }
+        else if (outcome == 2) continue;
+        // outcome 0: x (possibly a row reached by the march: its frame is sp) has no candidate left -> pop below
+      }
+    }
+    if (augment) break;
+    if (best != INT_MAX) {
+      if (lane == 0) { atomicOr(&s.visy[best >> 5], 1u << (best & 31)); s.sty[sp] = (unsigned short)best; }
+      if (mbest == K4_NONE) break;
+      sp++;
+      if (lane == 0) { s.stx[sp] = (unsigned short)mbest; s.sty[sp] = (unsigned short)K4_NONE; }
+      x = mbest; ystart = 0;
+    } else {
+      sp--;
+      if (sp < 0) return false;
+      x = s.stx[sp]; ystart = (int)s.sty[sp] + 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // augment: match[y] = x on every level of the recursion (km.cpp:26-29); the last column is no longer free
+  __builtin_amdgcn_wave_barrier();
+  const int ylast = s.sty[sp];
+  for (int f = lane; f <= sp; f += 64) s.match[s.sty[f]] = s.stx[f];
+  if (lane == 0) atomicAnd(&s.freey[ylast >> 5], ~(1u << (ylast & 31)));
+  return true;
+}
+
+// ---- literal solver (hazard fallback of R4): lane 0 of wave 0 runs the reference line by line on background + CSR.
+// A matrix that gets here has an edge within an ulp of eps after a relabelling; the reference itself usually does not
+// terminate on such input (its delta becomes 0), hence the step budget (the O(n^3) bound of a legitimate instance).  Slow by design,
+// never on the hot path.
+__device__ inline int k4_literal(const K4& s, const Km2Problem& P) {
+  const int n = s.n;
+  const double bg = s.bg, eps = s.eps;
+  unsigned short* curs = s.tlc;  // per frame: CSR cursor relative to the row start (n entries of the 3n available)
+  for (int i = 0; i < n; i++) { s.lx[i] = P.lx_init[i]; s.ly[i] = 0.0; s.match[i] = (unsigned short)K4_NONE; }
+  // bound of the reference itself: <= n descents per phase, <= n failed phases per root, n roots (the budget only stops non-finite input)
+  long long budget = 2ll * n * n * n + 4096;
+  for (int root = 0; root < n; root++) {
+    for (int j = 0; j < n; j++) s.slack[j] = K4_INF;
+    for (;;) {
+      for (int w = 0; w < s.nw; w++) { s.visx[w] = 0u; s.visy[w] = 0u; }
+      int sp = 0;
+      s.stx[0] = (unsigned short)root; s.sty[0] = 0; curs[0] = 0;
+      s.visx[root >> 5] |= 1u << (root & 31);
+      bool ok = false;
+      while (sp >= 0) {
+        const int x = s.stx[sp];
+        const double lxv = s.lx[x];
+        const unsigned rb = s.rptr[x], re = s.rptr[x + 1];
+        unsigned c = rb + curs[sp];
+        int y = s.sty[sp];
+        bool descended = false;
+        for (; y < n; ++y) {
+          double wv = bg;
+          if (c < re && s.cols[c] == y) { wv = s.vals[c]; ++c; }
+          if (k4_bit(s.visy, y)) continue;
+          const double t = lxv + s.ly[y] - wv;
+          if (t < eps) {
+            s.visy[y >> 5] |= 1u << (y & 31);
+            const int m = s.match[y];
+            s.sty[sp] = (unsigned short)y;  // the column this frame is waiting on
+            curs[sp] = (unsigned short)(c - rb);
+            if (m == K4_NONE) { ok = true; break; }
+            if (--budget < 0) return 5;
+            sp++;
+            s.stx[sp] = (unsigned short)m; s.sty[sp] = 0; curs[sp] = 0;
+            s.visx[m >> 5] |= 1u << (m & 31);
+            descended = true;
+            break;
+          } else
+            s.slack[y] = fmin(t, s.slack[y]);
+        }
+        if (ok) break;
+        if (descended) continue;
+        sp--;  // findpath(x) returns false: the caller resumes after the column it was waiting on
+        if (sp >= 0) s.sty[sp] = (unsigned short)(s.sty[sp] + 1);
+      }
+      if (ok) {
+        for (int f = 0; f <= sp; f++) s.match[s.sty[f]] = s.stx[f];
+        break;
+      }
+      double delta = K4_INF;
+      for (int j = 0; j < n; j++)
+        if (!k4_bit(s.visy, j)) delta = fmin(delta, s.slack[j]);
+      for (int i = 0; i < n; i++)
+        if (k4_bit(s.visx, i)) s.lx[i] -= delta;
+      for (int i = 0; i < n; i++) {
+        if (k4_bit(s.visy, i)) s.ly[i] += delta;
+        else s.slack[i] -= delta;
+      }
+      if (--budget < 0) return 5;
+    }
+  }
+  return 0;
+}
+
+// One solve by the calling 256-thread workgroup: `smem` = lds_bytes of LDS (gh_km4_lds_bytes(P.n) at least), every thread of the
+// workgroup must call.  Shared by the stand-alone kernel k_km4 (km4.hip) and the persistent pair loop (loop.hip).
+template <bool PROF>
+__device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem, int lds_bytes, unsigned long long* __restrict__ lstat) {
+  const unsigned long long t_wall0 = lstat ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, common to all CUs
+  const int n = P.n, nw = (n + 31) / 32, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  K4 s;
+  s.n = n; s.nw = nw; s.bg = P.bg; s.eps = P.eps;
+  s.rptr = (k4_gu32)P.row_ptr; s.cols = (k4_gint)P.cols; s.vals = (k4_gf64)P.vals;
+  s.lx = (double*)smem;
+  s.ly = s.lx + n;
+  s.slack = s.ly + n;
+  s.tlv = s.slack + n;
+  s.red = s.tlv + (size_t)n * K4_CAP;  // 16 doubles
+  s.visx = (unsigned*)(s.red + 16);
+  s.visy = s.visx + nw; s.prevy = s.visy + nw; s.pushed = s.prevy + nw; s.good = s.pushed + nw; s.goody = s.good + nw;
+  s.freey = s.goody + nw; s.ovf = s.freey + nw;
+  s.sh = (int*)(s.ovf + nw);
+  s.match = (unsigned short*)(s.sh + SH_NUM);
+  s.stx = s.match + n;
+  s.sty = s.stx + n + 2;
+  s.tlc = s.sty + n + 2;
+  s.tln = (unsigned char*)(s.tlc + (size_t)n * K4_CAP);
+  // pool blocks in whatever the launch's LDS allocation leaves beyond this problem's arrays
+  {
+    char* pend = (char*)(s.tln + n);
+    pend += (8 - ((size_t)pend & 7)) & 7;
+    const long long spare = (long long)lds_bytes - (long long)(pend - smem) - 16;
+    s.nblk = (int)max(0ll, min((long long)K4_MAXBLK, spare / (K4_BLK * 10)));
+    s.pval = (double*)pend;
+    s.pcol = (unsigned short*)(s.pval + (size_t)s.nblk * K4_BLK);
+    s.fb = (unsigned*)(s.pcol + (size_t)s.nblk * K4_BLK + (((size_t)s.nblk * K4_BLK) & 1));
+  }
+  const double bg = s.bg, eps = s.eps;
+
+  long long c_flood = 0, c_fail = 0, c_pull = 0, c_dfs = 0, q_phase = 0, q_fail = 0, q_rounds = 0, q_iter = 0, q_act = 0, q_frows = 0, q_prows = 0;
+  long long pcf[5] = {0, 0, 0, 0, 0};
+  const long long t_begin = PROF ? (long long)__builtin_readcyclecounter() : 0;
+
+  for (int i = tid; i < n; i += K4_T) { s.lx[i] = P.lx_init[i]; s.ly[i] = 0.0; s.match[i] = (unsigned short)K4_NONE; s.tln[i] = 0; }
+  for (int i = tid; i < n * K4_CAP; i += K4_T) { s.tlc[i] = 0; s.tlv[i] = 0.0; }  // list slots are read unconditionally: keep them valid
+  for (int w = tid; w < nw; w += K4_T) {
+    unsigned all = ~0u;
+    if (w == nw - 1 && (n & 31)) all = (1u << (n & 31)) - 1u;
+    s.freey[w] = all; s.ovf[w] = 0u;
+  }
+  if (tid < SH_NUM) s.sh[tid] = 0;
+  if (tid < 2) s.fb[tid] = s.nblk >= 32 * (tid + 1) ? ~0u : (s.nblk > 32 * tid ? (1u << (s.nblk - 32 * tid)) - 1u : 0u);
+  __syncthreads();
+  // initial lists: every row once (R2); stx doubles as the list of all rows
+  for (int i = tid; i < n; i += K4_T) s.stx[i] = (unsigned short)i;
+  __syncthreads();
+  k4_bulk<true, false, false>(s, s.stx, n, wave, lane);
+  __syncthreads();
+
+  int bad = 0;
+  bool hazard = false;
+  for (int root = 0; root < n && !bad && !hazard; ++root) {
+    for (int i = tid; i < n; i += K4_T) s.slack[i] = K4_INF;
+    for (int w = tid; w < nw; w += K4_T) s.pushed[w] = 0u;
+    bool have_prev = false;
+    for (int phase = 0;; ++phase) {
+      if (PROF) q_phase++;
+      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; }
+      __syncthreads();
+      const long long t0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+      if (wave == 0) {
+        int fq = 0;
+        const bool fr = k4_flood<PROF>(s, root, lane, &fq, pcf);
+        if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
+      }
+      __syncthreads();
+      const bool free_found = s.sh[SH_RES] != 0;
+      const int qt = s.sh[SH_QTF];
+      const long long t1 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+      if (PROF) c_flood += t1 - t0;
+      if (!free_found) {
+        // ---- R4: failed phase
+        if (PROF) { q_fail++; q_frows += qt; }
+        k4_bulk<false, true, true>(s, s.stx, qt, wave, lane);  // rows that are new in this phase of the root
+        double lm = INFINITY;
+        for (int i = tid; i < qt; i += K4_T) lm = fmin(lm, s.lx[s.stx[i]]);
+        lm = k4_wave_min(lm);
+        if (lane == 0) s.red[wave] = lm;
+        __syncthreads();
+        const double lxmin = fmin(fmin(s.red[0], s.red[1]), fmin(s.red[2], s.red[3]));
+        double dl = K4_INF;
+        for (int y = tid; y < n; y += K4_T)
+          if (!k4_bit(s.visy, y)) {
+            const double s2 = fmin(s.slack[y], (lxmin + s.ly[y]) - bg);  // E4
+            s.slack[y] = s2;
+            dl = fmin(dl, s2);
+          }
+        dl = k4_wave_min(dl);
+        if (lane == 0) s.red[4 + wave] = dl;
+        for (int w = tid; w < nw; w += K4_T) {
+          if (have_prev && (s.prevy[w] & ~s.visy[w])) s.sh[SH_HAZ] = 1;  // a visited column dropped out (R4)
+          s.prevy[w] = s.visy[w];
+        }
+        __syncthreads();
+        dl = fmin(fmin(s.red[4], s.red[5]), fmin(s.red[6], s.red[7]));
+        if (s.sh[SH_HAZ] || ((flags & 4) && phase == 0 && root == n / 2)) { hazard = true; break; }
+        for (int i = tid; i < n; i += K4_T) {  // km.cpp:86-97
+          if (k4_bit(s.visx, i)) s.lx[i] -= dl;
+          if (k4_bit(s.visy, i)) s.ly[i] += dl;
+          else s.slack[i] -= dl;
+        }
+        for (int w = tid; w < nw; w += K4_T) s.pushed[w] = s.visx[w];
+        __syncthreads();
+        k4_bulk<true, true, false>(s, s.stx, qt, wave, lane);  // lists under the new labels + the minima of the next phase
+        have_prev = true;
+        if (PROF) { q_prows += qt; c_fail += (long long)__builtin_readcyclecounter() - t1; }
+        if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
+        continue;
+      }
+      // ---- R5: augmenting phase.  S by pull rounds ...
+      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = s.ovf[w]; s.goody[w] = s.freey[w]; }
+      if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; }
+      __syncthreads();
+      for (int round = 0;; round++) {
+        if (PROF) q_rounds++;
+        double gm = INFINITY;
+        for (int base = tid; base < n; base += 4 * K4_T) {  // columns: S gains the columns whose owner is in S
+          int yy[4], mm[4];
+          unsigned gw[4];
+          double lyv[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            yy[k] = base + k * K4_T;
+            const int yc = min(yy[k], n - 1);
+            gw[k] = s.goody[yc >> 5]; mm[k] = s.match[yc]; lyv[k] = s.ly[yc];
+          }
+          unsigned ow[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) ow[k] = s.good[(mm[k] == K4_NONE ? 0 : mm[k]) >> 5];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (yy[k] >= n) continue;
+            bool g = (gw[k] >> (yy[k] & 31)) & 1u;
+            if (!g && mm[k] != K4_NONE && ((ow[k] >> (mm[k] & 31)) & 1u)) { atomicOr(&s.goody[yy[k] >> 5], 1u << (yy[k] & 31)); g = true; }
+            if (g) gm = fmin(gm, lyv[k]);
+          }
+        }
+        gm = k4_wave_min(gm);
+        if (lane == 0) s.red[8 + wave] = gm;
+        __syncthreads();
+        if (tid == 0) s.sh[SH_CH0 + ((round + 1) & 1)] = 0;
+        const double gmin = fmin(fmin(s.red[8], s.red[9]), fmin(s.red[10], s.red[11]));
+        bool ch = false;
+        for (int base = tid; base < n; base += 4 * K4_T) {  // rows: background-tight to the best column of S, or a listed entry in S
+          int xx[4], tn[4], lc[4][K4_CAP];
+          unsigned gdw[4];
+          double lxv[4], lv[4][K4_CAP];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            xx[k] = base + k * K4_T;
+            const int xc = min(xx[k], n - 1);
+            gdw[k] = s.good[xc >> 5]; lxv[k] = s.lx[xc]; tn[k] = s.tln[xc];
+#pragma unroll
+            for (int e = 0; e < K4_CAP; e++) { lc[k][e] = s.tlc[xc * K4_CAP + e]; lv[k][e] = s.tlv[xc * K4_CAP + e]; }
+          }
+          double lyc[4][K4_CAP];
+          unsigned gyw[4][K4_CAP];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < K4_CAP; e++) { lyc[k][e] = s.ly[lc[k][e]]; gyw[k][e] = s.goody[lc[k][e] >> 5]; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (xx[k] >= n || ((gdw[k] >> (xx[k] & 31)) & 1u)) continue;
+            bool g = (int)((lxv[k] - bg) < eps) & (int)(((lxv[k] + gmin) - bg) < eps);
+            const int cn = k4_cnt(tn[k]), t = min(cn, K4_CAP);
+#pragma unroll
+            for (int e = 0; e < K4_CAP; e++)
+              g |= (int)(e < t) & (int)(((lxv[k] + lyc[k][e]) - lv[k][e]) < eps) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);
+            if (!g && cn > K4_CAP) {
+              const int pb = k4_blk(tn[k]) * K4_BLK - K4_CAP;
+              for (int e = K4_CAP; e < cn; e++) {
+                const int col = s.pcol[pb + e];
+                g |= (int)(((lxv[k] + s.ly[col]) - s.pval[pb + e]) < eps) & (int)k4_bit(s.goody, col);
+              }
+            }
+            if (g) { atomicOr(&s.good[xx[k] >> 5], 1u << (xx[k] & 31)); ch = true; }
+          }
+        }
+        if (ch) s.sh[SH_CH0 + (round & 1)] = 1;
+        __syncthreads();
+        if (!s.sh[SH_CH0 + (round & 1)]) break;
+        if (round >= 40) {  // give up pruning for this phase: any superset of good is valid (R5)
+          for (int w = tid; w < nw; w += K4_T) s.goody[w] = ~0u;
+          break;
+        }
+      }
+      __syncthreads();
+      const long long t2 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+      if (PROF) c_pull += t2 - t1;
+      // ... then the DFS (wave 0)
+      if (wave == 0) {
+        const bool ok = k4_dfs<PROF>(s, root, lane, &q_iter, &q_act);
+        if (!ok && lane == 0) s.sh[SH_BAD] = 3;
+      }
+      __syncthreads();
+      if (PROF) c_dfs += (long long)__builtin_readcyclecounter() - t2;
+      if (s.sh[SH_BAD]) bad = s.sh[SH_BAD];
+      break;
+    }
+  }
+  __syncthreads();
+  if (hazard) {
+    if (tid == 0) s.sh[SH_BAD] = k4_literal(s, P);
+    __syncthreads();
+    bad = s.sh[SH_BAD];
+  }
+  for (int i = tid; i < n; i += K4_T) P.match_out[i] = s.match[i] == K4_NONE ? -1 : (int)s.match[i];
+  if (tid == 0 && lstat) {  // launch record: first start, last end, sum and maximum of the solve times, solves
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), dt = t1 - t_wall0;
+    atomicMax(&lstat[0], (1ull << 62) - t_wall0);
+    atomicMax(&lstat[1], t1);
+    atomicAdd(&lstat[2], dt);
+    atomicMax(&lstat[3], dt);
+    atomicAdd(&lstat[4], 1ull);
+  }
+  if (tid == 0) {
+    if (bad && P.status) *P.status = bad;
+    if (P.steps) {
+      P.steps[0] = q_act;
+      if (PROF) {
+        P.steps[1] = q_phase; P.steps[2] = q_fail; P.steps[3] = q_rounds; P.steps[4] = q_iter; P.steps[5] = q_frows; P.steps[6] = q_prows;
+        P.steps[7] = c_flood; P.steps[8] = c_fail; P.steps[9] = c_pull; P.steps[10] = c_dfs;
+        P.steps[11] = (long long)__builtin_readcyclecounter() - t_begin; P.steps[12] = hazard ? 1 : 0;
+        for (int k = 0; k < 5; k++) P.steps[13 + k] = pcf[k];
+      }
+    }
+  }
+}
+
+
+}  // namespace

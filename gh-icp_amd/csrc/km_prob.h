@@ -18,6 +18,7 @@ int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
 bool gh_km2_fits(int n);
 int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
 bool gh_km4_fits(int n);
+size_t gh_km4_lds_bytes(int n);
 
 // A batch of problems of different sizes: problems are grouped into classes of equal LDS occupancy (problems per CU) so that one
 // large problem does not lower the occupancy of all the others, and within a class the largest problems start first.

@@ -19,6 +19,7 @@
 #include <cmath>
 
 #include "km_prob.h"
+#include "km4_dev.h"
 int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, const int* done_flag);
 
 namespace {
@@ -75,24 +76,22 @@ __device__ inline double cd_pivot(const LoopProb& P, double wed, double wfd, dou
 // One sweep: thread = "row" a (keypoint of set A), loop over a chunk of set B staged in LDS.
 // The feature matrix is read as [b][a] so that lanes (consecutive a) touch consecutive addresses.
 // Row arg-min semantics = ghicp_reg.cpp:715-724 / 622-650: start (9e20, 0), strict '<', ascending index.
+// (bx, by) = the block coordinates of the stand-alone kernel; sB: CHUNK_MAX * 3 doubles, red: 16 doubles of LDS.  The persistent
+// pair loop calls the same body for every (bx, by) in turn, so both paths produce the same partial sums in the same order.
 template <int FT, bool COLS>
-__global__ __launch_bounds__(ROWS) void k_cd_rowmin(const LoopProb* __restrict__ probs) {
-  const LoopProb& P = probs[blockIdx.z];
-  if (P.st->done) return;
+__device__ inline void dev_cd_rowmin(const LoopProb& P, const int bx, const int by, double* sB, double* red) {
   const int ka = COLS ? P.C.kt : P.C.ks, kb = COLS ? P.C.ks : P.C.kt;
   const int chunk = COLS ? P.C.chunk_a : P.C.chunk_b, nchunk = COLS ? P.C.nchunk_a : P.C.nchunk_b;
-  if ((int)blockIdx.y >= nchunk || (int)blockIdx.x * ROWS >= ka) return;
-  const double* __restrict__ A = COLS ? P.kpT : P.kpS;
-  const double* __restrict__ B = COLS ? P.kpS : P.kpT;
-  const void* __restrict__ F = COLS ? P.FD : P.FDt;
-  __shared__ double sB[CHUNK_MAX * 3];
-  __shared__ double red[16];
+  if (by >= nchunk || bx * ROWS >= ka) return;
+  const double* A = COLS ? P.kpT : P.kpS;
+  const double* B = COLS ? P.kpS : P.kpT;
+  const void* F = COLS ? P.FD : P.FDt;
   const int it = P.st->it;
-  const int jb = blockIdx.y * chunk;
+  const int jb = by * chunk;
   const int je = min(kb, jb + chunk);
   for (int t = threadIdx.x; t < (je - jb) * 3; t += ROWS) sB[t] = B[(size_t)jb * 3 + t];
   __syncthreads();
-  const int a = blockIdx.x * ROWS + threadIdx.x;
+  const int a = bx * ROWS + threadIdx.x;
   const bool live = a < ka;
   double ax = 0, ay = 0, az = 0;
   if (live) { ax = A[(size_t)a * 3]; ay = A[(size_t)a * 3 + 1]; az = A[(size_t)a * 3 + 2]; }
@@ -114,27 +113,33 @@ __global__ __launch_bounds__(ROWS) void k_cd_rowmin(const LoopProb* __restrict__
       if (cd < best) { best = cd; bidx = j; }
       if (!COLS) { const double c0 = cd - piv; s += c0; s2 += c0 * c0; }
     }
-    (COLS ? P.pminB : P.pminA)[(size_t)blockIdx.y * ka + a] = best;
-    (COLS ? P.pidxB : P.pidxA)[(size_t)blockIdx.y * ka + a] = bidx;
+    (COLS ? P.pminB : P.pminA)[(size_t)by * ka + a] = best;
+    (COLS ? P.pidxB : P.pidxA)[(size_t)by * ka + a] = bidx;
   }
   if (!COLS) {
     const double bs = gh_block_sum(s, red);
     const double bs2 = gh_block_sum(s2, red);
     if (threadIdx.x == 0) {
-      const size_t b = (size_t)blockIdx.y * cdiv_dev(ka, ROWS) + blockIdx.x;
+      const size_t b = (size_t)by * cdiv_dev(ka, ROWS) + bx;
       P.psum[b * 2] = bs;
       P.psum[b * 2 + 1] = bs2;
     }
   }
 }
 
-// calCD_* tails: CDmean, CDstd, penalty (ghicp_reg.cpp:228-239, 264-287, 317-335)
-__global__ __launch_bounds__(256) void k_penalty(const LoopProb* __restrict__ probs) {
-  const LoopProb& P = probs[blockIdx.x];
-  LoopState* st = P.st;
-  if (st->done) return;
-  const LoopConst& C = P.C;
+template <int FT, bool COLS>
+__global__ __launch_bounds__(ROWS) void k_cd_rowmin(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.z];
+  if (P.st->done) return;
+  __shared__ double sB[CHUNK_MAX * 3];
   __shared__ double red[16];
+  dev_cd_rowmin<FT, COLS>(P, (int)blockIdx.x, (int)blockIdx.y, sB, red);
+}
+
+// calCD_* tails: CDmean, CDstd, penalty (ghicp_reg.cpp:228-239, 264-287, 317-335)
+__device__ inline void dev_penalty(const LoopProb& P, double* red) {
+  LoopState* st = P.st;
+  const LoopConst& C = P.C;
   double s = 0, s2 = 0;
   for (int i = threadIdx.x; i < C.nparts; i += blockDim.x) { s += P.psum[i * 2]; s2 += P.psum[i * 2 + 1]; }
   s = gh_block_sum(s, red);
@@ -173,6 +178,13 @@ __global__ __launch_bounds__(256) void k_penalty(const LoopProb* __restrict__ pr
   }
 }
 
+__global__ __launch_bounds__(256) void k_penalty(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.x];
+  if (P.st->done) return;
+  __shared__ double red[16];
+  dev_penalty(P, red);
+}
+
 // Dense KM weights for the large-n fallback (ghicp_reg.cpp:348-365).
 template <int FT>
 __global__ __launch_bounds__(256) void k_km_weights(const LoopProb* __restrict__ probs) {
@@ -200,12 +212,10 @@ __global__ __launch_bounds__(256) void k_km_weights(const LoopProb* __restrict__
 // Sparse KM input (km2.hip): per row the explicit entries (j, -CD) with CD < penalty (ghicp_reg.cpp:358-365);
 // every other entry of the n x n graph is the background -penalty.  One wave per row, two passes (count, fill).
 template <int FT, int FILL>
-__global__ __launch_bounds__(256) void k_km_csr(const LoopProb* __restrict__ probs) {
-  const LoopProb& P = probs[blockIdx.y];
-  if (P.st->done || P.km_rptr == nullptr) return;
+__device__ inline void dev_km_csr(const LoopProb& P, const int bx) {
   const LoopConst& C = P.C;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
+  const int i = bx * 4 + wave;
   if (i >= C.n) return;
   const double pen = P.st->penalty;
   if (i >= C.ks) {  // padding rows: all background
@@ -246,14 +256,18 @@ __global__ __launch_bounds__(256) void k_km_csr(const LoopProb* __restrict__ pro
   }
 }
 
-// exclusive scan of the row counts (one block per pair) + the km2 problem descriptor
-__global__ __launch_bounds__(1024) void k_km_scan_desc(const LoopProb* __restrict__ probs) {
-  const LoopProb& P = probs[blockIdx.x];
+template <int FT, int FILL>
+__global__ __launch_bounds__(256) void k_km_csr(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.y];
   if (P.st->done || P.km_rptr == nullptr) return;
-  __shared__ int sc[17];
+  dev_km_csr<FT, FILL>(P, (int)blockIdx.x);
+}
+
+// exclusive scan of the row counts (one block per pair) + the km2 problem descriptor
+__device__ inline void dev_km_scan_desc(const LoopProb& P, int* sc) {
   const int n = P.C.n;
   int carry = 0;
-  for (int base = 0; base < n; base += 1024) {
+  for (int base = 0; base < n; base += (int)blockDim.x) {
     const int i = base + threadIdx.x;
     const int v = i < n ? (int)P.km_cnt[i] : 0;
     int tot;
@@ -271,21 +285,24 @@ __global__ __launch_bounds__(1024) void k_km_scan_desc(const LoopProb* __restric
   }
 }
 
-// Everything after the sweep, one 1024-thread workgroup per pair.
-template <int FT>
-__global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ probs) {
+__global__ __launch_bounds__(1024) void k_km_scan_desc(const LoopProb* __restrict__ probs) {
   const LoopProb& P = probs[blockIdx.x];
+  if (P.st->done || P.km_rptr == nullptr) return;
+  __shared__ int sc[17];
+  dev_km_scan_desc(P, sc);
+}
+
+// Everything after the sweep, one 1024-thread workgroup per pair.
+// red: 16 doubles, ired: 17 ints, sh: 32 doubles of LDS
+template <int FT>
+__device__ inline void dev_solve(const LoopProb& P, double* red, int* ired, double* sh) {
   LoopState* st = P.st;
-  if (st->done) return;
   const LoopConst& C = P.C;
-  double* __restrict__ kpS = P.kpS;
-  const double* __restrict__ kpT = P.kpT;
-  const void* __restrict__ FD = P.FD;
-  int* __restrict__ SP = P.SP;
-  int* __restrict__ TP = P.TP;
-  __shared__ double red[16];
-  __shared__ int ired[17];
-  __shared__ double sh[32];
+  double* kpS = P.kpS;
+  const double* kpT = P.kpT;
+  const void* FD = P.FD;
+  int* SP = P.SP;
+  int* TP = P.TP;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int it = st->it;
   const double penalty = st->penalty;
@@ -490,6 +507,16 @@ __global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ pro
   }
 }
 
+template <int FT>
+__global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.x];
+  if (P.st->done) return;
+  __shared__ double red[16];
+  __shared__ int ired[17];
+  __shared__ double sh[32];
+  dev_solve<FT>(P, red, ired, sh);
+}
+
 template <typename T> __global__ void k_transpose(const T* __restrict__ in, int rows, int cols, T* __restrict__ out) {
   __shared__ T tile[32][33];
   const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
@@ -504,6 +531,94 @@ template <typename T> __global__ void k_transpose(const T* __restrict__ in, int 
 __global__ void k_collect_done(const LoopProb* __restrict__ probs, int n, int* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { out[i * 2] = probs[i].st->it; out[i * 2 + 1] = probs[i].st->done; }
+}
+
+// ---- Persistent pair loop (Kuhn-Munkres configurations).  One 256-thread workgroup = one SOLVE SLOT: it pops a pair from the class
+// queue and runs that pair's whole GH-ICP loop (ghicp_reg.cpp:49-103: calED + calCD_* sweep, penalty, graph build, Kuhn-Munkres
+// solve, transformestimation, adjustweight, iterate until converged), then pops the next pair.  No kernel boundary, no host poll
+// and no other pair stands between two iterations of a pair, so a slot is never idle while its queue holds work: converged pairs
+// free their slot at once and the next pair is admitted at once (continuous batching at pair granularity; per pair the order of
+// ghicp_reg.cpp:49-103 is kept).  The stages are the SAME device functions the stand-alone kernels run, called for every block
+// coordinate in turn: identical partial sums, identical results.  Stage scratch (13 KB) overlays the solver's LDS.
+constexpr int PL_SCRATCH = (CHUNK_MAX * 3 + 16 + 32) * 8 + 20 * 4;
+
+// The stages as out-of-line calls: the persistent kernel's register budget is then the LARGEST stage's, not what the register
+// allocator makes of all of them inlined into one loop (256 VGPRs + scratch, one workgroup per CU, when everything is inlined).
+template <int FT>
+__device__ __noinline__ void pl_sweep(const LoopProb& P, double* sB, double* red) {
+  const int rbA = cdiv_dev(P.C.ks > 0 ? P.C.ks : 1, ROWS);
+  for (int by = 0; by < P.C.nchunk_b; by++)
+    for (int bx = 0; bx < rbA; bx++) {
+      __syncthreads();
+      dev_cd_rowmin<FT, false>(P, bx, by, sB, red);
+    }
+  __syncthreads();
+  dev_penalty(P, red);
+  __syncthreads();
+}
+template <int FT>
+__device__ __noinline__ void pl_graph(const LoopProb& P, int* ired) {
+  const int rb4 = cdiv_dev(P.C.n, 4);
+  for (int bx = 0; bx < rb4; bx++) dev_km_csr<FT, 0>(P, bx);
+  __syncthreads();
+  dev_km_scan_desc(P, ired);
+  __syncthreads();
+  for (int bx = 0; bx < rb4; bx++) dev_km_csr<FT, 1>(P, bx);
+  __syncthreads();
+}
+template <bool PROF>
+__device__ __noinline__ void pl_km(const Km2Problem* desc, int km_flags, char* smem, int lds_bytes) {
+  const Km2Problem KP = *desc;
+  k4_solve_block<PROF>(KP, km_flags, smem, lds_bytes, nullptr);
+  __syncthreads();
+}
+template <int FT>
+__device__ __noinline__ void pl_solve(const LoopProb& P, double* red, int* ired, double* sh) {
+  dev_solve<FT>(P, red, ired, sh);
+  __syncthreads();
+}
+
+template <int FT, bool PROF>
+__global__ __launch_bounds__(K4_T, 3) void k_pair_loop(const LoopProb* __restrict__ probs, const int* __restrict__ order, const int npairs, int* qhead,
+                                                  const int km_flags, const int lds_bytes, unsigned long long* lstat, int* progress) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_idx;
+  double* sB = reinterpret_cast<double*>(smem);
+  double* red = sB + CHUNK_MAX * 3;
+  double* sh = red + 16;
+  int* ired = reinterpret_cast<int*>(sh + 32);
+  const unsigned long long t_slot0 = lstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  unsigned long long t_solve = 0ull, t_solve_max = 0ull, n_solve = 0ull;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_idx = atomicAdd(qhead, 1);
+    __syncthreads();
+    const int q = s_idx;
+    if (q >= npairs) break;
+    const LoopProb& P = probs[order[q]];
+    while (*(volatile int*)&P.st->done == 0) {
+      pl_sweep<FT>(P, sB, red);   // calED + calCD_* + sums + penalty (ghicp_reg.cpp:114-139, 216-341)
+      pl_graph<FT>(P, ired);      // the sparse graph of findcorrespondenceKM (ghicp_reg.cpp:348-365): count, scan, fill
+      const unsigned long long t0 = lstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
+      pl_km<PROF>(P.km_desc, km_flags, smem, lds_bytes);  // Km::kmsolve (km.cpp:40-126)
+      if (lstat) {
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+        t_solve += dt; t_solve_max = dt > t_solve_max ? dt : t_solve_max; n_solve++;
+      }
+      pl_solve<FT>(P, red, ired, sh);  // Km::output, transformestimation, adjustweight (ghicp_reg.cpp:416-460, 605-927)
+    }
+    if (threadIdx.x == 0 && progress) __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0 && lstat) {  // launch record: first slot start, last slot end, sum / max of the solve times, solves, sum of slot lifetimes
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    atomicMax(&lstat[0], (1ull << 62) - t_slot0);
+    atomicMax(&lstat[1], t1);
+    atomicAdd(&lstat[2], t_solve);
+    atomicMax(&lstat[3], t_solve_max);
+    atomicAdd(&lstat[4], n_solve);
+    atomicAdd(&lstat[5], t1 - t_slot0);
+    atomicAdd(&lstat[6], 1ull);
+  }
 }
 
 static void pick_chunks(int ka, int kb, int batch, int* chunk, int* nchunk) {
@@ -529,6 +644,72 @@ struct Carver {
   }
 };
 
+// Launches the persistent pair loop: one launch per LDS-occupancy class of the batch (gh_km4_plan: problems per CU, largest graphs
+// first), all classes concurrently -- class 0 on the context's stream, the others on auxiliary streams forked from and joined into
+// it -- each with its own queue head.  A launch has at most (slots per CU x CUs) workgroups; every workgroup pops pairs until its
+// queue is empty.  Returns when every pair of the batch has converged (or hit max_iter).
+template <int FT>
+int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan& plan, int* dqheads) {
+  hipStream_t s = ctx->stream;
+  const int nc = plan.nclass;
+  if (nc <= 0) return GHICP_OK;
+  while ((int)ctx->aux_streams.size() < nc - 1) {
+    hipStream_t a = nullptr;
+    GH_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    ctx->aux_streams.push_back(a);
+  }
+  while ((int)ctx->aux_events.size() < nc + 1) {
+    hipEvent_t e = nullptr;
+    GH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->aux_events.push_back(e);
+  }
+  if (!ctx->progress_host) {
+    if (hipHostMalloc((void**)&ctx->progress_host, 64, hipHostMallocMapped) != hipSuccess)
+      return ctx->fail(GHICP_ERR_HIP, "pair loop: mapped progress counter allocation failed");
+  }
+  *(volatile int*)ctx->progress_host = 0;
+  ctx->progress_live.store(true, std::memory_order_release);
+  const bool prof = getenv("GHICP_KM_STATS") != nullptr;
+  const void* fn = prof ? reinterpret_cast<const void*>(&k_pair_loop<FT, true>) : reinterpret_cast<const void*>(&k_pair_loop<FT, false>);
+  GH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int kflags = getenv("GHICP_KM_FORCE_HAZARD") ? 4 : 0;  // test hook: sends one phase through the hazard fallback
+  GH_HIP(hipMemsetAsync(dqheads, 0, 16 * sizeof(int), s));
+  hipEvent_t kt = ctx->kt_begin(KT_PAIR_LOOP);
+  GH_HIP(hipEventRecord(ctx->aux_events[0], s));
+  for (int c = 0; c < nc; c++) {
+    if (plan.count[c] <= 0) continue;
+    hipStream_t sc = c == 0 ? s : ctx->aux_streams[(size_t)c - 1];
+    if (c > 0) GH_HIP(hipStreamWaitEvent(sc, ctx->aux_events[0], 0));
+    const size_t lds = std::max(plan.lds[c], (size_t)PL_SCRATCH + 64);
+    int per_cu = 0;
+    GH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K4_T, lds));
+    if (per_cu <= 0) return ctx->fail(GHICP_ERR_INTERNAL, "pair loop: a workgroup with %zu bytes of LDS does not fit a CU", lds);
+    const int slots = per_cu * ctx->num_cu;
+    const int grid = std::min(plan.count[c], slots);
+    unsigned long long* lstat = nullptr;
+    if (ctx->kt_on && ctx->km_launches < ghicp_ctx::KM_LSTAT_MAX) {
+      GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W, &lstat));
+      lstat += ctx->km_launches * ghicp_ctx::KM_LSTAT_W;
+      ctx->km_slots.push_back(slots);
+      ctx->km_launches++;
+    }
+    if (prof)
+      hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
+                         dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+    else
+      hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
+                         dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+    GH_HIP(hipGetLastError());
+    if (c > 0) {
+      GH_HIP(hipEventRecord(ctx->aux_events[(size_t)c + 1], sc));
+      GH_HIP(hipStreamWaitEvent(s, ctx->aux_events[(size_t)c + 1], 0));
+    }
+  }
+  ctx->kt_end(KT_PAIR_LOOP, kt);
+  GH_HIP(hipStreamSynchronize(s));
+  return GHICP_OK;
+}
+
 template <int FT>
 int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
   hipStream_t s = ctx->stream;
@@ -545,6 +726,13 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
   std::vector<LoopState> hst(nb);
   size_t total = 0;
   int max_rowsA = 1, max_chunkB = 1, max_rowsB = 1, max_chunkA = 1, max_n = 1;
+  // Kuhn-Munkres batches whose every graph fits the LDS-resident solver run as the persistent pair loop (k_pair_loop)
+  bool persistent = corr == GHICP_CORR_KM;
+  for (int b = 0; b < nb && persistent; b++) {
+    const int n = std::max(jobs[b].ks, jobs[b].kt);
+    persistent = (jobs[b].ks <= 0 || jobs[b].kt <= 0) || (gh_km4_fits(n) && gh_km2_fits(n));
+  }
+  const int chunk_batch = persistent ? (1 << 20) : nb;  // one workgroup sweeps a pair: the largest chunks (fewest partial sums)
   for (int pass = 0; pass < 2; pass++) {
     char* arena = nullptr;
     if (pass == 1) GH_TRY(ctx->reserve(B_LOOP_STATE, total + 4096, &arena));
@@ -552,6 +740,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
     const double* wfd = cv.take<double>(wtab.size());
     LoopProb* dprobs = cv.take<LoopProb>(nb);
     int* dflags = cv.take<int>((size_t)nb * 2);
+    int* dqheads = cv.take<int>(16);  // queue heads of the persistent pair loop, one per class
     Km2Problem* d_descs = cv.take<Km2Problem>(nb);  // contiguous: one k_km2 launch solves every pair's matching concurrently
     for (int b = 0; b < nb; b++) {
       const gh_loop_job& J = jobs[b];
@@ -564,8 +753,8 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       C.scale = (float)(0.005 * p->bbx_magnitude);  // ghicp_reg.h:40 (double product stored to float)
       C.est_iou = p->est_iou; C.adjust_ratio = p->adjust_ratio; C.adjust_step = p->adjust_step;
       C.converge_t = (double)p->converge_t; C.converge_r = (double)p->converge_r; C.penalty_initial = p->penalty_initial; C.km_eps = p->km_eps;
-      pick_chunks(ks, kt, nb, &C.chunk_b, &C.nchunk_b);
-      pick_chunks(kt, ks, nb, &C.chunk_a, &C.nchunk_a);
+      pick_chunks(ks, kt, chunk_batch, &C.chunk_b, &C.nchunk_b);
+      pick_chunks(kt, ks, chunk_batch, &C.chunk_a, &C.nchunk_a);
       C.nparts = cdiv(ks > 0 ? ks : 1, ROWS) * C.nchunk_b;
       max_rowsA = std::max(max_rowsA, cdiv(ks > 0 ? ks : 1, ROWS)); max_chunkB = std::max(max_chunkB, C.nchunk_b);
       max_rowsB = std::max(max_rowsB, cdiv(kt > 0 ? kt : 1, ROWS)); max_chunkA = std::max(max_chunkA, C.nchunk_a);
@@ -651,6 +840,10 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         for (int b = 0; b < nb; b++) { hn[b] = hp[b].C.n; all_sparse &= (hp[b].km_rptr != nullptr) || jobs[b].ks <= 0 || jobs[b].kt <= 0; }
         if (all_sparse) { GH_TRY(gh_km4_plan(ctx, hn.data(), nb, &km_plan)); use_plan = true; }
       }
+      if (persistent && use_plan) {
+        GH_TRY(run_pair_loop<FT>(ctx, dprobs, nb, km_plan, dqheads));
+        all_done = true;
+      }
       while (!all_done && launched < max_iter) {
         for (int r = 0; r < poll_every && launched < max_iter; r++, launched++) {
           hipEvent_t kev = ctx->kt_begin(KT_CD_ROWMIN);
@@ -685,6 +878,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         ctx->loop_active.store(still, std::memory_order_relaxed);
       }
       ctx->loop_active.store(0, std::memory_order_relaxed);
+      ctx->progress_live.store(false, std::memory_order_release);
       // ---- results
       for (int b = 0; b < nb; b++) GH_HIP(hipMemcpyAsync(&hst[b], hp[b].st, sizeof(LoopState), hipMemcpyDeviceToHost, s));
       GH_HIP(hipStreamSynchronize(s));

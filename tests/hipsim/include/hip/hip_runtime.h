@@ -205,7 +205,8 @@ struct hipsimEvent { double t_ms; };
 typedef hipsimEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-enum { hipHostMallocDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t {
   char name[256];
   int multiProcessorCount;

@@ -19,7 +19,7 @@ def _same(a, b):
             np.testing.assert_array_equal(da[key].cpu().numpy(), db[key].cpu().numpy(), err_msg=key)
 
 
-@pytest.mark.parametrize("feature,dof", [("bsc", 6), ("bsc", 4), ("none", 6)])
+@pytest.mark.parametrize("feature,dof", [("bsc", 6), ("bsc", 4), ("none", 6), ("fpfh", 6)])
 def test_batch_equals_cloud_by_cloud(ctx, api, synth, feature, dof):
     check_batch_equals_cloud_by_cloud(ctx, api, synth, feature, dof)
 
@@ -103,3 +103,24 @@ def test_batch_edge_cases(ctx, api, synth):
     c2 = ctx.cloud_create(other, p.source[:300])
     with pytest.raises(api.GhicpError):
         ctx.clouds_recompute([batch[0], c2], [one, one])  # two front-end configurations
+
+
+def test_batch_large_extent_splits_instead_of_failing(ctx, api, synth):
+    """Round-2 advisor finding: the cell tables of a batch are summed into one, and clouds of large extent (tens of millions of PCA
+    cells each) used to return GHICP_ERR_CAPACITY where the cloud-by-cloud path works.  The batch now halves itself."""
+    rng = np.random.default_rng(5)
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_NN, dof=6, voxel=0.2, pattern=synth.bsc_pattern_glibc(), max_iter=40)
+    dense = synth.tls_pair(20_000, pair_id=25).source
+    raws = []
+    for i in range(6):  # 20 k scan points + a sprinkle over a 300 m cube: ~2^26 cells of 0.5 m per cloud, 6 clouds > the 2^28 budget
+        far = (rng.random((400, 3), dtype=np.float32) - 0.5) * np.float32(300.0)
+        raws.append(np.ascontiguousarray(np.concatenate([dense[i::6], far]).astype(np.float32)))
+    single = [ctx.cloud_create(cfg, dense[:300]) for _ in raws]
+    batch = [ctx.cloud_create(cfg, dense[:300]) for _ in raws]
+    for c, r in zip(single, raws):
+        c.recompute(r)
+    ctx.clouds_recompute(batch, raws)
+    for c, d in zip(single, batch):
+        _same(c, d)
+    for c in single + batch:
+        c.close()

@@ -174,3 +174,49 @@ def test_km_solver_paths_fuzz(ctx, oracle, mode):
             np.testing.assert_array_equal(ctx.km_solve(w).cpu().numpy(), oracle.km(w)[0], err_msg="%s t=%d n=%d" % (mode, t, n))
     finally:
         os.environ.pop(mode, None)
+
+
+def test_pair_loop_persistent_batch(ctx, api, synth, oracle):
+    """The persistent pair loop (loop.hip:k_pair_loop; Kuhn-Munkres batches): pairs of very different sizes in ONE batch -- several
+    LDS-occupancy classes, each its own launch and queue, more pairs than one class has slots for is not needed for the logic -- against
+    the oracle pair by pair (iterations, every iteration's transform, final 4x4), and the batch against the same pairs registered alone."""
+    rng = np.random.default_rng(21)
+    pat = synth.bsc_pattern_glibc()
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, dof=6, est_iou=0.6, voxel=0.2, pattern=pat, max_iter=25)
+    p = synth.gauss_pair(n_kp=1000)
+    bbx = float(oracle.bbx_magnitude(p.source))
+    shapes = [(600, 700), (150, 100), (40, 300), (900, 880), (64, 64), (0, 50), (300, 310), (2, 3)]
+    clouds, refs = [], []
+    for ks, kt in shapes:
+        kpS = p.source[p.kp_source[:ks]].astype(np.float64)
+        kpT = p.target[p.kp_target[:kt]].astype(np.float64)
+        fS = rng.integers(0, 256, size=(4, ks, 56), dtype=np.uint8)
+        fT = rng.integers(0, 256, size=(4, kt, 56), dtype=np.uint8)
+        m = min(ks, kt)
+        fT[0, :m] = fS[0, :m] ^ (rng.random((m, 56)) < 0.03).astype(np.uint8)  # matching keypoints: close strings
+        S = ctx.cloud_from_features(cfg, kpS, fS, bbx)
+        T = ctx.cloud_from_features(cfg, kpT, fT, bbx)
+        clouds.append((S, T))
+        if ks and kt:
+            po = oracle.default_params(oracle.BSC, oracle.KM, 6, 0.6, 1.5, bbx, max_iter=25)
+            refs.append(oracle.register(po, kpS, kpT, oracle.fd_bsc(fS, fT[0]).astype(np.float64)))
+        else:
+            refs.append(None)
+    ctx.kernel_timing(True)
+    got = ctx.register_clouds(cfg, clouds)
+    stats = ctx.pair_loop_stats()
+    ms, launches = ctx.kernel_time("pair_loop")
+    ctx.kernel_timing(False)
+    assert launches == 1 and stats["launches"] >= 2 and stats["solves"] >= sum(r["iters"] for r in refs if r), stats  # the persistent path ran
+    for (ks, kt), st, r in zip(shapes, got, refs):
+        if r is None:
+            assert st.iterations == 0
+            continue
+        assert st.iterations == r["iters"], (ks, kt)
+        assert st.converged == r["trace"][-1]["converged"]
+        np.testing.assert_allclose(np.array(st.Rt[:]).reshape(4, 4), r["Rt"], rtol=0, atol=1e-6)
+        assert st.rmse_after == pytest.approx(r["trace"][-1]["rmse_after"], rel=1e-9)
+    alone = [ctx.register_clouds(cfg, [c])[0] for c in clouds]
+    for a, b in zip(alone, got):
+        assert (a.iterations, a.converged) == (b.iterations, b.converged)
+        np.testing.assert_array_equal(np.array(a.Rt[:]), np.array(b.Rt[:]))
