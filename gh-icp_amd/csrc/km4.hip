@@ -19,21 +19,11 @@ __global__ __launch_bounds__(K4_T) void k_km4(const Km2Problem* __restrict__ pro
 
 }  // namespace
 
+// lx, ly, slack (f64) + 16 f64 of reduction scratch + 8 bitsets + SH_NUM ints + match, two stacks, listed columns and CSR offsets (u16)
+// + list lengths (u8): 44 B per row
 size_t gh_km4_lds_bytes(int n) {
   const size_t nw = (size_t)(n + 31) / 32;
-  return (size_t)n * (3 + K4_CAP) * 8 + 16 * 8 + 8 * nw * 4 + SH_NUM * 4 + ((size_t)n * (1 + K4_CAP) + 2 * ((size_t)n + 2)) * 2 + (size_t)n + 64;
-}
-
-// what a launch asks for: the arrays plus, with GHICP_KM_POOL=1, as many pool blocks (rows with 4..8 tight entries) as fit without
-// lowering the number of problems per CU.  Off by default: on the cfg2 matrices the blocks cut the DFS iterations by 10-25 % but the
-// rows they hold are no longer in S from the start, S needs 5-25 % more rounds, and the solve ends up 0-8 % SLOWER (n = 840 leaves
-// room for 43 blocks only; profiles/r02_km4_stages.txt).
-static size_t k4_launch_lds(int n) {
-  if (!getenv("GHICP_KM_POOL")) return gh_km4_lds_bytes(n);
-  const size_t base = gh_km4_lds_bytes(n), cu = 160 * 1024;
-  const size_t per_cu = std::max<size_t>(1, cu / base);
-  const size_t room = cu / per_cu - 64;
-  return std::min(room, base + (size_t)K4_MAXBLK * K4_BLK * 10 + 32);
+  return (size_t)n * 3 * 8 + 16 * 8 + 8 * nw * 4 + SH_NUM * 4 + ((size_t)n * (1 + 2 * K4_CAP) + 2 * ((size_t)n + 2)) * 2 + (size_t)n + 64;
 }
 
 bool gh_km4_fits(int n) { return n <= 65534 && gh_km4_lds_bytes(n) <= 160 * 1024 - 256; }
@@ -62,7 +52,7 @@ static int k4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, size_
 }
 
 int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max) {
-  return k4_launch(ctx, d_probs, nprob, std::max(gh_km4_lds_bytes(n_max), k4_launch_lds(n_max)), nullptr);
+  return k4_launch(ctx, d_probs, nprob, gh_km4_lds_bytes(n_max), nullptr);
 }
 
 int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan) {
@@ -86,7 +76,7 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan) {
     if (nc == 8) { plan->count[7] += nprob - i; break; }  // cannot happen: at most 8 occupancy classes
     plan->begin[nc] = i; plan->count[nc] = j - i;
     const int nmax = key[order[i]].second;
-    plan->lds[nc] = std::max(gh_km4_lds_bytes(nmax), k4_launch_lds(nmax));
+    plan->lds[nc] = gh_km4_lds_bytes(nmax);
     nc++;
     i = j;
   }

@@ -1,12 +1,16 @@
 // Kuhn-Munkres, fourth-generation kernel (gfx950): the reference's result (src/km.cpp:13-126) WITHOUT stepping through the
 // reference's depth-first search wherever its outcome is order independent.  One 256-thread workgroup per problem, all
-// solver state in LDS (61.75 B per row), the CSR of the explicit entries streamed from global memory only by the bulk
-// passes of failed phases.  Rules (oracle/km4_model.inc states them sequentially and is fuzzed against the reference
-// traversal; R1 = E1-E3 of km2.hip):
-//   R2  per row a list of <= 3 (column, weight) pairs in LDS, ascending column, a SUPERSET of the row's tight explicit entries;
-//       members are re-tested with fl(fl(lx+ly) - w) < eps at every use.  An explicit entry can only become tight when its
-//       row label drops, i.e. for rows visited by a failed phase: those lists are rebuilt after the relabelling.  Rows with
-//       more than 3 tight entries are flagged (scanned from the CSR row, never pruned).
+// solver state in LDS (44 B per row: 4 problems per CU up to n = 930), the CSR of the explicit entries streamed from global
+// memory only by the bulk passes of failed phases.  Rules (oracle/km4_model.inc states them sequentially and is fuzzed against
+// the reference traversal; R1 = E1-E3 of km2.hip):
+//   R2  per row a list of <= 3 columns in LDS, ascending, EXACTLY the row's tight explicit entries (fl(fl(lx+ly) - w) < eps), plus
+//       each entry's offset in its CSR row.  An explicit entry can only BECOME tight when its row label drops, i.e. for rows visited
+//       by a failed phase: those lists are rebuilt after the relabelling.  It can only STOP being tight when its column label rises,
+//       i.e. for columns visited by a failed phase: rows that were not visited but list such a column re-test their entries (one
+//       value load through the stored offset) right after the relabelling.  So a listed entry needs no value and no test at use:
+//       the flood, the DFS and the S rounds read columns only.  (Round 2 kept (column, weight) pairs as a superset and re-tested at
+//       every use: 61.75 B per row, three problems per CU.)  Rows with more than 3 tight entries are flagged (scanned from the CSR
+//       row with the test, never pruned).
 //   R3  every phase starts with an order-free flood from the root (wave 0; lists + one sweep of
 //       T_L = {y : fl(fl(L+ly[y]) - bg) < eps} for the smallest label met -- T_L is nested in L).  No free column reached:
 //       the phase FAILS and the visited sets are the reference's (a failed findpath() visits exactly the reachable set).
@@ -35,9 +39,7 @@ namespace {
 
 
 constexpr int K4_CAP = 3;
-constexpr int K4_OVER = 255;  // tln: 0..3 = entries in the row's own slots; 4 + blk*5 + (cnt-4) = cnt in 4..8, entries 3.. in pool block blk; 255 = flagged
-constexpr int K4_BLK = 5;     // entries per pool block
-constexpr int K4_MAXBLK = 48;
+constexpr int K4_OVER = 255;  // tln: 0..3 = listed entries; 255 = flagged (more than 3 tight entries when the list was built)
 constexpr int K4_T = 256;
 constexpr int K4_NONE = 0xFFFF;
 constexpr double K4_INF = 1000.0;  // km.cpp:42
@@ -49,12 +51,10 @@ typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
 enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NUM = 16 };
 
 struct K4 {
-  double *lx, *ly, *slack, *tlv, *red, *pval;
+  double *lx, *ly, *slack, *red;
   unsigned *visx, *visy, *prevy, *pushed, *good, *goody, *freey, *ovf;
   int* sh;
-  unsigned short *match, *stx, *sty, *tlc, *pcol;
-  unsigned* fb;  // free pool blocks (2 words)
-  int nblk;
+  unsigned short *match, *stx, *sty, *tlc, *tlo;  // tlc / tlo: listed columns and their offsets in the CSR row (K4_CAP per row)
   unsigned char* tln;
   int n, nw;
   double bg, eps;
@@ -64,21 +64,7 @@ struct K4 {
 };
 
 __device__ inline bool k4_bit(const unsigned* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
-__device__ inline int k4_cnt(int tn) { return tn < 4 ? tn : (tn == K4_OVER ? 0 : 4 + (tn - 4) % K4_BLK); }  // listed entries (0 for flagged rows)
-__device__ inline int k4_blk(int tn) { return (tn >= 4 && tn != K4_OVER) ? (tn - 4) / K4_BLK : -1; }
-
-// pool blocks: lock-free bitmap allocator (bit set = free)
-__device__ inline int k4_blk_alloc(const K4& s) {
-  for (int w = 0; w < 2; w++)
-    for (;;) {
-      const unsigned m = *(volatile unsigned*)&s.fb[w];
-      if (!m) break;
-      const int b = __ffs((int)m) - 1;
-      if (atomicAnd(&s.fb[w], ~(1u << b)) & (1u << b)) return w * 32 + b;
-    }
-  return -1;
-}
-__device__ inline void k4_blk_free(const K4& s, int b) { atomicOr(&s.fb[b >> 5], 1u << (b & 31)); }
+__device__ inline int k4_cnt(int tn) { return tn == K4_OVER ? 0 : tn; }  // listed entries (0 for flagged rows)
 
 // Bulk pass over rows list[0..count), all 4 waves: REBUILD writes the rows' lists (R2), PUSH sends the slack minima of their
 // non-tight entries (R4), ONLY_UNPUSHED skips rows whose minima are already in slack.  16 lanes per row, so a wave instruction works
@@ -98,8 +84,7 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
     unsigned cb = 0, ce = 0;
     double lxr = 0.0;
     if (x >= 0) { cb = s.rptr[x]; ce = s.rptr[x + 1]; lxr = s.lx[x]; }
-    int cnt = 0, blk = -1;
-    if (REBUILD && x >= 0) blk = k4_blk(s.tln[x]);  // a row that had a pool block keeps it for its new list
+    int cnt = 0;
     for (unsigned off = 0; __ballot(cb + off < ce); off += 64) {
       int col[4];
       double val[4];
@@ -121,28 +106,16 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
         if (PUSH && in && !td) atomicMin(&sl[col[j]], (unsigned long long)__double_as_longlong(d));
         if (REBUILD) {
           const unsigned gb = (unsigned)(__ballot(in && td) >> (grp * 16)) & 0xffffu;
-          const int after = cnt + __popc(gb);
-          if (after > K4_CAP && blk == -1) {  // first entry beyond the row's own slots: take a pool block (asked for once per row)
-            int b = -2;
-            if (lig == 0) b = k4_blk_alloc(s);
-            blk = __shfl(b, grp * 16, 64);
-            if (blk < 0) blk = -2;  // none free: the row ends up flagged
-          }
           if (in && td) {
             const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
-            if (rk < K4_CAP) { s.tlc[x * K4_CAP + rk] = (unsigned short)col[j]; s.tlv[x * K4_CAP + rk] = val[j]; }
-            else if (rk < K4_CAP + K4_BLK && blk >= 0) { s.pcol[blk * K4_BLK + rk - K4_CAP] = (unsigned short)col[j]; s.pval[blk * K4_BLK + rk - K4_CAP] = val[j]; }
+            if (rk < K4_CAP) { s.tlc[x * K4_CAP + rk] = (unsigned short)col[j]; s.tlo[x * K4_CAP + rk] = (unsigned short)(c[j] - cb); }
           }
-          cnt = after;
+          cnt += __popc(gb);
         }
       }
     }
     if (REBUILD && lig == 0 && x >= 0) {
-      int tn = cnt;
-      if (cnt > K4_CAP) {
-        if (cnt <= K4_CAP + K4_BLK && blk >= 0) tn = 4 + blk * K4_BLK + (cnt - 4);
-        else { tn = K4_OVER; if (blk >= 0) k4_blk_free(s, blk); }
-      } else if (blk >= 0) k4_blk_free(s, blk);
+      const int tn = cnt > K4_CAP ? K4_OVER : cnt;
       const bool over = tn == K4_OVER, was = s.tln[x] == K4_OVER;
       s.tln[x] = (unsigned char)tn;
       if (over != was) {
@@ -150,6 +123,30 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
         else atomicAnd(&s.ovf[x >> 5], ~(1u << (x & 31)));
       }
     }
+  }
+}
+
+// R2, second half: after the relabelling of a failed phase the labels of the VISITED columns have risen, so a listed entry of a row
+// that was NOT visited may have left the tight set.  Such rows re-test their entries (value through the stored CSR offset) and
+// compact their list; visited rows are rebuilt from their CSR row by the bulk pass.  Few rows qualify (the visited sets are small),
+// so the pass is an LDS sweep plus, rarely, one round of value loads.
+__device__ inline void k4_revalidate(const K4& s, int tid) {
+  for (int i = tid; i < s.n; i += K4_T) {
+    const int tn = s.tln[i];
+    if (tn == 0 || tn == K4_OVER || k4_bit(s.visx, i)) continue;
+    bool hit = false;
+    for (int e = 0; e < tn; e++) hit |= k4_bit(s.visy, s.tlc[i * K4_CAP + e]);
+    if (!hit) continue;
+    const double lxv = s.lx[i];
+    const unsigned rb = s.rptr[i];
+    int keep = 0;
+    for (int e = 0; e < tn; e++) {
+      const int col = s.tlc[i * K4_CAP + e];
+      const unsigned short o = s.tlo[i * K4_CAP + e];
+      const double w = s.vals[rb + o];
+      if (((lxv + s.ly[col]) - w) < s.eps) { s.tlc[i * K4_CAP + keep] = (unsigned short)col; s.tlo[i * K4_CAP + keep] = o; keep++; }
+    }
+    s.tln[i] = (unsigned char)keep;
   }
 }
 
@@ -199,29 +196,16 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
       const double lxr = s.lx[xr];
       const int tn = s.tln[xr];
       int lc[K4_CAP], mc[K4_CAP];
-      double lv[K4_CAP], lyc[K4_CAP];
       unsigned vw[K4_CAP];
 #pragma unroll
-      for (int k = 0; k < K4_CAP; k++) { lc[k] = s.tlc[xr * K4_CAP + k]; lv[k] = s.tlv[xr * K4_CAP + k]; }
+      for (int k = 0; k < K4_CAP; k++) lc[k] = s.tlc[xr * K4_CAP + k];
 #pragma unroll
-      for (int k = 0; k < K4_CAP; k++) { lyc[k] = s.ly[lc[k]]; vw[k] = s.visy[lc[k] >> 5]; mc[k] = s.match[lc[k]]; }
-      const int cntv = act ? k4_cnt(tn) : 0, blkv = k4_blk(tn);
-      const int t = min(cntv, K4_CAP);
+      for (int k = 0; k < K4_CAP; k++) { vw[k] = s.visy[lc[k] >> 5]; mc[k] = s.match[lc[k]]; }
+      const int t = act ? k4_cnt(tn) : 0;
 #pragma unroll
-      for (int k = 0; k < K4_CAP; k++) {
-        const bool want = (int)(k < t) & (int)(((lxr + lyc[k]) - lv[k]) < s.eps) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
+      for (int k = 0; k < K4_CAP; k++) {  // listed entries are tight (R2): unvisited is all that is asked
+        const bool want = (int)(k < t) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
         K4_CLAIM(want, lc[k], mc[k]);
-      }
-      for (int e = K4_CAP; __ballot(e < cntv); e++) {  // entries in pool blocks
-        const int pi = blkv * K4_BLK + e - K4_CAP;
-        int col = 0, m = K4_NONE;
-        bool want = false;
-        if (e < cntv) {
-          col = s.pcol[pi];
-          m = s.match[col];
-          want = (int)(((lxr + s.ly[col]) - s.pval[pi]) < s.eps) & (int)!k4_bit(s.visy, col);
-        }
-        K4_CLAIM(want, col, m);
       }
       if (act && (lxr - s.bg) < s.eps) lcand = fmin(lcand, lxr);
       unsigned long long ob = __ballot(act && tn == K4_OVER);
@@ -279,8 +263,8 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
 
 // ---- R5: the reference's DFS restricted to S (wave 0).  Returns false only on an internal error.
 // One iteration == one findpath() activation or resumption (km.cpp:13-37) and costs two dependent LDS round trips: (1) the
-// row record (label, list), (2) everything the verdict needs -- for the <= 3 listed entries and for a 64-column window of
-// background candidates at the E7 pointer of the row's label: ly, the visited / S words and the owner of every candidate.
+// row record (label, listed columns), (2) everything the verdict needs -- the visited / S words and the owner of the <= 3 listed
+// columns, and for a 64-column window of background candidates at the E7 pointer of the row's label: ly, visited / S words, owner.
 template <bool PROF>
 __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter, long long* q_act) {
   const int n = s.n;
@@ -296,13 +280,8 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
     // ---- round trip 1: the row record
     const double lxv = s.lx[x];
     const int tn = s.tln[x];
-    int lc = s.tlc[x * K4_CAP + lk];
-    double lv = s.tlv[x * K4_CAP + lk];
+    const int lc = s.tlc[x * K4_CAP + lk];
     const int ncnt = k4_cnt(tn);
-    if (ncnt > K4_CAP && lane >= K4_CAP) {  // entries 3.. of a row with a pool block
-      const int pi = k4_blk(tn) * K4_BLK + min(lane, K4_CAP + K4_BLK - 1) - K4_CAP;
-      lc = s.pcol[pi]; lv = s.pval[pi];
-    }
     const bool bgt = (lxv - bg) < eps;
     int slot = 0, p = n;
     if (bgt) {  // E7: one scan pointer per distinct label value; everything below ystart is dead for this label as well
@@ -318,7 +297,6 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
       }
     }
     // ---- round trip 2: listed entries and the first window, issued together
-    const double lyL = s.ly[lc];
     const unsigned vwL = s.visy[lc >> 5], gwL = s.goody[lc >> 5];
     const int mL = s.match[lc];
     int yw = p + lane, ywc = min(yw, n - 1);
@@ -337,7 +315,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
         if (b) { best = __builtin_amdgcn_readlane(col, (int)__ffsll((long long)b) - 1); mbest = s.match[best]; break; }
       }
     } else {
-      const bool t = (int)(lane < ncnt) & (int)(((lxv + lyL) - lv) < eps) & (int)(lc >= ystart) & (int)((((~vwL & gwL) >> (lc & 31)) & 1u) != 0u);
+      const bool t = (int)(lane < ncnt) & (int)(lc >= ystart) & (int)((((~vwL & gwL) >> (lc & 31)) & 1u) != 0u);  // listed = tight (R2)
       const unsigned long long b = __ballot(t);
       if (b) {
         const int l = (int)__ffsll((long long)b) - 1;
@@ -515,8 +493,7 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
   s.lx = (double*)smem;
   s.ly = s.lx + n;
   s.slack = s.ly + n;
-  s.tlv = s.slack + n;
-  s.red = s.tlv + (size_t)n * K4_CAP;  // 16 doubles
+  s.red = s.slack + n;  // 16 doubles
   s.visx = (unsigned*)(s.red + 16);
   s.visy = s.visx + nw; s.prevy = s.visy + nw; s.pushed = s.prevy + nw; s.good = s.pushed + nw; s.goody = s.good + nw;
   s.freey = s.goody + nw; s.ovf = s.freey + nw;
@@ -525,17 +502,9 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
   s.stx = s.match + n;
   s.sty = s.stx + n + 2;
   s.tlc = s.sty + n + 2;
-  s.tln = (unsigned char*)(s.tlc + (size_t)n * K4_CAP);
-  // pool blocks in whatever the launch's LDS allocation leaves beyond this problem's arrays
-  {
-    char* pend = (char*)(s.tln + n);
-    pend += (8 - ((size_t)pend & 7)) & 7;
-    const long long spare = (long long)lds_bytes - (long long)(pend - smem) - 16;
-    s.nblk = (int)max(0ll, min((long long)K4_MAXBLK, spare / (K4_BLK * 10)));
-    s.pval = (double*)pend;
-    s.pcol = (unsigned short*)(s.pval + (size_t)s.nblk * K4_BLK);
-    s.fb = (unsigned*)(s.pcol + (size_t)s.nblk * K4_BLK + (((size_t)s.nblk * K4_BLK) & 1));
-  }
+  s.tlo = s.tlc + (size_t)n * K4_CAP;
+  s.tln = (unsigned char*)(s.tlo + (size_t)n * K4_CAP);
+  (void)lds_bytes;
   const double bg = s.bg, eps = s.eps;
 
   long long c_flood = 0, c_fail = 0, c_pull = 0, c_dfs = 0, q_phase = 0, q_fail = 0, q_rounds = 0, q_iter = 0, q_act = 0, q_frows = 0, q_prows = 0;
@@ -543,14 +512,13 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
   const long long t_begin = PROF ? (long long)__builtin_readcyclecounter() : 0;
 
   for (int i = tid; i < n; i += K4_T) { s.lx[i] = P.lx_init[i]; s.ly[i] = 0.0; s.match[i] = (unsigned short)K4_NONE; s.tln[i] = 0; }
-  for (int i = tid; i < n * K4_CAP; i += K4_T) { s.tlc[i] = 0; s.tlv[i] = 0.0; }  // list slots are read unconditionally: keep them valid
+  for (int i = tid; i < n * K4_CAP; i += K4_T) { s.tlc[i] = 0; s.tlo[i] = 0; }  // list slots are read unconditionally: keep them valid
   for (int w = tid; w < nw; w += K4_T) {
     unsigned all = ~0u;
     if (w == nw - 1 && (n & 31)) all = (1u << (n & 31)) - 1u;
     s.freey[w] = all; s.ovf[w] = 0u;
   }
   if (tid < SH_NUM) s.sh[tid] = 0;
-  if (tid < 2) s.fb[tid] = s.nblk >= 32 * (tid + 1) ? ~0u : (s.nblk > 32 * tid ? (1u << (s.nblk - 32 * tid)) - 1u : 0u);
   __syncthreads();
   // initial lists: every row once (R2); stx doubles as the list of all rows
   for (int i = tid; i < n; i += K4_T) s.stx[i] = (unsigned short)i;
@@ -612,7 +580,9 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         }
         for (int w = tid; w < nw; w += K4_T) s.pushed[w] = s.visx[w];
         __syncthreads();
-        k4_bulk<true, true, false>(s, s.stx, qt, wave, lane);  // lists under the new labels + the minima of the next phase
+        k4_revalidate(s, tid);                                  // rows that were not visited: entries in visited columns may have left
+        __syncthreads();                                        // (it reads the visited sets, which the next phase clears)
+        k4_bulk<true, true, false>(s, s.stx, qt, wave, lane);  // visited rows: lists under the new labels + the minima of the next phase
         have_prev = true;
         if (PROF) { q_prows += qt; c_fail += (long long)__builtin_readcyclecounter() - t1; }
         if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
@@ -655,36 +625,27 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         for (int base = tid; base < n; base += 4 * K4_T) {  // rows: background-tight to the best column of S, or a listed entry in S
           int xx[4], tn[4], lc[4][K4_CAP];
           unsigned gdw[4];
-          double lxv[4], lv[4][K4_CAP];
+          double lxv[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             xx[k] = base + k * K4_T;
             const int xc = min(xx[k], n - 1);
             gdw[k] = s.good[xc >> 5]; lxv[k] = s.lx[xc]; tn[k] = s.tln[xc];
 #pragma unroll
-            for (int e = 0; e < K4_CAP; e++) { lc[k][e] = s.tlc[xc * K4_CAP + e]; lv[k][e] = s.tlv[xc * K4_CAP + e]; }
+            for (int e = 0; e < K4_CAP; e++) lc[k][e] = s.tlc[xc * K4_CAP + e];
           }
-          double lyc[4][K4_CAP];
           unsigned gyw[4][K4_CAP];
 #pragma unroll
           for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int e = 0; e < K4_CAP; e++) { lyc[k][e] = s.ly[lc[k][e]]; gyw[k][e] = s.goody[lc[k][e] >> 5]; }
+            for (int e = 0; e < K4_CAP; e++) gyw[k][e] = s.goody[lc[k][e] >> 5];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             if (xx[k] >= n || ((gdw[k] >> (xx[k] & 31)) & 1u)) continue;
             bool g = (int)((lxv[k] - bg) < eps) & (int)(((lxv[k] + gmin) - bg) < eps);
-            const int cn = k4_cnt(tn[k]), t = min(cn, K4_CAP);
+            const int t = k4_cnt(tn[k]);
 #pragma unroll
-            for (int e = 0; e < K4_CAP; e++)
-              g |= (int)(e < t) & (int)(((lxv[k] + lyc[k][e]) - lv[k][e]) < eps) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);
-            if (!g && cn > K4_CAP) {
-              const int pb = k4_blk(tn[k]) * K4_BLK - K4_CAP;
-              for (int e = K4_CAP; e < cn; e++) {
-                const int col = s.pcol[pb + e];
-                g |= (int)(((lxv[k] + s.ly[col]) - s.pval[pb + e]) < eps) & (int)k4_bit(s.goody, col);
-              }
-            }
+            for (int e = 0; e < K4_CAP; e++) g |= (int)(e < t) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);  // listed = tight (R2)
             if (g) { atomicOr(&s.good[xx[k] >> 5], 1u << (xx[k] & 31)); ch = true; }
           }
         }

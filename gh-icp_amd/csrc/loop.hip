@@ -579,21 +579,21 @@ __device__ __noinline__ void pl_solve(const LoopProb& P, double* red, int* ired,
 }
 
 template <int FT, bool PROF>
-__global__ __launch_bounds__(K4_T, 3) void k_pair_loop(const LoopProb* __restrict__ probs, const int* __restrict__ order, const int npairs, int* qhead,
+__global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restrict__ probs, const int* __restrict__ order, const int npairs, int* qhead,
                                                   const int km_flags, const int lds_bytes, unsigned long long* lstat, int* progress) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_idx;
   double* sB = reinterpret_cast<double*>(smem);
   double* red = sB + CHUNK_MAX * 3;
   double* sh = red + 16;
   int* ired = reinterpret_cast<int*>(sh + 32);
+  volatile int* s_idx = ired + 18;  // (no static LDS in this kernel: the launch may ask for all 160 KB as dynamic LDS)
   const unsigned long long t_slot0 = lstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned long long t_solve = 0ull, t_solve_max = 0ull, n_solve = 0ull;
   for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) s_idx = atomicAdd(qhead, 1);
+    if (threadIdx.x == 0) *s_idx = atomicAdd(qhead, 1);
     __syncthreads();
-    const int q = s_idx;
+    const int q = *s_idx;
     if (q >= npairs) break;
     const LoopProb& P = probs[order[q]];
     while (*(volatile int*)&P.st->done == 0) {

@@ -155,10 +155,10 @@ def test_rigid_svd(ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["default", "GHICP_KM_V2", "GHICP_KM_POOL", "GHICP_KM_FORCE_HAZARD"])
+@pytest.mark.parametrize("mode", ["default", "GHICP_KM_V2", "GHICP_KM_FORCE_HAZARD"])
 def test_km_solver_paths_fuzz(ctx, oracle, mode):
     """Every Kuhn-Munkres path of the library on the fuzz generators of scripts/km4_model_fuzz.py (ties, dense rows, empty rows,
-    ulp-perturbed lattices): the flood-first kernel (default), the DFS emulation it replaced (GHICP_KM_V2), the pool-block variant
+    ulp-perturbed lattices): the flood-first kernel (default), the DFS emulation it replaced (GHICP_KM_V2)
     and the literal fallback behind the slack-hazard check -- all bit-exact against the restatement of km.cpp:13-126."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
