@@ -61,7 +61,16 @@ def make_pair(config_id, pair_id, hits):
 
 
 def _gen_worker(a):
-    p = make_pair(*a)
+    cache = a[3] if len(a) > 3 else None
+    f = os.path.join(cache, "scene_c%d_p%d_h%d.npz" % a[:3]) if cache else None
+    if f and os.path.exists(f):  # sweeps of several bench runs in one session: the (untimed) generation is paid once
+        z = np.load(f)
+        return z["s"], z["t"], z["gt"]
+    p = make_pair(*a[:3])
+    if f:
+        os.makedirs(cache, exist_ok=True)
+        np.savez(f + ".tmp.npz", s=p.source, t=p.target, gt=p.gt)
+        os.replace(f + ".tmp.npz", f)
     return p.source, p.target, p.gt
 
 
@@ -178,6 +187,9 @@ def main():
     ap.add_argument("--fe-batch-size", type=int, default=32, help="clouds per launch sequence when --fe-batch -1 picks the batched front end")
     ap.add_argument("--fe-batch-streams", type=int, default=4, help="worker contexts of the batched front end")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = every logical CPU of the host; the distinct scenes are cycled)")
+    ap.add_argument("--fe-cus", type=int, default=0, help="compute units reserved for the front-end streams (hipExtStreamCreateWithCUMask; the mask bits "
+                    "interleave over the 8 XCDs, so F bits = F/8 CUs per XCD); the loop contexts get the other CUs.  0 = no partition")
+    ap.add_argument("--scene-cache", default="", help="directory that keeps the generated synthetic scenes between runs (the generation is untimed)")
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"], help="pair queue across ranks: static p mod R, or chunks claimed from a shared counter")
     ap.add_argument("--detail-dir", default=os.path.join(ROOT, "gpurun_out"), help="where the per-scene / per-kernel side file goes")
     args = ap.parse_args()
@@ -206,9 +218,9 @@ def main():
     nproc = max(1, min(len(my_scenes), (os.cpu_count() or 8) // max(1, world), 32))
     if nproc > 1:
         with mp.get_context("fork").Pool(nproc) as pool:
-            gen = pool.map(_gen_worker, [(args.config, sid, hits) for sid in my_scenes])
+            gen = pool.map(_gen_worker, [(args.config, sid, hits, args.scene_cache) for sid in my_scenes])
     else:
-        gen = [_gen_worker((args.config, sid, hits)) for sid in my_scenes]
+        gen = [_gen_worker((args.config, sid, hits, args.scene_cache)) for sid in my_scenes]
     scene = {sid: g for sid, g in zip(my_scenes, gen)}
     gen_s = time.time() - t0
 
@@ -238,6 +250,20 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(nstream + G * LP)]
     ctxs = [api.Context(local_rank, stream=s) for s in streams]
     fe_ctxs, loop_ctxs = ctxs[:nstream], ctxs[nstream:]
+    if args.fe_cus > 0:  # hard partition of the chip: the solve slots of the persistent pair loop fill every CU they may use (LDS and VGPRs),
+        # so front-end kernels only run beside them on CUs of their own
+        try:
+            ncu = int(torch.cuda.get_device_properties(local_rank).multi_processor_count)
+        except Exception:  # noqa: BLE001
+            ncu = 256
+        F = max(8, min(ncu - 8, args.fe_cus))
+        bits_loop = (1 << (ncu - F)) - 1
+        bits_fe = ((1 << ncu) - 1) ^ bits_loop
+        words = lambda b: [(b >> (32 * i)) & 0xFFFFFFFF for i in range((ncu + 31) // 32)]
+        for c in fe_ctxs:
+            c.set_cu_mask(words(bits_fe))
+        for c in loop_ctxs:
+            c.set_cu_mask(words(bits_loop))
     # ---- which front end: cloud by cloud on `nstream` streams, or ghicp_clouds_recompute batches on a few.  Both give the same bits
     # (tests/test_gpu_batch.py); the choice is a throughput calibration on a sample of this rank's pairs, before the warm-up.
     def fe_sample_rate(batch, nthreads, sample):
@@ -682,7 +708,7 @@ def main():
         "ms_per_iteration": round(ms_iter_single, 4), "ms_per_iteration_in_batch": round(ms_per_step / max(1.0, it_mean), 2),
         "single_pair_latency_s": round(single_latency, 4),
         "batch_ms": {"front_end_thread_s_per_step": round(thread_busy["front_end"] / max(1, args.steps), 2), "front_end_threads": fe_n,
-                     "loop_thread_s_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G, "pipeline": args.pipeline,
+                     "loop_thread_s_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G, "pipeline": args.pipeline, "fe_cus": args.fe_cus,
                      "front_end_ms_per_cloud_on_its_stream": round(1e3 * thread_busy["front_end"] / max(1, args.steps) / max(1, 2 * nb), 4)},
         "km_launch_stats": km_stats, "pair_loop_stats": pl_stats,
         "rank_wall_s": {"per_rank": [round(b, 3) for b in busy_all], "imbalance_max_over_mean": round(max(busy_all) / max(1e-9, float(np.mean(busy_all))), 4)},

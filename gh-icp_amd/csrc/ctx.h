@@ -144,6 +144,7 @@ struct ghicp_ctx {
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;  // created by ghicp_ctx_set_cu_mask
   // persistent pair loop: one launch per LDS-occupancy class, concurrently, on these streams (forked from / joined into `stream`)
+  std::vector<uint32_t> cu_mask;       // set by ghicp_ctx_set_cu_mask: the auxiliary streams are restricted to the same compute units
   std::vector<hipStream_t> aux_streams;
   std::vector<hipEvent_t> aux_events;  // [0] fork, [1 + c] join of class c
   int* progress_host = nullptr;        // mapped pinned counter: pairs completed by the running persistent loop

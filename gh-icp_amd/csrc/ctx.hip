@@ -82,6 +82,9 @@ extern "C" int ghicp_ctx_set_cu_mask(ghicp_ctx* ctx, const uint32_t* mask, int32
   if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
   ctx->own_stream = s;
   ctx->stream = s;
+  ctx->cu_mask.assign(mask, mask + n_words);
+  for (hipStream_t a : ctx->aux_streams) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }  // they carry the previous mask
+  ctx->aux_streams.clear();
   return GHICP_OK;
 }
 

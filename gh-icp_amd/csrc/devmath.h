@@ -111,6 +111,38 @@ __host__ __device__ inline void gh_kabsch(const double A[9], double R[9]) {
     for (int j = 0; j < 3; j++) R[i * 3 + j] = u[0][i] * v[0][j] + u[1][i] * v[1][j] + sgn * u[2][i] * v[2][j];
 }
 
+// ---- N7: atan2f of the SPFH angle feature (pcl::computePairFeatures: f1 = atan2f(w . n2, u . n2)).  glibc's atan2f and the device
+// library's differ by an ulp on some inputs, and an ulp moves a pair feature across a histogram bin edge.  Both sides of the parity
+// test therefore evaluate THIS function (the oracle holds its own transcription): atan2 in f64 from +, -, *, / only -- octant
+// reduction, t' = (t - 1) / (t + 1) above tan(pi / 8), 19-term odd series in Horner form, |t'| <= 0.4143 -> truncation < 1e-16 --
+// rounded once to f32.  Against a correctly rounded atan2f it differs by at most one f32 ulp, on ~1e-5 of the inputs
+// (tests/test_oracle_cpu.py); IEEE special cases (signed zeros, infinities, NaN) follow C99 F.9.1.4.
+__host__ __device__ inline float gh_atan2f(float yf, float xf) {
+  if (yf != yf || xf != xf) return yf + xf;
+  const double PI = 3.14159265358979323846, PI_2 = 1.57079632679489661923, PI_4 = 0.78539816339744830962;
+  const double y = (double)yf, x = (double)xf;
+  const double ay = fabs(y), ax = fabs(x);
+  double r;
+  if (ay == 0.0 && ax == 0.0) {
+    r = 0.0;
+  } else if (ax == INFINITY && ay == INFINITY) {
+    r = PI_4;
+  } else {
+    const double hi = ax > ay ? ax : ay, lo = ax > ay ? ay : ax;
+    double t = hi == INFINITY ? 0.0 : lo / hi, base = 0.0;
+    if (t > 0.41421356237309503) { t = (t - 1.0) / (t + 1.0); base = PI_4; }
+    const double z = t * t;
+    double p = 1.0 / 37.0;
+#pragma unroll
+    for (int k = 35; k >= 3; k -= 2) p = 1.0 / (double)k - z * p;
+    r = base + (t - t * z * p);
+    if (ay > ax) r = PI_2 - r;
+  }
+  if (xf < 0.0f || (xf == 0.0f && copysignf(1.0f, xf) < 0.0f)) r = PI - r;
+  const float rf = (float)r;
+  return copysignf(1.0f, yf) < 0.0f ? -rf : rf;
+}
+
 // ---- reductions (fixed tree order => run-to-run deterministic)
 __device__ inline double gh_wave_sum(double x) {
 #pragma unroll

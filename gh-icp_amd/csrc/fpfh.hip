@@ -203,7 +203,7 @@ __global__ __launch_bounds__(128) void k_spfh(const float* __restrict__ xyz, int
     for (int d = 0; d < 3; d++) vv[d] *= iv;
     const float ww[3] = {a1[1] * vv[2] - a1[2] * vv[1], a1[2] * vv[0] - a1[0] * vv[2], a1[0] * vv[1] - a1[1] * vv[0]};
     const float f2 = dot3f(vv, a2);
-    const float f1 = atan2f(dot3f(ww, a2), dot3f(a1, a2));
+    const float f1 = gh_atan2f(dot3f(ww, a2), dot3f(a1, a2));  // N7: the contract's atan2f, not the device library's
     int h1 = (int)floor(11 * (((double)f1 + M_PI) * (1.0 / (2.0 * M_PI))));
     int h2 = (int)floor(11 * (((double)f2 + 1.0) * 0.5));
     int h3 = (int)floor(11 * (((double)f3 + 1.0) * 0.5));

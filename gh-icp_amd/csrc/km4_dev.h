@@ -131,22 +131,42 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
 // compact their list; visited rows are rebuilt from their CSR row by the bulk pass.  Few rows qualify (the visited sets are small),
 // so the pass is an LDS sweep plus, rarely, one round of value loads.
 __device__ inline void k4_revalidate(const K4& s, int tid) {
-  for (int i = tid; i < s.n; i += K4_T) {
-    const int tn = s.tln[i];
-    if (tn == 0 || tn == K4_OVER || k4_bit(s.visx, i)) continue;
-    bool hit = false;
-    for (int e = 0; e < tn; e++) hit |= k4_bit(s.visy, s.tlc[i * K4_CAP + e]);
-    if (!hit) continue;
-    const double lxv = s.lx[i];
-    const unsigned rb = s.rptr[i];
-    int keep = 0;
-    for (int e = 0; e < tn; e++) {
-      const int col = s.tlc[i * K4_CAP + e];
-      const unsigned short o = s.tlo[i * K4_CAP + e];
-      const double w = s.vals[rb + o];
-      if (((lxv + s.ly[col]) - w) < s.eps) { s.tlc[i * K4_CAP + keep] = (unsigned short)col; s.tlo[i * K4_CAP + keep] = o; keep++; }
+  // visited rows / columns of the failed phase through their copies `pushed` / `prevy`: the next phase clears visx / visy, the copies
+  // stay until the next failed phase, so this pass needs no barrier of its own (the one that opens the next phase orders its writes)
+  for (int base = tid; base < s.n; base += 4 * K4_T) {
+    int tn[4], lc[4][K4_CAP];
+    unsigned px[4], pv[4][K4_CAP];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // every load of the common case issued before the first use
+      const int ic = min(base + k * K4_T, s.n - 1);
+      tn[k] = s.tln[ic];
+      px[k] = s.pushed[ic >> 5];
+#pragma unroll
+      for (int e = 0; e < K4_CAP; e++) lc[k][e] = s.tlc[ic * K4_CAP + e];
     }
-    s.tln[i] = (unsigned char)keep;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int e = 0; e < K4_CAP; e++) pv[k][e] = s.prevy[lc[k][e] >> 5];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = base + k * K4_T;
+      if (i >= s.n || tn[k] == 0 || tn[k] == K4_OVER || ((px[k] >> (i & 31)) & 1u)) continue;
+      bool hit = false;
+#pragma unroll
+      for (int e = 0; e < K4_CAP; e++) hit |= (int)(e < tn[k]) & (int)((pv[k][e] >> (lc[k][e] & 31)) & 1u);
+      if (!hit) continue;
+      const double lxv = s.lx[i];
+      const unsigned rb = s.rptr[i];
+      int keep = 0;
+      for (int e = 0; e < tn[k]; e++) {
+        const int col = s.tlc[i * K4_CAP + e];
+        const unsigned short o = s.tlo[i * K4_CAP + e];
+        const double w = s.vals[rb + o];
+        if (((lxv + s.ly[col]) - w) < s.eps) { s.tlc[i * K4_CAP + keep] = (unsigned short)col; s.tlo[i * K4_CAP + keep] = o; keep++; }
+      }
+      s.tln[i] = (unsigned char)keep;
+    }
   }
 }
 
@@ -581,7 +601,6 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         for (int w = tid; w < nw; w += K4_T) s.pushed[w] = s.visx[w];
         __syncthreads();
         k4_revalidate(s, tid);                                  // rows that were not visited: entries in visited columns may have left
-        __syncthreads();                                        // (it reads the visited sets, which the next phase clears)
         k4_bulk<true, true, false>(s, s.stx, qt, wave, lane);  // visited rows: lists under the new labels + the minima of the next phase
         have_prev = true;
         if (PROF) { q_prows += qt; c_fail += (long long)__builtin_readcyclecounter() - t1; }

@@ -655,7 +655,8 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
   if (nc <= 0) return GHICP_OK;
   while ((int)ctx->aux_streams.size() < nc - 1) {
     hipStream_t a = nullptr;
-    GH_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    if (ctx->cu_mask.empty()) GH_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    else GH_HIP(hipExtStreamCreateWithCUMask(&a, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));  // stay on the context's compute units
     ctx->aux_streams.push_back(a);
   }
   while ((int)ctx->aux_events.size() < nc + 1) {

@@ -556,6 +556,35 @@ static void knn_grid(const Grid& g, const float* xyz, int stride, int i, int k, 
   }
 }
 
+// N7 of the numerics contract: the atan2f behind the SPFH angle feature f1 (pcl::computePairFeatures calls atan2f).
+// Two libm implementations differ by an ulp here and there, and an ulp moves a feature across a bin edge, so the contract fixes the
+// evaluation: atan2 in f64 from + - * / only (octant reduction, (t - 1) / (t + 1) above tan(pi / 8), odd series to z^37 in Horner
+// form), rounded once to f32.  This is the oracle's own transcription; the kernels hold theirs (gh_atan2f, csrc/devmath.h).
+static float contract_atan2f(float yf, float xf) {
+  if (yf != yf || xf != xf) return yf + xf;
+  const double PI = 3.14159265358979323846, PI_2 = 1.57079632679489661923, PI_4 = 0.78539816339744830962;
+  const double y = (double)yf, x = (double)xf;
+  const double ay = std::fabs(y), ax = std::fabs(x);
+  double r;
+  if (ay == 0.0 && ax == 0.0) {
+    r = 0.0;
+  } else if (std::isinf(ax) && std::isinf(ay)) {
+    r = PI_4;
+  } else {
+    const double hi = ax > ay ? ax : ay, lo = ax > ay ? ay : ax;
+    double t = std::isinf(hi) ? 0.0 : lo / hi, base = 0.0;
+    if (t > 0.41421356237309503) { t = (t - 1.0) / (t + 1.0); base = PI_4; }
+    const double z = t * t;
+    double p = 1.0 / 37.0;
+    for (int k = 35; k >= 3; k -= 2) p = 1.0 / (double)k - z * p;
+    r = base + (t - t * z * p);
+    if (ay > ax) r = PI_2 - r;
+  }
+  if (std::signbit(xf)) r = PI - r;
+  const float rf = (float)r;
+  return std::signbit(yf) ? -rf : rf;
+}
+
 static void fpfh_cloud(const float* xyz, int m, int stride, int k, float* normals /*m x 3*/, float* hist /*m x 33*/) {
   Grid g;
   // cell ~ the radius that holds k points on a surface sampled like this cloud would be ideal; any cell is exact
@@ -635,7 +664,7 @@ static void fpfh_cloud(const float* xyz, int m, int stride, int k, float* normal
       for (int d = 0; d < 3; d++) vv[d] *= iv;
       const float ww[3] = {a1[1] * vv[2] - a1[2] * vv[1], a1[2] * vv[0] - a1[0] * vv[2], a1[0] * vv[1] - a1[1] * vv[0]};
       const float f2 = dot3(vv, a2);
-      const float f1 = std::atan2(dot3(ww, a2), dot3(a1, a2));
+      const float f1 = contract_atan2f(dot3(ww, a2), dot3(a1, a2));  // N7 (PCL calls atan2f; see contract_atan2f)
       int h = (int)std::floor(11 * (((double)f1 + M_PI) * (1.0 / (2.0 * M_PI))));
       h = std::min(std::max(h, 0), 10);
       H[h] += incr;
@@ -1064,6 +1093,11 @@ float orc_bbx_magnitude(const float* xyz, int n, int stride) {
       if (mx[d] < v) mx[d] = v;
     }
   return (float)(mx[0] - mn[0] + mx[1] - mn[1] + mx[2] - mn[2]);
+}
+
+// N7 test hook: the contract's atan2f (tests/test_oracle_cpu.py compares it with the correctly rounded value)
+void orc_atan2f(const float* y, const float* x, int n, float* out) {
+  for (int i = 0; i < n; i++) out[i] = orc::contract_atan2f(y[i], x[i]);
 }
 
 }  // extern "C"

@@ -159,6 +159,15 @@ def fpfh(xyz, k=20):
     return nrm, hist
 
 
+def atan2f(y, x):
+    """N7 of the numerics contract: the atan2f of the SPFH angle feature (orc::contract_atan2f)."""
+    y = np.ascontiguousarray(y, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(y.shape, np.float32)
+    lib().orc_atan2f(_p(y, C.c_float), _p(x, C.c_float), int(y.size), _p(out, C.c_float))
+    return out
+
+
 def fd_bsc(fS, fT):
     """fS: (V,ks,56) u8, fT: (kt,56) u8 -> (ks,kt) f64"""
     fS = np.ascontiguousarray(fS, np.uint8)

@@ -5,6 +5,7 @@ that are too slow to run live inside `pytest -m gpu` (cfg3 needs ~75 s per pair 
 The inputs are the seeded synthetic generators of gh-icp_amd/synth.py (seed = 0x5EED0000 + 256 * config + pair), so the GPU test
 regenerates identical clouds on the GPU box and compares its 4x4 with the one stored here (tests/test_gpu_fullsize.py).
     python tests/golden/make_fullsize_golden.py            # ~7 minutes on one core
+    python tests/golden/make_fullsize_golden.py 3          # only the cases of config 3, merged into the existing file
 Reference for the pipeline being restated: /root/reference/test/ghicp_main.cpp:86-153."""
 import importlib
 import json
@@ -25,8 +26,12 @@ CASES = [(2, 0), (3, 0), (3, 1), (5, 1)]
 def main():
     synth = importlib.import_module("gh-icp_amd.synth")
     O.build()
-    rows = []
+    out_path = os.path.join(ROOT, "tests", "golden", "fullsize.json")
+    only = {int(a) for a in sys.argv[1:]}
+    rows = [c for c in json.load(open(out_path))["cases"] if c["config"] not in only] if only and os.path.exists(out_path) else []
     for cfg_id, pair_id in CASES:
+        if only and cfg_id not in only:
+            continue
         CF = bench.CONFIGS[cfg_id]
         p = bench.make_pair(cfg_id, pair_id, CF["hits"])
         t = time.time()
@@ -39,8 +44,8 @@ def main():
                      "oracle_seconds": {k: round(v, 2) for k, v in r["seconds"].items()}, "wall_s": round(time.time() - t, 1)})
         print(rows[-1], flush=True)
     json.dump({"made_by": "tests/golden/make_fullsize_golden.py", "oracle": "oracle/libghicp_oracle.so (g++ -O2 -ffp-contract=off contract build)",
-               "tolerance": "1e-4 rotation (||R_gpu R_cpu^T - I||_F), 1e-3 m translation", "cases": rows},
-              open(os.path.join(ROOT, "tests", "golden", "fullsize.json"), "w"), indent=1)
+               "tolerance": "1e-4 rotation (||R_gpu R_cpu^T - I||_F), 1e-3 m translation",
+               "cases": sorted(rows, key=lambda c: (c["config"], c["pair_id"]))}, open(out_path, "w"), indent=1)
 
 
 if __name__ == "__main__":

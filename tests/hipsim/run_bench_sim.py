@@ -50,6 +50,8 @@ def main():
             return real_init(backend="gloo", **kw)
 
         dist.init_process_group = init_gloo
+    if "--detail-dir" not in sys.argv:  # the interpreter's side files stay out of gpurun_out/ (that directory holds MI355X records)
+        sys.argv += ["--detail-dir", os.path.join(HERE, "_build", "bench_detail")]
     sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 

@@ -62,7 +62,7 @@ def test_gpu_reproduces_golden(ctx, api, gold, gin):
     assert ham.max() <= 1 and (ham > 0).sum() <= max(1, fe["kp"].size // 200)
     nrm, hist = ctx.fpfh(ds[:3000])
     np.testing.assert_array_equal(nrm.cpu().numpy(), fe["normals"])
-    assert np.isclose(hist.cpu().numpy(), fe["fpfh"], rtol=1e-4, atol=1e-3).all(axis=1).mean() > 0.995
+    np.testing.assert_array_equal(hist.cpu().numpy(), fe["fpfh"])  # N7: the angle feature's atan2f is the contract's own on both sides
     g = gin["g"]
     kpS, kpT = g.source[g.kp_source].astype(np.float64), g.target[g.kp_target].astype(np.float64)
     import ctypes

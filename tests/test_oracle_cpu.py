@@ -468,3 +468,24 @@ def test_gpu_solver_state_machine_model_matches_reference_traversal(oracle):
         m, s2, mr2, fp, _, _, dead_rows, probe_rows = oracle.km_model(w, march=True, sweep_first=True, flood_dead=True, full=True)
         np.testing.assert_array_equal(m, ref)
         assert fp == failed and s2 - mr2 < 0.6 * (s - mr) and dead_rows > 0  # E12 at least halves... the serial DFS iterations
+
+
+def test_contract_atan2f_is_a_faithful_atan2f(oracle):
+    """N7: the contract's atan2f (f64 series rounded once) against the correctly rounded value: never more than one f32 ulp away, equal
+    on all but ~1e-5 of random inputs, exact on the axes / signed zeros / infinities (C99 F.9.1.4), and odd in y."""
+    rng = np.random.default_rng(123)
+    n = 400_000
+    y = np.concatenate([rng.normal(size=n), rng.normal(size=n) * 1e-6, rng.uniform(-1, 1, n)]).astype(np.float32)
+    x = np.concatenate([rng.normal(size=n), rng.uniform(-1, 1, n), rng.normal(size=n) * 1e-6]).astype(np.float32)
+    got = oracle.atan2f(y, x)
+    ref = np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp != 0).mean() < 1e-4, (ulp.max(), (ulp != 0).mean())
+    np.testing.assert_array_equal(oracle.atan2f(-y, x), -got)
+    inf, z = np.float32(np.inf), np.float32(0.0)
+    sy = np.array([z, -z, z, -z, 1, -1, 1, -1, inf, -inf, inf, -inf, inf, -inf, 2, -2, z, z], np.float32)
+    sx = np.array([z, z, -z, -z, z, z, -z, -z, inf, inf, -inf, -inf, 3, 3, -inf, inf, 5, -5], np.float32)
+    g = oracle.atan2f(sy, sx)
+    r = np.arctan2(sy.astype(np.float64), sx.astype(np.float64)).astype(np.float32)
+    np.testing.assert_array_equal(g.view(np.int32), r.view(np.int32))  # incl. the sign of zero
+    assert np.isnan(oracle.atan2f(np.array([np.nan], np.float32), np.array([1.0], np.float32)))[0]

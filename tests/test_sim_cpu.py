@@ -65,7 +65,7 @@ def test_bench_py_on_the_host_simt_interpreter():
         assert {"frac", "whole_pair_frac", "achieved", "peak", "traffic", "bound", "unit"} <= set(out["roofline"])
         assert all(v is not None for v in out["roofline"]["per_kernel_GBps"].values()), out["roofline"]["per_kernel_GBps"]
         assert {"reference_verdict_ok", "gt_ok", "value_gt_ok"} <= set(out["registered_ok"])
-        detail = json.load(open(os.path.join(ROOT, "gpurun_out", "bench_detail_cfg4.json")))
+        detail = json.load(open(os.path.join(ROOT, "tests", "hipsim", "_build", "bench_detail", "bench_detail_cfg4.json")))
         assert len(detail["scenes"]) == 2 and len(detail["scenes"][0]["Rt"]) == 16 and detail["line"]["value"] == out["value"]
         if expect_batch is None:
             cal = detail["front_end_calibration"]
