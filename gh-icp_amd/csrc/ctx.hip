@@ -37,6 +37,8 @@ extern "C" int ghicp_ctx_create(int device, ghicp_ctx** out) {
   ghicp_ctx* c = new ghicp_ctx();
   c->device = device;
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->km_stats = getenv("GHICP_KM_STATS") != nullptr;
+  c->km_force_hazard = getenv("GHICP_KM_FORCE_HAZARD") != nullptr;
   if (hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) { delete c; return GHICP_ERR_HIP; }
   c->pinned_cap = 4096;
   *out = c;

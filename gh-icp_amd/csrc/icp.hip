@@ -628,12 +628,11 @@ int build_index(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float
     GH_TRY(gh_bbox_dev(ctx, xyz, n, stride, mm));
     const double vol = fmax(1e-9, (double)(mm[3] - mm[0] + 1e-3) * (mm[4] - mm[1] + 1e-3) * (mm[5] - mm[2] + 1e-3));
     cell = fmaxf((float)cbrt(vol / (double)n * 8.0), 0.02f);
-    if (const char* e = getenv("GHICP_ICP_CELL")) cell = (float)atof(e);
     unsigned* cnt;
     GH_TRY(ctx->reserve(B_ICP_PEND, (size_t)n + 4, &cnt));
     for (int attempt = 0;; attempt++) {
       GH_TRY(gh_grid_build(ctx, xyz, n, stride, cell, sf, &gf));
-      if (attempt >= 5 || getenv("GHICP_ICP_CELL")) break;
+      if (attempt >= 5) break;
       const double nc_next = (double)gf.d.dim[0] * gf.d.dim[1] * gf.d.dim[2] * 8.0;
       if (nc_next > (double)(1u << 26) || 1.0f / gf.d.inv > cell * 1.01f) break;  // next halving would not fit / was already coarsened
       GH_HIP(hipMemsetAsync(cnt, 0, 4, s));

@@ -225,8 +225,8 @@ int gh_km_solve_dev(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t*
   return GHICP_OK;
 }
 
-bool gh_km2_fits(int n);
-int gh_km2_solve_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, int* status_dev);
+#include "km_prob.h"
+int gh_km_solve_sparse_from_dense(ghicp_ctx* ctx, const double* w, int n, double eps, int32_t* match, int* status_dev);
 
 extern "C" int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double eps, int32_t* match) {
   GH_ENTER(ctx);
@@ -236,12 +236,12 @@ extern "C" int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double
   int32_t* dm;
   GH_TRY(sg.in(w, (size_t)n * n, &dw));
   GH_TRY(sg.out(match, (size_t)n, &dm));
-  const bool v2 = n > 0 && gh_km2_fits((int)n) && !getenv("GHICP_KM_DENSE");
+  const bool v2 = n > 0 && gh_km4_fits((int)n);  // LDS-resident sparse solver (n <= ~3700); beyond: the dense solver below
   if (v2) {
     int* stv;
     GH_TRY(ctx->reserve(B_P_MISC, 16, &stv));
     GH_HIP(hipMemsetAsync(stv, 0, sizeof(int), ctx->stream));
-    GH_TRY(gh_km2_solve_dense(ctx, dw, (int)n, eps, dm, stv));
+    GH_TRY(gh_km_solve_sparse_from_dense(ctx, dw, (int)n, eps, dm, stv));
   } else {
     GH_TRY(gh_km_solve_dev(ctx, dw, (int)n, eps, dm, nullptr));
   }

@@ -33,7 +33,7 @@ static int k4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, size_
   // per device and thread safe: the attribute is cheap to set, so it is simply set before every launch
   GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
   GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
-  const int kflags = getenv("GHICP_KM_FORCE_HAZARD") ? 4 : 0;  // test hook: sends one phase through the hazard fallback
+  const int kflags = ctx->km_force_hazard ? 4 : 0;  // test hook: sends one phase through the hazard fallback
   unsigned long long* lstat = nullptr;
   if (ctx->kt_on && ctx->km_launches < ghicp_ctx::KM_LSTAT_MAX) {
     GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W, &lstat));
@@ -44,7 +44,7 @@ static int k4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, size_
     ctx->km_launches++;
   }
   hipEvent_t kt = ctx->kt_begin(KT_KM_SOLVE);
-  if (getenv("GHICP_KM_STATS")) hipLaunchKernelGGL((k_km4<true>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds, lstat, d_order);
+  if (ctx->km_stats) hipLaunchKernelGGL((k_km4<true>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds, lstat, d_order);
   else hipLaunchKernelGGL((k_km4<false>), dim3(nprob), dim3(K4_T), lds, ctx->stream, d_probs, kflags, (int)lds, lstat, d_order);
   ctx->kt_end(KT_KM_SOLVE, kt);
   GH_HIP(hipGetLastError());

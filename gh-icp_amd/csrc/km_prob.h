@@ -1,4 +1,4 @@
-// Internal: descriptor of one sparse Kuhn-Munkres problem (shared by loop.hip, km2.hip, km4.hip).  Not part of the ABI.
+// Internal: descriptor of one sparse Kuhn-Munkres problem (shared by loop.hip, km_dense_door.hip, km4.hip).  Not part of the ABI.
 #pragma once
 struct Km2Problem {
   int n, pad_;
@@ -11,11 +11,8 @@ struct Km2Problem {
   int* status;              // 0 = ok
   const int* done;          // optional early-exit flag (device)
   long long* steps;         // optional: counters (profiling)
-  double* slack;            // n doubles of global scratch (k_km2 only)
 };
 struct ghicp_ctx;
-int gh_km2_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
-bool gh_km2_fits(int n);
 int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_max);
 bool gh_km4_fits(int n);
 size_t gh_km4_lds_bytes(int n);

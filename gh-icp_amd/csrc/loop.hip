@@ -53,7 +53,7 @@ struct LoopProb {
   // KM
   unsigned *km_cnt, *km_rptr;
   int *km_cols, *kmmatch, *km_status;
-  double *km_vals, *km_lx, *kmw, *km_slack;
+  double *km_vals, *km_lx, *kmw;
   Km2Problem* km_desc;
 };
 
@@ -280,7 +280,7 @@ __device__ inline void dev_km_scan_desc(const LoopProb& P, int* sc) {
     P.km_rptr[n] = (unsigned)carry;
     Km2Problem p;
     p.n = n; p.pad_ = 0; p.bg = -P.st->penalty; p.eps = P.C.km_eps; p.row_ptr = P.km_rptr; p.cols = P.km_cols; p.vals = P.km_vals;
-    p.lx_init = P.km_lx; p.match_out = P.kmmatch; p.status = P.km_status; p.done = &P.st->done; p.steps = nullptr; p.slack = P.km_slack;
+    p.lx_init = P.km_lx; p.match_out = P.kmmatch; p.status = P.km_status; p.done = &P.st->done; p.steps = nullptr;
     *P.km_desc = p;
   }
 }
@@ -670,10 +670,10 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
   }
   *(volatile int*)ctx->progress_host = 0;
   ctx->progress_live.store(true, std::memory_order_release);
-  const bool prof = getenv("GHICP_KM_STATS") != nullptr;
+  const bool prof = ctx->km_stats;
   const void* fn = prof ? reinterpret_cast<const void*>(&k_pair_loop<FT, true>) : reinterpret_cast<const void*>(&k_pair_loop<FT, false>);
   GH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  const int kflags = getenv("GHICP_KM_FORCE_HAZARD") ? 4 : 0;  // test hook: sends one phase through the hazard fallback
+  const int kflags = ctx->km_force_hazard ? 4 : 0;  // test hook: sends one phase through the hazard fallback
   GH_HIP(hipMemsetAsync(dqheads, 0, 16 * sizeof(int), s));
   hipEvent_t kt = ctx->kt_begin(KT_PAIR_LOOP);
   GH_HIP(hipEventRecord(ctx->aux_events[0], s));
@@ -731,7 +731,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
   bool persistent = corr == GHICP_CORR_KM;
   for (int b = 0; b < nb && persistent; b++) {
     const int n = std::max(jobs[b].ks, jobs[b].kt);
-    persistent = (jobs[b].ks <= 0 || jobs[b].kt <= 0) || (gh_km4_fits(n) && gh_km2_fits(n));
+    persistent = (jobs[b].ks <= 0 || jobs[b].kt <= 0) || gh_km4_fits(n);
   }
   const int chunk_batch = persistent ? (1 << 20) : nb;  // one workgroup sweeps a pair: the largest chunks (fewest partial sums)
   for (int pass = 0; pass < 2; pass++) {
@@ -781,11 +781,10 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       if (corr == GHICP_CORR_KM) {
         L.kmmatch = cv.take<int>((size_t)C.n + 1);
         L.km_status = cv.take<int>(4);
-        if (gh_km2_fits(C.n)) {
+        if (gh_km4_fits(C.n)) {
           L.km_cnt = cv.take<unsigned>((size_t)C.n + 1);
           L.km_rptr = cv.take<unsigned>((size_t)C.n + 2);
           L.km_lx = cv.take<double>((size_t)C.n + 1);
-          L.km_slack = cv.take<double>((size_t)C.n + 2);
           L.km_cols = cv.take<int>((size_t)ks * kt + 1);
           L.km_vals = cv.take<double>((size_t)ks * kt + 1);
           L.km_desc = d_descs ? d_descs + b : nullptr;
@@ -835,7 +834,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       // the Kuhn-Munkres launches of this batch: problems grouped by LDS occupancy, largest first (km4.hip)
       Km4Plan km_plan;
       bool use_plan = false;
-      if (any_sparse && !any_dense && gh_km4_fits(max_n_sparse) && !getenv("GHICP_KM_V2") && !getenv("GHICP_KM_NOPLAN")) {
+      if (any_sparse && !any_dense && gh_km4_fits(max_n_sparse)) {
         std::vector<int> hn((size_t)nb);
         bool all_sparse = true;
         for (int b = 0; b < nb; b++) { hn[b] = hp[b].C.n; all_sparse &= (hp[b].km_rptr != nullptr) || jobs[b].ks <= 0 || jobs[b].kt <= 0; }
@@ -858,7 +857,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
             hipLaunchKernelGGL(k_km_scan_desc, dim3(nb), dim3(1024), 0, s, dprobs);
             hipLaunchKernelGGL((k_km_csr<FT, 1>), dim3(cdiv(max_n, 4), nb), dim3(256), 0, s, dprobs);
             ctx->kt_end(KT_KM_WEIGHTS, kw);
-            if (any_sparse) GH_TRY(use_plan ? gh_km4_launch_plan(ctx, d_descs, km_plan) : gh_km2_launch(ctx, d_descs, nb, max_n_sparse));
+            if (any_sparse) GH_TRY(use_plan ? gh_km4_launch_plan(ctx, d_descs, km_plan) : gh_km4_launch(ctx, d_descs, nb, max_n_sparse));
             if (any_dense) {  // matrices too large for the LDS-resident solver: dense fallback, one pair at a time
               hipLaunchKernelGGL(k_km_weights<FT>, dim3(cdiv(max_n, 256), max_n, nb), dim3(256), 0, s, dprobs);
               for (int b = 0; b < nb; b++)

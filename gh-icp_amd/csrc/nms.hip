@@ -6,8 +6,7 @@
 // emit the best unsuppressed one and erase everything within R of it.  Greedy NMS over a strict total
 // order is the unique fixed point of
 //     selected(i)  <=>  no selected j with rank(j) < rank(i) and d2(i,j) < R^2          
-// which is computed here in parallel rounds: a candidate whose better-ranked neighbours are all
-// decided-suppressed becomes selected; one with a selected better-ranked neighbour becomes suppressed.
+// and is computed by ONE workgroup per cloud that sweeps the rank-ordered candidates in chunks (nms_dev.h).
 // Rank = (curvature desc, candidate order asc): stable radix sort, so ties resolve to the lower point index.
 #include "grid.h"
 
@@ -47,65 +46,10 @@ __global__ __launch_bounds__(256) void k_nms_points(const float* __restrict__ xy
   cpts[r * 3 + 2] = xyz[s * stride + 2];
 }
 
-enum { UNDECIDED = 0, SELECTED = 1, SUPPRESSED = 2 };
-
-__global__ __launch_bounds__(256) void k_nms_round(GridArgs G, float r2, int* __restrict__ state, int* __restrict__ undecided) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= G.d.n) return;
-  const float4 P = G.pts[p];
-  const int rp = (int)__float_as_uint(P.w);
-  if (__hip_atomic_load(&state[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != UNDECIDED) return;
-  const int cx = gh_cell_coord(P.x, G.d.mn[0], G.d.inv, G.d.dim[0]);
-  const int cy = gh_cell_coord(P.y, G.d.mn[1], G.d.inv, G.d.dim[1]);
-  const int cz = gh_cell_coord(P.z, G.d.mn[2], G.d.inv, G.d.dim[2]);
-  // Spin in place: a candidate decides as soon as every better-ranked neighbour within R has decided.  All
-  // candidates of a launch are co-resident for C <= ~0.5 M, so the globally best undecided one can always move;
-  // the bounded loop + host relaunch keeps this safe when they are not.  Inside a cell the points are in rank
-  // order (stable cell sort of a rank-ordered array), so a cell scan stops at the first rank >= own rank.
-  const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.d.dim[2] - 1);
-  for (int iter = 0; iter < 3; iter++) {
-    bool pending = false, killed = false;
-    for (int x = max(cx - 1, 0); x <= min(cx + 1, G.d.dim[0] - 1) && !killed; x++)
-      for (int y = max(cy - 1, 0); y <= min(cy + 1, G.d.dim[1] - 1) && !killed; y++)
-        for (int z = z0; z <= z1 && !killed; z++) {
-          const unsigned key = ((unsigned)x * G.d.dim[1] + y) * G.d.dim[2] + z;
-          const unsigned e = G.start[key + 1];
-          for (unsigned q = G.start[key]; q < e; q++) {
-            const float4 Q = G.pts[q];
-            const int rq = (int)__float_as_uint(Q.w);
-            if (rq >= rp) break;
-            const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
-            float d2 = dx * dx;
-            d2 += dy * dy;
-            d2 += dz * dz;
-            if (d2 < r2) {
-              const int sq = __hip_atomic_load(&state[rq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (sq == SELECTED) { killed = true; break; }
-              if (sq == UNDECIDED) pending = true;
-            }
-          }
-        }
-    if (killed) { __hip_atomic_store(&state[rp], SUPPRESSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    if (!pending) { __hip_atomic_store(&state[rp], SELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-  }
-  atomicAdd(undecided, 1);
-}
-
 __global__ __launch_bounds__(NMS_T) void k_nms_greedy(const float* __restrict__ cpts, int c, GridDesc g, float r2, int* __restrict__ head,
                                                       int* __restrict__ next, const int* __restrict__ cand, const int* __restrict__ ord,
                                                       int* __restrict__ kp, int* __restrict__ kcount) {
   gh_nms_greedy_cloud(cpts, c, g, r2, head, next, cand, ord, kp, kcount, 0);
-}
-
-__global__ __launch_bounds__(256) void k_nms_flags(const int* __restrict__ state, int c, unsigned char* __restrict__ flags) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r < c) flags[r] = state[r] == SELECTED ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void k_nms_emit(const int* __restrict__ sel_rank, const int* __restrict__ nsel, const int* __restrict__ cand,
-                                                  const int* __restrict__ ord, int* __restrict__ kp) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < *nsel) kp[i] = cand[ord[sel_rank[i]]];
 }
 
 }  // namespace
@@ -119,67 +63,35 @@ int gh_nms_dev(ghicp_ctx* ctx, const float* xyz, int stride, const double* curva
   if (c <= 0) return GHICP_OK;  // NB the reference's do-while dereferences an empty set here (keypoint_detect.hpp:177)
   hipStream_t s = ctx->stream;
   unsigned long long *keys, *keys2;
-  int *vals, *ord, *state, *misc, *selrank;
+  int *vals, *ord, *misc;
   float* cpts;
-  unsigned char* flags;
   GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)c + 1, &keys));
   GH_TRY(ctx->reserve(B_FE_SORTK2, (size_t)c + 1, &keys2));
   GH_TRY(ctx->reserve(B_FE_SORTV, (size_t)c + 1, &vals));
   GH_TRY(ctx->reserve(B_FE_SORTV2, (size_t)c + 1, &ord));
-  GH_TRY(ctx->reserve(B_FE_STATE, (size_t)c + 1, &state));
   GH_TRY(ctx->reserve(B_FE_CPTS, (size_t)c * 3 + 3, &cpts));
-  GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)c + 16, &flags));
   GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
-  GH_TRY(ctx->reserve(B_FE_KP, (size_t)c + 1, &selrank));
   hipLaunchKernelGGL(k_nms_keys, dim3(cdiv(c, 256)), dim3(256), 0, s, curvature, cand, (int)c, keys, vals);
-  size_t tb = 0, tb2 = 0;
+  size_t tb = 0;
   GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys, keys2, vals, ord, (int)c, 0, 64, s));
-  hipcub::CountingInputIterator<int> iota(0);
-  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, iota, flags, selrank, misc, (int)c, s));
   char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, keys, keys2, vals, ord, (int)c, 0, 64, s));  // stable
   hipLaunchKernelGGL(k_nms_points, dim3(cdiv(c, 256)), dim3(256), 0, s, xyz, stride, cand, ord, (int)c, cpts);
   const float r2 = (float)((double)radius * (double)radius);
   int* hflag = reinterpret_cast<int*>(ctx->pinned);
-  if (!getenv("GHICP_NMS_ROUNDS")) {
-    // ---- single-launch exact greedy NMS over a grid of SELECTED keypoints
-    float mm[6];
-    GH_TRY(gh_bbox_dev(ctx, cpts, c, 3, mm));
-    const GridDesc g = gh_grid_desc(mm, c, radius * 1.0001f);
-    int *head, *next;
-    GH_TRY(ctx->reserve(B_GRID_START, (size_t)g.ncell + 2, &head));
-    GH_TRY(ctx->reserve(B_FE_STATE, (size_t)c + 1, &next));
-    GH_HIP(hipMemsetAsync(head, 0xff, (size_t)g.ncell * sizeof(int), s));
-    hipEvent_t kev = ctx->kt_begin(KT_NMS_ROUND);
-    hipLaunchKernelGGL(k_nms_greedy, dim3(1), dim3(NMS_T), 0, s, cpts, (int)c, g, r2, head, next, cand, ord, kp, misc);
-    ctx->kt_end(KT_NMS_ROUND, kev);
-    GH_HIP(hipGetLastError());
-    GH_HIP(hipMemcpyAsync(hflag, misc, sizeof(int), hipMemcpyDeviceToHost, s));
-    GH_HIP(hipStreamSynchronize(s));
-    *k_out = hflag[0];
-    return GHICP_OK;
-  }
-  // ---- multi-launch fixed-point rounds (kept as a cross-check: GHICP_NMS_ROUNDS=1)
-  DeviceGrid G;
-  const GridSlots sl = {B_GRID_KEYS, B_GRID_KEYS2, B_GRID_VALS, B_GRID_VALS2, B_GRID_START, B_GRID_PTS};
-  GH_TRY(gh_grid_build(ctx, cpts, c, 3, radius * 1.0001f, sl, &G));  // float4.w of the grid points = rank
-  GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
-  GH_HIP(hipMemsetAsync(state, 0, (size_t)c * sizeof(int), s));
-  GridArgs A = {G.d, G.pts, G.start};
-  for (int round = 0;; round++) {
-    for (int r = 0; r < 4; r++) {
-      GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
-      hipLaunchKernelGGL(k_nms_round, dim3(cdiv(c, 256)), dim3(256), 0, s, A, r2, state, misc + 1);
-    }
-    GH_HIP(hipMemcpyAsync(hflag, misc + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    GH_HIP(hipStreamSynchronize(s));
-    if (hflag[0] == 0) break;
-    if (round > (int)c + 8) return ctx->fail(GHICP_ERR_INTERNAL, "nms: no progress");
-  }
-  hipLaunchKernelGGL(k_nms_flags, dim3(cdiv(c, 256)), dim3(256), 0, s, state, (int)c, flags);
-  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, iota, flags, selrank, misc, (int)c, s));  // ascending rank = descending curvature
-  hipLaunchKernelGGL(k_nms_emit, dim3(cdiv(c, 256)), dim3(256), 0, s, selrank, misc, cand, ord, kp);
+  // ---- single-launch exact greedy NMS over a grid of SELECTED keypoints
+  float mm[6];
+  GH_TRY(gh_bbox_dev(ctx, cpts, c, 3, mm));
+  const GridDesc g = gh_grid_desc(mm, c, radius * 1.0001f);
+  int *head, *next;
+  GH_TRY(ctx->reserve(B_GRID_START, (size_t)g.ncell + 2, &head));
+  GH_TRY(ctx->reserve(B_FE_STATE, (size_t)c + 1, &next));
+  GH_HIP(hipMemsetAsync(head, 0xff, (size_t)g.ncell * sizeof(int), s));
+  hipEvent_t kev = ctx->kt_begin(KT_NMS_ROUND);
+  hipLaunchKernelGGL(k_nms_greedy, dim3(1), dim3(NMS_T), 0, s, cpts, (int)c, g, r2, head, next, cand, ord, kp, misc);
+  ctx->kt_end(KT_NMS_ROUND, kev);
+  GH_HIP(hipGetLastError());
   GH_HIP(hipMemcpyAsync(hflag, misc, sizeof(int), hipMemcpyDeviceToHost, s));
   GH_HIP(hipStreamSynchronize(s));
   *k_out = hflag[0];

@@ -197,7 +197,7 @@ extern "C" int ghicp_register_pairs(ghicp_ctx* ctx, const ghicp_pair_config* cfg
   if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_register_pairs: device-pointer mode only");
   if (n_pairs == 0) return GHICP_OK;
   for (int i = 0; i < n_pairs; i++) GH_ARG(nS[i] >= 0 && nT[i] >= 0 && nS[i] < (1ll << 31) - 2 && nT[i] < (1ll << 31) - 2);
-  if (n_pairs > 1 && !getenv("GHICP_PAIRS_ONE_BY_ONE")) {  // the batched front end (batch.hip) when the configuration allows it
+  if (n_pairs > 1) {  // the batched front end (batch.hip) when the configuration allows it
     int handled = 0;
     GH_TRY(gh_register_pairs_batched(ctx, cfg, n_pairs, xyzS, nS, xyzT, nT, stride, stats, &handled));
     if (handled) return GHICP_OK;

@@ -6,9 +6,9 @@
 
 #include <cstdlib>
 
-constexpr int PCA_CHUNK = 512;  // default LDS tile (8 KB: 5 waves per SIMD); 256 (4 KB: 8 waves per SIMD) behind GHICP_PCA_CHUNK=256 for timing
+constexpr int PCA_CHUNK = 512;  // LDS tile of neighbour points (8 KB: 5 waves per SIMD)
 inline int gh_pca_chunk() {
-  static const int v = [] { const char* e = getenv("GHICP_PCA_CHUNK"); return (e && atoi(e) == 256) ? 256 : PCA_CHUNK; }();
+  static const int v = PCA_CHUNK;
   return v;
 }
 

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 mkdir -p $O
-timeout 900 python -m pytest tests/test_golden.py tests/test_gpu_frontend.py tests/test_gpu_loop.py tests/test_gpu_batch.py tests/test_gpu_configs.py -m gpu -x -q > $O/r03_gputests_3.txt 2>&1
+timeout 900 python -m pytest tests/test_golden.py tests/test_gpu_frontend.py tests/test_gpu_loop.py tests/test_gpu_batch.py tests/test_gpu_configs.py tests/test_gpu_icp.py tests/test_gpu_cloud_cache.py -m gpu -x -q > $O/r03_gputests_3.txt 2>&1
 echo "pytest rc=$?"; tail -4 $O/r03_gputests_3.txt
 timeout 300 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "cfg3" >> $O/r03_gputests_3.txt 2>&1
 echo "pytest cfg3 rc=$?"; tail -3 $O/r03_gputests_3.txt

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: fuzzes the Kuhn-Munkres KERNELS themselves (k_km4 and its variants, compiled for the host SIMT interpreter of
 tests/hipsim) against the restatement of the reference's km.cpp on the generators of scripts/km4_model_fuzz.py -- thousands of matrices,
-no GPU.  python tests/hipsim/km_fuzz_sim.py [count] [procs] [mode]   (mode: default | GHICP_KM_FORCE_HAZARD | GHICP_KM_POOL | GHICP_KM_V2)"""
+no GPU.  python tests/hipsim/km_fuzz_sim.py [count] [procs] [mode]   (mode: default | GHICP_KM_FORCE_HAZARD)"""
 import importlib
 import multiprocessing as mp
 import os

@@ -154,12 +154,22 @@ def test_rigid_svd(ctx, oracle):
     assert np.abs(Rg[:3, :3] - R).max() < 1e-3
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["default", "GHICP_KM_V2", "GHICP_KM_FORCE_HAZARD"])
-def test_km_solver_paths_fuzz(ctx, oracle, mode):
-    """Every Kuhn-Munkres path of the library on the fuzz generators of scripts/km4_model_fuzz.py (ties, dense rows, empty rows,
-    ulp-perturbed lattices): the flood-first kernel (default), the DFS emulation it replaced (GHICP_KM_V2)
-    and the literal fallback behind the slack-hazard check -- all bit-exact against the restatement of km.cpp:13-126."""
+def _fresh_context(api):
+    """a context of its own: the diagnostic switches are read from the environment once, when a context is created"""
+    import os
+
+    if os.environ.get("GHICP_SIM") == "1":
+        from hipsim import simctx
+
+        return simctx.make_context(api)
+    return api.Context(0)
+
+
+@pytest.mark.parametrize("mode", ["default", "GHICP_KM_FORCE_HAZARD"])
+def test_km_solver_paths_fuzz(api, oracle, mode):
+    """The Kuhn-Munkres kernel on the fuzz generators of scripts/km4_model_fuzz.py (ties, dense rows, empty rows, ulp-perturbed
+    lattices): the flood-first solver and the literal fallback behind its slack-hazard check (GHICP_KM_FORCE_HAZARD=1, the library's one
+    test hook, sends a phase of every solve through it) -- bit-exact against the restatement of km.cpp:13-126."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import km4_model_fuzz as F
@@ -168,12 +178,30 @@ def test_km_solver_paths_fuzz(ctx, oracle, mode):
     if mode != "default":
         os.environ[mode] = "1"
     try:
+        c = _fresh_context(api)
         for t in range(60):
             n = int(rng.choice(sizes))
             w = F.gen(rng, n, t % 5)
-            np.testing.assert_array_equal(ctx.km_solve(w).cpu().numpy(), oracle.km(w)[0], err_msg="%s t=%d n=%d" % (mode, t, n))
+            np.testing.assert_array_equal(c.km_solve(w).cpu().numpy(), oracle.km(w)[0], err_msg="%s t=%d n=%d" % (mode, t, n))
+        c.close()
     finally:
         os.environ.pop(mode, None)
+
+
+def test_km_beyond_the_lds_resident_solver(ctx, oracle):
+    """n = 3800: the solver state (44 B per row) no longer fits the 160 KB of a CU, ghicp_km_solve goes to the dense solver of km.hip
+    (its only live range).  A graph the O(n^3) restatement finishes in seconds: one cheap column per row through a permutation, a few
+    dozen rows competing for the same columns (failed phases + relabelling), everything else background."""
+    n = 3800
+    rng = np.random.default_rng(9)
+    w = np.full((n, n), -8.0)
+    perm = rng.permutation(n)
+    w[np.arange(n), perm] = -rng.uniform(0.5, 3.0, n)
+    rows = rng.choice(n, 40, replace=False)
+    w[rows, perm[rng.choice(n, 40)]] = -rng.uniform(0.1, 0.4, 40)  # 40 rows prefer somebody else's column
+    m_o, _ = oracle.km(w)
+    m_g = ctx.km_solve(w).cpu().numpy()
+    np.testing.assert_array_equal(m_g, m_o)
 
 
 def test_pair_loop_persistent_batch(ctx, api, synth, oracle):
