@@ -191,6 +191,7 @@ def main():
                     "interleave over the 8 XCDs, so F bits = F/8 CUs per XCD); the loop contexts get the other CUs.  0 = no partition")
     ap.add_argument("--scene-cache", default="", help="directory that keeps the generated synthetic scenes between runs (the generation is untimed)")
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"], help="pair queue across ranks: static p mod R, or chunks claimed from a shared counter")
+    ap.add_argument("--queue-chunks", type=int, default=8, help="--queue dynamic: claims per rank and step (chunk = job / (ranks x this))")
     ap.add_argument("--detail-dir", default=os.path.join(ROOT, "gpurun_out"), help="where the per-scene / per-kernel side file goes")
     args = ap.parse_args()
     CF = CONFIGS[args.config]
@@ -208,10 +209,13 @@ def main():
     pq = importlib.import_module("gh-icp_amd.pairqueue")
     manifest = pq.job_manifest(B, distinct, world, strong)
     n_job = len(manifest)
+    dynamic = args.queue == "dynamic" and world > 1
+    if dynamic:  # any rank may claim any pair: every rank holds the same `distinct` scenes
+        manifest = [p % distinct for p in range(n_job)]
 
     # ---- scenes this rank needs, generated in parallel BEFORE HIP is initialised (fork-safe), untimed
     mine = pq.pairs_for_rank(n_job, rank, world)
-    my_scenes = sorted({manifest[p] for p in mine})
+    my_scenes = sorted(set(manifest)) if dynamic else sorted({manifest[p] for p in mine})
     t0 = time.time()
     import multiprocessing as mp
 
@@ -356,7 +360,7 @@ def main():
     group_of = np.zeros(max(1, nb), np.int64)
     for g in range(G):
         group_of[bounds[g]:bounds[g + 1]] = g
-    nb_max = pq.records_per_rank(n_job, world)  # same record block on every rank (all_gather wants equal shapes)
+    nb_max = n_job if dynamic else pq.records_per_rank(n_job, world)  # same record block on every rank (all_gather wants equal shapes)
     rec_dev = torch.zeros((nb_max, pq.RECORD_WIDTH), dtype=torch.float64, device="cuda")
     job_records = {}
     last_results = [None] * G
@@ -480,21 +484,99 @@ def main():
         for g in range(G):
             last_results[g] = res[K - 1][g]
 
+    # ---- dynamic pair queue (--queue dynamic, N > 1): per step the ranks claim chunks of pair ids from a shared counter until the step's
+    # job is drained (gh-icp_amd/pairqueue.py:SharedCounter); the front ends of chunk c + 1 overlap the loop of chunk c (two handle sets)
+    dyn = {"epoch": 0, "handles": [[{} for _ in range(fe_n)] for _ in range(2)], "claimed": []}
+
+    def run_dynamic(K):
+        import queue as _queue
+        from concurrent.futures import ThreadPoolExecutor
+
+        chunk = pq.chunk_size(n_job, world, args.queue_chunks)
+        per_call = max(1, args.fe_batch // 2) if args.fe_batch > 1 else 1
+        for _ in range(max(0, K)):
+            counter = pq.SharedCounter(dist, "ghicp_step_%d" % dyn["epoch"])
+            dyn["epoch"] += 1
+            qq = _queue.Queue(maxsize=1)
+            err, got = [], []
+
+            def fe_part(slot, w, ids):
+                c, hs = fe_ctxs[w], dyn["handles"][slot][w]
+                out = []
+                for c0 in range(0, len(ids), per_call):
+                    part = ids[c0:c0 + per_call]
+                    flat_h, flat_x = [], []
+                    for j, pid in enumerate(part):
+                        S, T = dev[manifest[pid]]
+                        key = c0 + j
+                        if key not in hs:
+                            hs[key] = (c.cloud_create(cfg, S[:0]), c.cloud_create(cfg, T[:0]))
+                        flat_h += [hs[key][0], hs[key][1]]
+                        flat_x += [S, T]
+                        out.append(hs[key])
+                    if args.fe_batch > 1:
+                        c.clouds_recompute(flat_h, flat_x)
+                    else:
+                        for h, x in zip(flat_h, flat_x):
+                            h.recompute(x)
+                return out
+
+            def fe_thread():
+                slot = 0
+                try:
+                    with ThreadPoolExecutor(fe_n) as pool:
+                        while not err:
+                            ids = counter.claim(chunk, n_job)
+                            if not ids:
+                                break
+                            t = time.perf_counter()
+                            parts = [ids[w::fe_n] for w in range(fe_n)]
+                            res = list(pool.map(lambda a: fe_part(slot, a[0], a[1]), [(w, pp) for w, pp in enumerate(parts)]))
+                            thread_busy["front_end"] += (time.perf_counter() - t) * fe_n
+                            order = [pid for pp in parts for pid in pp]
+                            qq.put((order, [h for r in res for h in r]))  # blocks until the loop has taken the previous chunk: its handle set is free then
+                            slot ^= 1
+                except Exception as e:  # noqa: BLE001
+                    err.append(e)
+                qq.put(None)
+
+            th = threading.Thread(target=fe_thread)
+            th.start()
+            while True:
+                item = qq.get()
+                if item is None:
+                    break
+                ids, hs = item
+                t = time.perf_counter()
+                r = loop_ctxs[0].register_clouds(cfg, hs)
+                thread_busy["loop"] += time.perf_counter() - t
+                got += list(zip(ids, r))
+            th.join()
+            if err:
+                raise err[0]
+            dyn["claimed"] = got
+            rec_dev.copy_(torch.from_numpy(pq.pack_records([i for i, _ in got], [(st.iterations, st.converged, st.Rt[:]) for _, st in got], nb_max)))
+            tg = time.perf_counter()
+            job_records.clear()
+            job_records.update(pq.gather_records(rec_dev, dist))
+            thread_busy["gather_wait"] += time.perf_counter() - tg
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_pipeline(max(args.warmup, 0))
-    if any(h is None for buf in pool_h for h in buf):  # allocate every handle of both buffers outside the timed region
+    run_steps = run_dynamic if dynamic else run_pipeline
+    run_steps(max(args.warmup, 0))
+    if not dynamic and any(h is None for buf in pool_h for h in buf):  # allocate every handle of both buffers outside the timed region
         run_pipeline(NBUF)
     for c in ctxs:
         c.kernel_timing(True)
     thread_busy["front_end"] = thread_busy["loop"] = thread_busy["gather_wait"] = 0.0
     barrier()
     t0 = time.perf_counter()
-    run_pipeline(args.steps)
+    run_steps(args.steps)
     time_own = time.perf_counter() - t0  # before the closing barrier
     barrier()
     elapsed = time.perf_counter() - t0
@@ -510,6 +592,9 @@ def main():
         dist.all_gather(bt, torch.tensor([busy_mine], dtype=torch.float64, device="cuda"))
         busy_all = [float(x.item()) for x in bt]
     results = last_results
+    if dynamic:  # what this rank claimed in the last step, as one "group"
+        mine = [i for i, _ in dyn["claimed"]]
+        results = [[st for _, st in dyn["claimed"]]]
     ktimes = {k: (sum(c.kernel_time(k)[0] for c in ctxs), sum(c.kernel_time(k)[1] for c in ctxs)) for k in KERNELS}
     kml = [c.km_launch_stats() for c in loop_ctxs]
     pls = [c.pair_loop_stats() for c in loop_ctxs]
@@ -521,7 +606,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    flat = [st for r in results for st in r]
+    flat = [st for r in results for st in r if r]
     by_scene, cand_of = {}, {}
     last_buf = pool_h[(args.steps - 1) % NBUF] if args.steps > 0 else pool_h[0]
     for i, st in enumerate(flat):
@@ -529,7 +614,7 @@ def main():
         if sid not in by_scene:
             by_scene[sid] = st
             try:  # NMS candidates of the two clouds (recorded by the batched front end; 0 otherwise)
-                cand_of[sid] = 0.5 * (last_buf[i][0].info().candidates + last_buf[i][1].info().candidates)
+                cand_of[sid] = 0.0 if dynamic else 0.5 * (last_buf[i][0].info().candidates + last_buf[i][1].info().candidates)
             except Exception:  # noqa: BLE001
                 cand_of[sid] = 0.0
     pairs_total = args.steps * n_job

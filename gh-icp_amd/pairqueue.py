@@ -136,3 +136,73 @@ def gather_records(block, dist=None):
             if row[0] >= 0:
                 out[int(row[0])] = (int(row[1]), int(row[2]), [float(v) for v in row[3:]])
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Dynamic variant ("or a dynamic counter for skewed sizes").  The iterations a pair needs are not known in advance
+# (24 ... 112 on the bench scenes), so the static p mod R split leaves ranks waiting for the rank that drew the slow pairs.  Here the
+# ranks claim CHUNKS of consecutive pair ids from ONE shared counter -- an atomic add on torch.distributed's key-value store (the TCP
+# store rank 0 owns; host side, a few bytes per claim) -- until the job is drained.  Still no collective on the data path: what is
+# exchanged is the manifest, one integer per claim and the result records.
+class SharedCounter:
+    """Atomic counter shared by the ranks of a process group; a plain local counter without one."""
+
+    def __init__(self, dist=None, name: str = "ghicp_pairqueue"):
+        self._local = 0
+        self._store = None
+        self._key = name
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d as c10d
+
+            self._store = c10d._get_default_store()
+
+    def claim(self, count: int, limit: int) -> List[int]:
+        """The next `count` ids below `limit` (fewer at the end, [] when the queue is drained)."""
+        if count <= 0:
+            return []
+        if self._store is None:
+            lo = self._local
+            self._local += count
+        else:
+            lo = int(self._store.add(self._key, count)) - count  # add() returns the value AFTER the addition, atomically
+        return list(range(min(lo, limit), min(lo + count, limit)))
+
+
+def chunk_size(n_pairs: int, world: int, chunks_per_rank: int = 8) -> int:
+    """Pairs per claim: small enough that the last chunks even out the ranks, large enough that a claim feeds a batched launch."""
+    return max(1, n_pairs // max(1, world * chunks_per_rank))
+
+
+def run_sharded_dynamic(manifest: Sequence, register_chunk: Callable[[List[int], List[object]], List[dict]], dist=None, chunk: int = 0,
+                        name: str = "ghicp_pairqueue") -> List[dict]:
+    """Like run_sharded, but the ranks claim chunks of pair ids from a SharedCounter until the job is drained.
+    `register_chunk(pair_ids, items)` registers the chunk's pairs on this rank's GPU (one batched call) and returns one picklable
+    record per pair.  `name` must be new for every job of a process group (the counter lives in the group's store).
+    Returns the records of ALL pairs in pair order on every rank."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if world > 1:
+        box = [list(manifest) if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        manifest = box[0]
+    n = len(manifest)
+    counter = SharedCounter(dist, name)
+    step = chunk or chunk_size(n, world)
+    mine = []
+    while True:
+        ids = counter.claim(step, n)
+        if not ids:
+            break
+        recs = register_chunk(ids, [manifest[i] for i in ids])
+        if len(recs) != len(ids):
+            raise RuntimeError("register_chunk returned %d records for %d pairs" % (len(recs), len(ids)))
+        mine += list(zip(ids, recs))
+    if world == 1:
+        gathered = [mine]
+    else:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+    out = [None] * n
+    for part in gathered:
+        for i, rec in part:
+            out[i] = rec
+    return out

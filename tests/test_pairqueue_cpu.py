@@ -175,3 +175,76 @@ def test_job_manifest_and_record_gather_two_ranks():
     assert out0 == out1 and [k for k, _ in out0] == list(range(10))
     for pid, (it, conv, Rt) in out0:
         assert it == 10 + pid and conv == pid % 2 and Rt == [float(man0[pid] * 100 + k) for k in range(16)]
+
+
+def _dyn_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    # skewed job: the iterations of the bench scenes span 24 ... 112; here a pair "costs" its iteration count in milliseconds and the
+    # slow pairs all sit on the even ids, i.e. on rank 0 under the static p mod R split
+    iters = [112 if p % 2 == 0 and p < 24 else 24 for p in range(48)]
+    manifest = [{"iters": it} for it in iters] if rank == 0 else []
+    busy = {"static": 0.0, "dynamic": 0.0}
+
+    def cost(item):
+        time.sleep(item["iters"] * 1e-3)
+        return item["iters"]
+
+    def reg_one(i, item):
+        t = time.perf_counter()
+        v = cost(item)
+        busy["static"] += time.perf_counter() - t
+        return {"pair": i, "rank": rank, "iters": v}
+
+    def reg_chunk(ids, items):
+        t = time.perf_counter()
+        out = [{"pair": i, "rank": rank, "iters": cost(it)} for i, it in zip(ids, items)]
+        busy["dynamic"] += time.perf_counter() - t
+        return out
+
+    st = pq.run_sharded(manifest, reg_one, dist)
+    dy = pq.run_sharded_dynamic(manifest, reg_chunk, dist, chunk=2, name="job_a")
+    dy2 = pq.run_sharded_dynamic(manifest, reg_chunk, dist, name="job_b")  # default chunk, a second job on the same group
+    q.put((rank, busy, st, dy, dy2))
+    dist.destroy_process_group()
+
+
+def test_dynamic_pair_queue_two_ranks_skewed():
+    """The dynamic counter: every pair registered exactly once, every rank ends up with every record, and on a skewed job the busier
+    rank carries far less than under the static split (max / mean of the per-rank busy time)."""
+    import torch.multiprocessing as mp
+
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    c = pq.SharedCounter()
+    assert c.claim(3, 7) == [0, 1, 2] and c.claim(3, 7) == [3, 4, 5] and c.claim(3, 7) == [6] and c.claim(3, 7) == [] and c.claim(0, 7) == []
+    assert pq.chunk_size(5376 * 8, 8) == 672 and pq.chunk_size(3, 8) == 1
+    seen = []
+    out = pq.run_sharded_dynamic([10, 20, 30], lambda ids, items: [seen.append(i) or {"v": x + 1} for i, x in zip(ids, items)])
+    assert seen == [0, 1, 2] and out == [{"v": 11}, {"v": 21}, {"v": 31}]
+    with pytest.raises(RuntimeError):
+        pq.run_sharded_dynamic([1, 2], lambda ids, items: [])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dyn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    iters = [112 if p % 2 == 0 and p < 24 else 24 for p in range(48)]
+    for _, _, st, dy, dy2 in got:
+        for recs in (st, dy, dy2):
+            assert [r["pair"] for r in recs] == list(range(48)) and [r["iters"] for r in recs] == iters
+    assert got[0][3] == got[1][3] and got[0][4] == got[1][4]
+    assert {r["rank"] for r in got[0][3]} == {0, 1}  # both ranks took part
+    imb = {k: max(g[1][k] for g in got) / (sum(g[1][k] for g in got) / 2) for k in ("static", "dynamic")}
+    assert imb["static"] > 1.3 and imb["dynamic"] < 1.15 and imb["dynamic"] < imb["static"], imb

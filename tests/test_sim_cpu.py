@@ -74,7 +74,11 @@ def test_bench_py_on_the_host_simt_interpreter():
             assert out["config"]["fe_batch"] == expect_batch
 
 
-def test_bench_py_two_ranks_on_the_host_simt_interpreter():
+import pytest
+
+
+@pytest.mark.parametrize("queue", ["static", "dynamic"])
+def test_bench_py_two_ranks_on_the_host_simt_interpreter(queue):
     """The N > 1 path of bench.py (manifest broadcast, static shard of the pair queue, per-step all-gather of the result records, max-over-
     ranks timing, per-rank wall times) with two processes; RCCL is replaced by gloo in tests/hipsim/run_bench_sim.py, nothing else."""
     import json
@@ -89,7 +93,7 @@ def test_bench_py_two_ranks_on_the_host_simt_interpreter():
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "hipsim", "run_bench_sim.py"), "--gpus", "2", "--config", "4", "--hits", "20000", "--distinct", "4",
-           "--pairs-per-step", "6", "--steps", "2", "--warmup", "1", "--cpu-baseline", "0"]
+           "--pairs-per-step", "6", "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--queue", queue, "--queue-chunks", "3"]
     r = subprocess.run(cmd, env=dict(os.environ, HIPSIM_THREADS="2"), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -97,3 +101,4 @@ def test_bench_py_two_ranks_on_the_host_simt_interpreter():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["pairs_per_step"] == 6 and out["value"] > 0
     assert len(out["rank_wall_s"]["per_rank"]) == 2 and len(lines[0]) < 6000
+    assert ("(%s)" % queue) in out["config"]["parallelism"]  # static p mod R, or chunks claimed from the shared counter (pairqueue.SharedCounter)
