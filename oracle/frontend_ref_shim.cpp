@@ -8,11 +8,18 @@
 //                                          463-565  computeFeatureProjectedGridAndCompareFeature2D (occupancy + depth / density bits)
 //                                          678-758  ReArrangeGrid / ReArrange_2D and the three re-arrangements
 //                                          839-872  getVoxelNum, getVoxelIndex, contain2DPair
+//                                          947-989  computeEigenVectorsByWeightPCA up to its Eigen::EigenSolver call: f64 centroid, weights
+//                                                   sqrt(2) R - distance, the float 3 x 3 running sums, the division by the weight sum
+//                                          1156-1165 Comput3DDistanceBetweenPoints
 //   include/filter.hpp                     18-88    CFilter::IDPair, CFilter::voxelfilter (std::sort, Q1 phantom entries)
 //   include/pca.h                          16-45    eigenValue, eigenVector, pcaFeature
 //   include/keypoint_detect.hpp            132-147  CKeypointDetect::pruneUnstablePoints
 //                                          119-130, 149-191  cmpBasedOnCurvature, nonMaximaSuppression (std::sort + std::set logic; the
 //                                          radius search behind it is the stand-in KdTreeFLANN of oracle/ref_stubs: exact, d^2 < r^2)
+//                                          60-107   keypointDetectionBasedOnCurvature_adaptive after its PCA call (the threshold loop)
+//   include/pca.h                          228-239  CalculatePcaFeature: eigenvalues -> lamada1..3 and the curvature formula
+//   include/fpfh.hpp                       93-115   FPFHfeature::keyfpfh (the keypoints' histogram rows)
+//   src/common_reg.cpp                     302-313  CRegistration::calOverlap (counting + ratio; the radius search is the stand-in)
 // Output only into oracle/_ref/.
 #include <cmath>
 #include <cstdlib>
@@ -40,6 +47,23 @@ class BSCEncoder : public StereoBinaryFeature {
 #include "bfe_binarize.inc"
 #include "bfe_rearrange.inc"
 #include "bfe_private.inc"
+ public:
+  // computeEigenVectorsByWeightPCA (bfe:940-1035) up to the Eigen::EigenSolver call: returns the covariance the solver would be given
+  bool weightedCovariance(const typename pcl::PointCloud<PointT>::Ptr& input_cloud, const vector<int>& search_indices, int test_index,
+                          Eigen::Matrix<float, 3, 3>& out) {
+#include "bfe_wcov.inc"
+    out = covariance;
+    return true;
+  }
+  float Comput3DDistanceBetweenPoints(const PointT& pt1, const PointT& pt2) {  // bfe:1156-1165 (closing brace of the class follows it there)
+    float dertax, dertay, dertaz, dis;
+    dertax = pt1.x - pt2.x;
+    dertay = pt1.y - pt2.y;
+    dertaz = pt1.z - pt2.z;
+    dis = (dertax) * (dertax) + (dertay) * (dertay) + (dertaz) * (dertaz);
+    dis = sqrt(dis);
+    return dis;
+  }
 };
 
 template <typename PointT>
@@ -57,8 +81,24 @@ class CKeypointDetect {
 #include "kd_prune.inc"
 #include "kd_cmp.inc"
 #include "kd_nms.inc"
+  // keypointDetectionBasedOnCurvature_adaptive (kd:53-111) after its PCA call: `features` come from the caller
+  // (the literal thresholds 50000 / 5000 of kd:83-106 become kUpper / kLower at extraction, so that the loop can be entered at test scale)
+  int kUpper = 50000, kLower = 5000;
+  bool adaptiveTail(std::vector<pcaFeature>& features, pcl::PointIndicesPtr& keypointIndices) {
+#include "kd_adaptive_tail.inc"
+    return true;
+  }
   int _min_point_num_neighborhood;
   float _curvature_non_max_radius;
+  float _ratio_unstable_thre = 0.65f;
+};
+
+// FPFHfeature::keyfpfh (fpfh.hpp:93-115) in a class that declares nothing else
+struct FpfhRow { float histogram[33]; };
+struct FpfhCloud { unsigned width = 0, height = 0; std::vector<FpfhRow> points; };
+typedef std::shared_ptr<FpfhCloud> fpfhFeaturePtr;
+struct FPFHfeatureKey {
+#include "fpfh_keyfpfh.inc"
 };
 }  // namespace ghicp
 
@@ -126,6 +166,73 @@ int ref_voxelfilter(const float* xyz, int n, int stride, float voxel, float* out
   f.voxelfilter(in, out, voxel);
   for (size_t i = 0; i < out->points.size(); i++) { out_xyz[i * 3] = out->points[i].x; out_xyz[i * 3 + 1] = out->points[i].y; out_xyz[i * 3 + 2] = out->points[i].z; }
   return (int)out->points.size();
+}
+
+// computeEigenVectorsByWeightPCA's covariance (bfe:947-989): neighbours = idx[0..cnt) (the radius search's order), test point = test_index.
+int ref_weighted_cov(const float* xyz, int n, const int* idx, int cnt, int test_index, float R, float* out9) {
+  Quiet q;
+  Enc e(R, 7, false);
+  pcl::PointCloud<pcl::PointXYZ>::Ptr cloud(new pcl::PointCloud<pcl::PointXYZ>);
+  cloud->points.resize(n);
+  for (int i = 0; i < n; i++) { cloud->points[i].x = xyz[(size_t)i * 3]; cloud->points[i].y = xyz[(size_t)i * 3 + 1]; cloud->points[i].z = xyz[(size_t)i * 3 + 2]; }
+  std::vector<int> si(idx, idx + cnt);
+  Eigen::Matrix<float, 3, 3> c;
+  if (!e.weightedCovariance(cloud, si, test_index, c)) return 0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) out9[i * 3 + j] = c(i, j);
+  return 1;
+}
+
+// pca.h:233-244: eigenvalues -> pcaFeature values + curvature
+double ref_pca_curvature(float l1, float l2, float l3) {
+  ghicp::pcaFeature feature;
+  Eigen::Vector3f eigen_values(l1, l2, l3);
+#include "pca_curvature.inc"
+  return feature.curvature;
+}
+
+// keypointDetectionBasedOnCurvature_adaptive (kd:53-111) on given PCA features (lam m x 3, count, curvature, xyz); returns the keypoints
+int ref_adaptive_tail(const float* xyz, const float* lam, const int* count, const double* curvature, int m, int min_n, float r_nms, float ratio, int upper,
+                      int lower, int* out_ids) {
+  std::vector<ghicp::pcaFeature> feats((size_t)m);
+  for (int i = 0; i < m; i++) {
+    feats[i].pt.x = xyz[(size_t)i * 3]; feats[i].pt.y = xyz[(size_t)i * 3 + 1]; feats[i].pt.z = xyz[(size_t)i * 3 + 2];
+    feats[i].values.lamada1 = lam[(size_t)i * 3]; feats[i].values.lamada2 = lam[(size_t)i * 3 + 1]; feats[i].values.lamada3 = lam[(size_t)i * 3 + 2];
+    feats[i].ptNum = count[i]; feats[i].curvature = curvature[i]; feats[i].ptId = i;
+  }
+  pcl::PointIndicesPtr idx(new pcl::PointIndices);
+  ghicp::CKeypointDetect<pcl::PointXYZ> kd(min_n, r_nms);
+  kd._ratio_unstable_thre = ratio; kd.kUpper = upper; kd.kLower = lower;
+  kd.adaptiveTail(feats, idx);
+  for (size_t i = 0; i < idx->indices.size(); i++) out_ids[i] = idx->indices[i];
+  return (int)idx->indices.size();
+}
+
+// FPFHfeature::keyfpfh (fpfh.hpp:93-115): rows of the keypoints (source side only is looked at; the target side gets the same input)
+void ref_keyfpfh(const float* hist, int m, const int* kp, int k, float* out) {
+  ghicp::fpfhFeaturePtr s(new ghicp::FpfhCloud), t(new ghicp::FpfhCloud), ks(new ghicp::FpfhCloud), kt(new ghicp::FpfhCloud);
+  s->points.resize(m);
+  for (int i = 0; i < m; i++) std::memcpy(s->points[i].histogram, hist + (size_t)i * 33, 33 * sizeof(float));
+  *t = *s;
+  pcl::PointIndicesPtr si(new pcl::PointIndices), ti(new pcl::PointIndices);
+  si->indices.assign(kp, kp + k);
+  ti->indices.assign(kp, kp + k);
+  ghicp::FPFHfeatureKey f;
+  f.keyfpfh(s, t, si, ti, ks, kt);
+  for (int i = 0; i < k; i++) std::memcpy(out + (size_t)i * 33, ks->points[i].histogram, 33 * sizeof(float));
+}
+
+// CRegistration::calOverlap (common_reg.cpp:294-317): counting loop and ratio over the stand-in exact radius search
+float ref_cal_overlap(const float* c1, int n1, const float* c2, int n2, float thre_dis) {
+  typedef pcl::PointXYZ PointT;
+  pcl::PointCloud<PointT>::Ptr Cloud1(new pcl::PointCloud<PointT>), Cloud2(new pcl::PointCloud<PointT>);
+  Cloud1->points.resize(n1); Cloud2->points.resize(n2);
+  for (int i = 0; i < n1; i++) { Cloud1->points[i].x = c1[(size_t)i * 3]; Cloud1->points[i].y = c1[(size_t)i * 3 + 1]; Cloud1->points[i].z = c1[(size_t)i * 3 + 2]; }
+  for (int i = 0; i < n2; i++) { Cloud2->points[i].x = c2[(size_t)i * 3]; Cloud2->points[i].y = c2[(size_t)i * 3 + 1]; Cloud2->points[i].z = c2[(size_t)i * 3 + 2]; }
+  int overlap_point_num = 0;
+  float overlap_ratio;
+#include "reg_overlap.inc"
+  return overlap_ratio;
 }
 
 // CKeypointDetect::pruneUnstablePoints (keypoint_detect.hpp:132-147).  lam: m x 3 (lamada1..3, stored as double like pca.h:243-245).

@@ -388,6 +388,32 @@ static void bsc_strings(const float* weight147, const float* depth147, int dof, 
   }
 }
 
+// The covariance computeEigenVectorsByWeightPCA hands to its eigen solver (bfe:947-989), under N2 of the numerics contract: centroid in f64,
+// weights sqrt(2) R - distance (float, Q8: negative beyond sqrt(2) R), the six sums in f64 rounded ONCE onto the f32 grid of the matrix
+// scale (the reference keeps float running sums in the radius search's order), then the division by the float-cast weight sum.
+// nb = (squared distance to the test point, point index) in the radius search's order.  Cf = xx, xy, xz, yy, yz, zz.
+static void weighted_covariance(const float* xyz, int stride, const std::vector<std::pair<float, int>>& nb, double radius_w, float Cf[6]) {
+  const int mm = (int)nb.size();
+  double c[3] = {0, 0, 0}, dis_all = 0;
+  for (auto& e : nb) {
+    const float* p = &xyz[(size_t)e.second * stride];
+    for (int d = 0; d < 3; d++) c[d] += (double)p[d];
+    dis_all += radius_w - (double)std::sqrt(e.first);  // Comput3DDistanceBetweenPoints: float sqrt of float d2
+  }
+  for (int d = 0; d < 3; d++) c[d] /= (double)mm;
+  double C[6] = {0, 0, 0, 0, 0, 0};
+  for (auto& e : nb) {
+    const float* p = &xyz[(size_t)e.second * stride];
+    const float w = (float)(radius_w - (double)std::sqrt(e.first));  // Q8: negative beyond sqrt2*R
+    double dx = (double)p[0] - c[0], dy = (double)p[1] - c[1], dz = (double)p[2] - c[2];
+    C[0] += (double)w * dx * dx; C[1] += (double)w * dx * dy; C[2] += (double)w * dx * dz;
+    C[3] += (double)w * dy * dy; C[4] += (double)w * dy * dz; C[5] += (double)w * dz * dz;
+  }
+  quant_grid(C, 6);                 // Matrix3f covariance (N2)
+  const float da = (float)dis_all;  // Matrix3f /= double scalar -> float divisor
+  for (int t = 0; t < 6; t++) Cf[t] = (float)C[t] / da;
+}
+
 static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K, float R, int dof, const int* pattern,
                        uint8_t* feat, float* lcs, double* mean_nb, std::vector<float>* dbg_loc = nullptr, float* dbg_cells294 = nullptr) {
   const double r_search = std::sqrt(3.0) * (double)R;  // bfe:641
@@ -413,25 +439,8 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
     // ---- a5: weighted PCA -> LCS (bfe:940-1035, 121-155)
     float X[3] = {1, 0, 0}, Y[3] = {0, 1, 0}, Z[3] = {0, 0, 1};
     if (mm >= 3) {
-      double c[3] = {0, 0, 0}, dis_all = 0;
-      for (auto& e : nb) {
-        const float* p = &xyz[(size_t)e.second * stride];
-        for (int d = 0; d < 3; d++) c[d] += (double)p[d];
-        dis_all += radius_w - (double)std::sqrt(e.first);  // Comput3DDistanceBetweenPoints: float sqrt of float d2
-      }
-      for (int d = 0; d < 3; d++) c[d] /= (double)mm;
-      double C[6] = {0, 0, 0, 0, 0, 0};
-      for (auto& e : nb) {
-        const float* p = &xyz[(size_t)e.second * stride];
-        const float w = (float)(radius_w - (double)std::sqrt(e.first));  // Q8: negative beyond sqrt2*R
-        double dx = (double)p[0] - c[0], dy = (double)p[1] - c[1], dz = (double)p[2] - c[2];
-        C[0] += (double)w * dx * dx; C[1] += (double)w * dx * dy; C[2] += (double)w * dx * dz;
-        C[3] += (double)w * dy * dy; C[4] += (double)w * dy * dz; C[5] += (double)w * dz * dz;
-      }
-      quant_grid(C, 6);                 // Matrix3f covariance (N2)
-      const float da = (float)dis_all;  // Matrix3f /= double scalar -> float divisor
       float Cf[6];
-      for (int t = 0; t < 6; t++) Cf[t] = (float)C[t] / da;
+      weighted_covariance(xyz, stride, nb, radius_w, Cf);
       double a[3][3] = {{Cf[0], Cf[1], Cf[2]}, {Cf[1], Cf[3], Cf[4]}, {Cf[2], Cf[4], Cf[5]}}, v[3][3];
       jacobi3(a, v);
       int imax = 0, imin = 0;  // bfe:999-1016 (strict compares, first index wins ties)
@@ -1093,6 +1102,21 @@ float orc_bbx_magnitude(const float* xyz, int n, int stride) {
       if (mx[d] < v) mx[d] = v;
     }
   return (float)(mx[0] - mn[0] + mx[1] - mn[1] + mx[2] - mn[2]);
+}
+
+// test hook: the contract's weighted covariance of one keypoint neighbourhood (idx in the radius search's order) -> 3 x 3 row-major
+void orc_weighted_cov(const float* xyz, int stride, const int* idx, int cnt, int test_index, float R, float* out9) {
+  std::vector<std::pair<float, int>> nb((size_t)cnt);
+  const float* q = &xyz[(size_t)test_index * stride];
+  for (int i = 0; i < cnt; i++) {
+    const float* p = &xyz[(size_t)idx[i] * stride];
+    const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+    nb[i] = std::make_pair((dx * dx + dy * dy) + dz * dz, idx[i]);
+  }
+  float Cf[6];
+  orc::weighted_covariance(xyz, stride, nb, std::sqrt(2.0) * (double)R, Cf);
+  const float M[9] = {Cf[0], Cf[1], Cf[2], Cf[1], Cf[3], Cf[4], Cf[2], Cf[4], Cf[5]};
+  for (int i = 0; i < 9; i++) out9[i] = M[i];
 }
 
 // N7 test hook: the contract's atan2f (tests/test_oracle_cpu.py compares it with the correctly rounded value)

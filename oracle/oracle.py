@@ -615,3 +615,65 @@ def ref_cubic_grid(loc, R):
     cells = np.zeros(294, np.float32)
     ref3_lib().ref_cubic_grid(_p(loc, C.c_float), loc.shape[0], C.c_float(R), _p(cells, C.c_float))
     return cells[:147].copy(), cells[147:].copy()
+
+
+# ---- round 3: more of the reference's plain C++ behind the same shim (oracle/frontend_ref_shim.cpp)
+def weighted_cov(xyz, idx, test_index, R):
+    """The contract's weighted covariance of one keypoint neighbourhood (orc::weighted_covariance) -> (3, 3) f32."""
+    xyz, idx = _f32(xyz), np.ascontiguousarray(idx, np.int32)
+    out = np.zeros(9, np.float32)
+    lib().orc_weighted_cov(_p(xyz, C.c_float), xyz.shape[1], _p(idx, C.c_int), int(idx.size), int(test_index), C.c_float(R), _p(out, C.c_float))
+    return out.reshape(3, 3)
+
+
+def ref_weighted_cov(xyz, idx, test_index, R):
+    """binary_feature_extraction.hpp:947-989 itself (float running sums in the given order) -> (3, 3) f32, or None for < 3 neighbours."""
+    xyz = np.ascontiguousarray(_f32(xyz)[:, :3])
+    idx = np.ascontiguousarray(idx, np.int32)
+    out = np.zeros(9, np.float32)
+    ok = ref3_lib().ref_weighted_cov(_p(xyz, C.c_float), xyz.shape[0], _p(idx, C.c_int), int(idx.size), int(test_index), C.c_float(R), _p(out, C.c_float))
+    return out.reshape(3, 3) if ok else None
+
+
+def ref_pca_curvature(lam):
+    """pca.h:228-239 itself for every eigenvalue triplet (m, 3) f32 -> curvature f64."""
+    L = ref3_lib()
+    L.ref_pca_curvature.restype = C.c_double
+    lam = _f32(lam)
+    return np.array([L.ref_pca_curvature(C.c_float(a), C.c_float(b), C.c_float(c)) for a, b, c in lam])
+
+
+def ref_adaptive_tail(xyz, lam, cnt, curv, R_nms, ratio_max=0.65, min_n=20, upper=50000, lower=5000):
+    """keypoint_detect.hpp:60-107 itself (the threshold loop of keypointDetectionBasedOnCurvature_adaptive) on given PCA features."""
+    xyz = np.ascontiguousarray(_f32(xyz)[:, :3])
+    lam, cnt, curv = _f32(lam), np.ascontiguousarray(cnt, np.int32), np.ascontiguousarray(curv, np.float64)
+    out = np.empty(max(1, xyz.shape[0]), np.int32)
+    k = ref3_lib().ref_adaptive_tail(_p(xyz, C.c_float), _p(lam, C.c_float), _p(cnt, C.c_int), _p(curv, C.c_double), xyz.shape[0], int(min_n),
+                                     C.c_float(R_nms), C.c_float(ratio_max), int(upper), int(lower), _p(out, C.c_int))
+    return out[:k].copy()
+
+
+def ref_keyfpfh(hist, kp):
+    """fpfh.hpp:93-115 itself: the histogram rows of the keypoints."""
+    hist, kp = _f32(hist), np.ascontiguousarray(kp, np.int32)
+    out = np.empty((kp.size, 33), np.float32)
+    ref3_lib().ref_keyfpfh(_p(hist, C.c_float), hist.shape[0], _p(kp, C.c_int), int(kp.size), _p(out, C.c_float))
+    return out
+
+
+def ref_cal_overlap(c1, c2, thre_dis):
+    """common_reg.cpp:302-313 itself (counting loop and ratio; exact stand-in radius search)."""
+    L = ref3_lib()
+    L.ref_cal_overlap.restype = C.c_float
+    c1, c2 = np.ascontiguousarray(_f32(c1)[:, :3]), np.ascontiguousarray(_f32(c2)[:, :3])
+    return float(L.ref_cal_overlap(_p(c1, C.c_float), c1.shape[0], _p(c2, C.c_float), c2.shape[0], C.c_float(thre_dis)))
+
+
+def adaptive_tail(xyz, lam, cnt, curv, R_nms, ratio_max=0.65, min_n=20, upper=50000, lower=5000):
+    """The restatement's threshold loop of keypointDetectionBasedOnCurvature_adaptive on given PCA features (orc_adaptive_tail)."""
+    xyz = _f32(xyz)
+    lam, cnt, curv = _f32(lam), np.ascontiguousarray(cnt, np.int32), np.ascontiguousarray(curv, np.float64)
+    out = np.empty(max(1, xyz.shape[0]), np.int32)
+    k = lib().orc_adaptive_tail(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], _p(lam, C.c_float), _p(curv, C.c_double), _p(cnt, C.c_int),
+                                C.c_float(ratio_max), int(min_n), C.c_float(R_nms), C.c_longlong(upper), C.c_longlong(lower), _p(out, C.c_int))
+    return out[:k].copy()

@@ -253,3 +253,78 @@ def test_cubic_grid_contract_against_the_reference_arithmetic(ref3, synth):
     assert wdiff <= 0.002 * 120 * 147, wdiff
     assert np.median(ulps) <= 2 and np.percentile(ulps, 99) <= 64
     assert differing <= 3 and bits <= 4, (differing, bits)
+
+
+def test_curvature_formula_keyfpfh_and_overlap(ref3, synth):
+    """Three small plain-C++ fragments compiled from where they lie: CalculatePcaFeature's curvature (pca.h:228-239; float eigenvalues
+    into double fields, 0 when they sum to 0), FPFHfeature::keyfpfh (fpfh.hpp:93-115) and CRegistration::calOverlap's counting loop and
+    (0.01 + count) / n ratio (common_reg.cpp:302-313, over the stand-in exact radius search)."""
+    O = ref3
+    scan = synth.tls_pair(60_000, pair_id=8).target
+    ds = scan[O.voxel_filter(scan, 0.1)]
+    lam, curv, cnt = O.pca(ds, 0.5)
+    ok = np.isfinite(lam).all(axis=1)
+    np.testing.assert_array_equal(O.ref_pca_curvature(lam[ok][:5000]), curv[ok][:5000])
+    assert O.ref_pca_curvature(np.zeros((1, 3), np.float32))[0] == 0.0
+    rng = np.random.default_rng(12)
+    hist = rng.random((400, 33)).astype(np.float32)
+    kp = rng.choice(400, 57, replace=False).astype(np.int32)
+    np.testing.assert_array_equal(O.ref_keyfpfh(hist, kp), hist[kp])
+    a = ds[:1500]
+    b = (ds[:2500] + np.float32(0.03)).astype(np.float32)[500:]
+    for thr in (0.02, 0.06, 0.3):
+        assert O.ref_cal_overlap(a, b, thr) == O.cal_overlap(a, b, thr)
+
+
+def test_adaptive_keypoint_loop(ref3, synth):
+    """keypointDetectionBasedOnCurvature_adaptive (keypoint_detect.hpp:53-111): the threshold loop after the PCA call, compiled from the
+    reference with its literal 50000 / 5000 made parameters (the loop is never entered below 50000 keypoints), against the restatement's
+    loop on the SAME PCA features.  Exact curvature ties (the reference's unstable sort decides them, see the NMS pin) are removed by an
+    index-proportional perturbation far below the curvature spacing, so that the loop logic -- float ratio stepped by the double
+    constants 0.05 / 0.025, the float-against-double floor test `ratioMax >= 0.65`, the one step back up -- is what is compared."""
+    O = ref3
+    scan = synth.tls_pair(80_000, pair_id=9).target
+    ds = scan[O.voxel_filter(scan, 0.1)]
+    lam, curv, cnt = O.pca(ds, 0.5)
+    curv = np.where(np.isfinite(curv), curv, 0.0) + np.arange(curv.size) * 1e-13
+    plain = O.adaptive_tail(ds, lam, cnt, curv, 0.6, 0.9, upper=10 ** 9, lower=0)
+    entered = 0
+    for ratio in (0.9, 0.8, 0.7):
+        for upper, lower in ((10 ** 6, 10), (plain.size - 1, plain.size // 2), (plain.size // 3, plain.size // 4), (plain.size // 2, plain.size // 2 - 5), (5, 2)):
+            ko = O.adaptive_tail(ds, lam, cnt, curv, 0.6, ratio, upper=upper, lower=lower)
+            kr = O.ref_adaptive_tail(ds, lam, cnt, curv, 0.6, ratio, upper=upper, lower=lower)
+            np.testing.assert_array_equal(kr, ko, err_msg=str((ratio, upper, lower)))
+            entered += int(ko.size != plain.size)
+    assert entered >= 6
+
+
+def test_weighted_covariance_contract_against_the_reference_arithmetic(ref3, synth):
+    """computeEigenVectorsByWeightPCA up to its eigen solver (binary_feature_extraction.hpp:947-989) ITSELF -- f64 centroid, weight
+    sqrt(2) R - distance, nine FLOAT running sums in the radius search's order, division by the weight sum -- on the sqrt(3) R
+    neighbourhoods of real keypoints, against the contract N2 (six f64 sums rounded once onto the f32 grid of the matrix scale).  Like the
+    cubic-grid test this QUANTIFIES the contract's distance from the reference's arithmetic: measured 83 ulp of the matrix scale at worst
+    (float running sums over the 1000-4000 neighbours of a keypoint), and the principal axis the LCS is built from turns by 1.6e-5 rad."""
+    from scipy.spatial import cKDTree
+
+    O = ref3
+    scan = synth.tls_pair(150_000, pair_id=6).target
+    ds = scan[O.voxel_filter(scan, 0.1)]
+    kp, _ = O.keypoints(ds, 0.5, 1.5)
+    assert kp.size >= 100
+    tree = cKDTree(ds.astype(np.float64))
+    R = 1.5
+    worst_ulp, worst_angle = 0.0, 0.0
+    for p in kp[:100]:
+        idx = np.array(tree.query_ball_point(ds[p].astype(np.float64), np.sqrt(3.0) * R), np.int64)
+        d2 = ((ds[idx] - ds[p]).astype(np.float32) ** 2)
+        d2 = (d2[:, 0] + d2[:, 1]) + d2[:, 2]
+        idx = idx[np.lexsort((idx, d2))].astype(np.int32)  # ascending distance, ties by index: the radius search's order
+        co, cr = O.weighted_cov(ds, idx, int(p), R), O.ref_weighted_cov(ds, idx, int(p), R)
+        assert cr is not None
+        scale = float(np.abs(cr).max())
+        worst_ulp = max(worst_ulp, float(np.abs(co.astype(np.float64) - cr.astype(np.float64)).max() / (scale * 2.0 ** -23)))
+        wo, vo = np.linalg.eigh(co.astype(np.float64))
+        wr, vr = np.linalg.eigh(0.5 * (cr + cr.T).astype(np.float64))
+        worst_angle = max(worst_angle, float(np.arccos(min(1.0, abs(vo[:, 2] @ vr[:, 2])))))
+    assert worst_ulp <= 256 and worst_angle < 1e-4, (worst_ulp, worst_angle)
+    assert O.ref_weighted_cov(ds, np.array([0, 1], np.int32), 0, R) is None  # fewer than 3 neighbours: no LCS (bfe:947)
