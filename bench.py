@@ -187,8 +187,6 @@ def main():
     ap.add_argument("--fe-batch-size", type=int, default=32, help="clouds per launch sequence when --fe-batch -1 picks the batched front end")
     ap.add_argument("--fe-batch-streams", type=int, default=4, help="worker contexts of the batched front end")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = every logical CPU of the host; the distinct scenes are cycled)")
-    ap.add_argument("--fe-cus", type=int, default=0, help="compute units reserved for the front-end streams (hipExtStreamCreateWithCUMask; the mask bits "
-                    "interleave over the 8 XCDs, so F bits = F/8 CUs per XCD); the loop contexts get the other CUs.  0 = no partition")
     ap.add_argument("--scene-cache", default="", help="directory that keeps the generated synthetic scenes between runs (the generation is untimed)")
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"], help="pair queue across ranks: static p mod R, or chunks claimed from a shared counter")
     ap.add_argument("--queue-chunks", type=int, default=8, help="--queue dynamic: claims per rank and step (chunk = job / (ranks x this))")
@@ -254,20 +252,6 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(nstream + G * LP)]
     ctxs = [api.Context(local_rank, stream=s) for s in streams]
     fe_ctxs, loop_ctxs = ctxs[:nstream], ctxs[nstream:]
-    if args.fe_cus > 0:  # hard partition of the chip: the solve slots of the persistent pair loop fill every CU they may use (LDS and VGPRs),
-        # so front-end kernels only run beside them on CUs of their own
-        try:
-            ncu = int(torch.cuda.get_device_properties(local_rank).multi_processor_count)
-        except Exception:  # noqa: BLE001
-            ncu = 256
-        F = max(8, min(ncu - 8, args.fe_cus))
-        bits_loop = (1 << (ncu - F)) - 1
-        bits_fe = ((1 << ncu) - 1) ^ bits_loop
-        words = lambda b: [(b >> (32 * i)) & 0xFFFFFFFF for i in range((ncu + 31) // 32)]
-        for c in fe_ctxs:
-            c.set_cu_mask(words(bits_fe))
-        for c in loop_ctxs:
-            c.set_cu_mask(words(bits_loop))
     # ---- which front end: cloud by cloud on `nstream` streams, or ghicp_clouds_recompute batches on a few.  Both give the same bits
     # (tests/test_gpu_batch.py); the choice is a throughput calibration on a sample of this rank's pairs, before the warm-up.
     def fe_sample_rate(batch, nthreads, sample):
@@ -675,9 +659,10 @@ def main():
     try:  # HBM-side traffic of the dominant kernel from the committed PMC passes (counters cannot be collected inside this run)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if dom in pmc:
-            units = (km_batch if dom == "km_solve" else shard_b) if pmc[dom]["per"] in ("solve", "pair") else 1
+            per = pmc[dom]["per"]
+            units = {"solve": km_batch, "pair": shard_b, "pair_iteration": (nb / float(G)) * it_mean, "cloud": clouds_total / max(1, dom_n)}.get(per, 1)
             traffic = int(pmc[dom]["bytes"] * units)
-            traffic_src = "%d B per %s x %.1f, %s" % (pmc[dom]["bytes"], pmc[dom]["per"], units, pmc["source"])
+            traffic_src = "%d B per %s x %.1f, %s" % (pmc[dom]["bytes"], per, units, pmc["source"])
     except (OSError, ValueError, KeyError):
         pass
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -793,7 +778,7 @@ def main():
         "ms_per_iteration": round(ms_iter_single, 4), "ms_per_iteration_in_batch": round(ms_per_step / max(1.0, it_mean), 2),
         "single_pair_latency_s": round(single_latency, 4),
         "batch_ms": {"front_end_thread_s_per_step": round(thread_busy["front_end"] / max(1, args.steps), 2), "front_end_threads": fe_n,
-                     "loop_thread_s_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G, "pipeline": args.pipeline, "fe_cus": args.fe_cus,
+                     "loop_thread_s_per_step": round(thread_busy["loop"] / max(1, args.steps), 2), "loop_groups": G, "pipeline": args.pipeline,
                      "front_end_ms_per_cloud_on_its_stream": round(1e3 * thread_busy["front_end"] / max(1, args.steps) / max(1, 2 * nb), 4)},
         "km_launch_stats": km_stats, "pair_loop_stats": pl_stats,
         "rank_wall_s": {"per_rank": [round(b, 3) for b in busy_all], "imbalance_max_over_mean": round(max(busy_all) / max(1e-9, float(np.mean(busy_all))), 4)},

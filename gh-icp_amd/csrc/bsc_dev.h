@@ -13,6 +13,11 @@ struct BscConst {
 };
 
 constexpr int BT = 256;
+// The sphere's points are compacted into LDS once (x, y, z, squared distance), so that the covariance sweep and the cell sweep -- 27
+// Gaussian weights, 54 f64 LDS atomics per point -- run on full waves: the 27 grid cells around a keypoint hold ~6.4 x the points of
+// the sqrt(3) R sphere, i.e. five lanes of six used to sit out the expensive part.  Spheres with more points than this keep the
+// three global sweeps.
+constexpr int BSC_CAP = 2048;
 
 int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_host, BscConst* out, float* r_search);  // bsc.hip
 
@@ -32,6 +37,8 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   __shared__ float s_axes[9];
   __shared__ double s_stat[3][4];  // per plane: avg_d, sd_d, avg_w, sd_w
   __shared__ unsigned s_bits[4][16];
+  __shared__ float4 s_pts[BSC_CAP];
+  __shared__ int s_scan[17];
   const int tid = threadIdx.x;
   // the keypoint itself: kp holds ORIGINAL indices; find its coordinates through the original cloud copy kept in pts? -> passed via lcs origin
   const float qx = lcs[(size_t)kk * 12 + 9], qy = lcs[(size_t)kk * 12 + 10], qz = lcs[(size_t)kk * 12 + 11];
@@ -57,12 +64,36 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
     }
   });
   sx = gh_block_sum(sx, red); sy = gh_block_sum(sy, red); sz = gh_block_sum(sz, red); sw = gh_block_sum(sw, red);
-  const int mm = (int)gh_block_sum((double)cnt, red);
+  int mm;
+  const int my_base = gh_block_excl_scan(cnt, s_scan, &mm);  // thread-major order of the sphere's points: deterministic
   const double mx = sx / (double)mm, my = sy / (double)mm, mz = sz / (double)mm;
+  const bool packed = mm <= BSC_CAP;
+  if (packed) {  // second global sweep: the same enumeration, hits written behind the thread's base
+    int w = my_base;
+    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+      for (unsigned q = b + tid; q < e; q += BT) {
+        const float4 P = G.pts[q];
+        const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        if (d2 < C.r2s) s_pts[w++] = make_float4(P.x, P.y, P.z, d2);
+      }
+    });
+    __syncthreads();
+  }
 
   // ---- sweep B
   double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-  if (mm >= 3) {
+  if (mm >= 3 && packed) {
+    for (int t = tid; t < mm; t += BT) {
+      const float4 P = s_pts[t];
+      const double w = (double)(float)(C.radius_w - (double)sqrtf(P.w));  // float weight (bfe:975-976), negative beyond sqrt2*R
+      const double ex = (double)P.x - mx, ey = (double)P.y - my, ez = (double)P.z - mz;
+      c00 += w * ex * ex; c01 += w * ex * ey; c02 += w * ex * ez;
+      c11 += w * ey * ey; c12 += w * ey * ez; c22 += w * ez * ez;
+    }
+  } else if (mm >= 3) {
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
       for (unsigned q = b + tid; q < e; q += BT) {
         const float4 P = G.pts[q];
@@ -78,6 +109,8 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
         }
       }
     });
+  }
+  if (mm >= 3) {
     c00 = gh_block_sum(c00, red); c01 = gh_block_sum(c01, red); c02 = gh_block_sum(c02, red);
     c11 = gh_block_sum(c11, red); c12 = gh_block_sum(c12, red); c22 = gh_block_sum(c22, red);
   }
@@ -128,39 +161,49 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   const float X0 = s_axes[0], X1 = s_axes[1], X2 = s_axes[2], Y0 = s_axes[3], Y1 = s_axes[4], Y2 = s_axes[5], Z0 = s_axes[6], Z1 = s_axes[7],
               Z2 = s_axes[8];
 
-  // ---- sweep C
-  gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
-    for (unsigned q = b + tid; q < e; q += BT) {
-      const float4 P = G.pts[q];
-      const float tx = qx - P.x, ty = qy - P.y, tz = qz - P.z;
-      float d2 = tx * tx;
-      d2 += ty * ty;
-      d2 += tz * tz;
-      if (!(d2 < C.r2s)) continue;
-      const float d0 = P.x - qx, d1 = P.y - qy, d2v = P.z - qz;  // bfe:178-180
-      const float loc[3] = {(X0 * d0 + X1 * d1) + X2 * d2v, (Y0 * d0 + Y1 * d1) + Y2 * d2v, (Z0 * d0 + Z1 * d1) + Z2 * d2v};
+  // ---- sweep C: one point of the sphere into the 3 x 7 x 7 cells (bfe:196-373)
+  auto splat = [&](float px, float py, float pz) {
+    const float d0 = px - qx, d1 = py - qy, d2v = pz - qz;  // bfe:178-180
+    const float loc[3] = {(X0 * d0 + X1 * d1) + X2 * d2v, (Y0 * d0 + Y1 * d1) + Y2 * d2v, (Z0 * d0 + Z1 * d1) + Z2 * d2v};
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++) {
-        const float a = loc[pl == 2 ? 1 : 0], bb = loc[pl == 0 ? 1 : 2];
-        const float depth = loc[pl == 0 ? 2 : (pl == 1 ? 1 : 0)] + C.R;
-        for (int j = 0; j < 7; j++) {
-          const float dy = bb - C.centre[j];
-          const float dy2 = dy * dy;
-          if (!(dy2 < C.r2c)) continue;  // dx*dx + dy2 >= dy2 in f32, so this skip is exact
-          for (int i = 0; i < 7; i++) {
-            const float dx = a - C.centre[i];
-            float dd = dx * dx;
-            dd += dy2;
-            if (dd < C.r2c) {
-              const float ew = (float)exp((double)(-dd / C.den));  // expf, correctly rounded (bfe:239)
-              atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);
-              atomicAdd(&s_dsum[i + 7 * j + 49 * pl], (double)depth * (double)ew);
-            }
+    for (int pl = 0; pl < 3; pl++) {
+      const float a = loc[pl == 2 ? 1 : 0], bb = loc[pl == 0 ? 1 : 2];
+      const float depth = loc[pl == 0 ? 2 : (pl == 1 ? 1 : 0)] + C.R;
+      for (int j = 0; j < 7; j++) {
+        const float dy = bb - C.centre[j];
+        const float dy2 = dy * dy;
+        if (!(dy2 < C.r2c)) continue;  // dx*dx + dy2 >= dy2 in f32, so this skip is exact
+        for (int i = 0; i < 7; i++) {
+          const float dx = a - C.centre[i];
+          float dd = dx * dx;
+          dd += dy2;
+          if (dd < C.r2c) {
+            const float ew = (float)exp((double)(-dd / C.den));  // expf, correctly rounded (bfe:239)
+            atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);
+            atomicAdd(&s_dsum[i + 7 * j + 49 * pl], (double)depth * (double)ew);
           }
         }
       }
     }
-  });
+  };
+  if (packed) {
+    for (int t = tid; t < mm; t += BT) {
+      const float4 P = s_pts[t];
+      splat(P.x, P.y, P.z);
+    }
+  } else {
+    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+      for (unsigned q = b + tid; q < e; q += BT) {
+        const float4 P = G.pts[q];
+        const float tx = qx - P.x, ty = qy - P.y, tz = qz - P.z;
+        float d2 = tx * tx;
+        d2 += ty * ty;
+        d2 += tz * tz;
+        if (!(d2 < C.r2s)) continue;
+        splat(P.x, P.y, P.z);
+      }
+    });
+  }
   __syncthreads();
 
   // ---- cell quantities (bfe:333-372)

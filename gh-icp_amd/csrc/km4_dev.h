@@ -286,7 +286,7 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
 // row record (label, listed columns), (2) everything the verdict needs -- the visited / S words and the owner of the <= 3 listed
 // columns, and for a 64-column window of background candidates at the E7 pointer of the row's label: ly, visited / S words, owner.
 template <bool PROF>
-__device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter, long long* q_act) {
+__device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter, long long* q_act, long long* pd) {
   const int n = s.n;
   const double bg = s.bg, eps = s.eps;
   if (lane == 0) { s.stx[0] = (unsigned short)root; s.sty[0] = (unsigned short)K4_NONE; }
@@ -297,12 +297,15 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
   const int lk = min(lane, K4_CAP - 1);
   for (;;) {
     if (PROF) { ++*q_iter; ++*q_act; }
+    const long long t_it0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    int it_type = 0;  // PROF: 0 flagged row, 1 listed-only row, 2 background-tight row with a list, 3 march, 4 ended in a pop
     // ---- round trip 1: the row record
     const double lxv = s.lx[x];
     const int tn = s.tln[x];
     const int lc = s.tlc[x * K4_CAP + lk];
     const int ncnt = k4_cnt(tn);
     const bool bgt = (lxv - bg) < eps;
+    if (PROF) it_type = tn == K4_OVER ? 0 : (!bgt ? 1 : (tn != 0 ? 2 : 3));
     int slot = 0, p = n;
     if (bgt) {  // E7: one scan pointer per distinct label value; everything below ystart is dead for this label as well
       const unsigned long long hit = __ballot(ck == lxv);
@@ -405,10 +408,11 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
         if (lane == slot) cp = min(p, n);
         __builtin_amdgcn_wave_barrier();
         if (outcome == 1) { augment = true; }
-        else if (outcome == 2) continue;
+        else if (outcome == 2) { if (PROF) { pd[it_type]++; pd[5 + it_type] += (long long)__builtin_readcyclecounter() - t_it0; } continue; }
         // outcome 0: x (possibly a row reached by the march: its frame is sp) has no candidate left -> pop below
       }
     }
+    if (PROF && (augment || best != INT_MAX)) { pd[it_type]++; pd[5 + it_type] += (long long)__builtin_readcyclecounter() - t_it0; }
     if (augment) break;
     if (best != INT_MAX) {
       if (lane == 0) { atomicOr(&s.visy[best >> 5], 1u << (best & 31)); s.sty[sp] = (unsigned short)best; }
@@ -420,6 +424,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
       sp--;
       if (sp < 0) return false;
       x = s.stx[sp]; ystart = (int)s.sty[sp] + 1;
+      if (PROF) { pd[4]++; pd[9] += (long long)__builtin_readcyclecounter() - t_it0; }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -526,9 +531,13 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
   s.tln = (unsigned char*)(s.tlo + (size_t)n * K4_CAP);
   (void)lds_bytes;
   const double bg = s.bg, eps = s.eps;
+  // (the flood and the DFS are one wave's work; letting co-resident workgroups use different waves for it -- block id >> 8 & 3 -- was
+  // measured in round 3: 49.04 against 49.08 ms per solve at four problems per CU, no effect, removed)
+  constexpr int sw = 0;
 
   long long c_flood = 0, c_fail = 0, c_pull = 0, c_dfs = 0, q_phase = 0, q_fail = 0, q_rounds = 0, q_iter = 0, q_act = 0, q_frows = 0, q_prows = 0;
   long long pcf[5] = {0, 0, 0, 0, 0};
+  long long pd[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = PROF ? (long long)__builtin_readcyclecounter() : 0;
 
   for (int i = tid; i < n; i += K4_T) { s.lx[i] = P.lx_init[i]; s.ly[i] = 0.0; s.match[i] = (unsigned short)K4_NONE; s.tln[i] = 0; }
@@ -557,7 +566,7 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
       for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; }
       __syncthreads();
       const long long t0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
-      if (wave == 0) {
+      if (wave == sw) {
         int fq = 0;
         const bool fr = k4_flood<PROF>(s, root, lane, &fq, pcf);
         if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
@@ -680,8 +689,8 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
       const long long t2 = PROF ? (long long)__builtin_readcyclecounter() : 0;
       if (PROF) c_pull += t2 - t1;
       // ... then the DFS (wave 0)
-      if (wave == 0) {
-        const bool ok = k4_dfs<PROF>(s, root, lane, &q_iter, &q_act);
+      if (wave == sw) {
+        const bool ok = k4_dfs<PROF>(s, root, lane, &q_iter, &q_act, pd);
         if (!ok && lane == 0) s.sh[SH_BAD] = 3;
       }
       __syncthreads();
@@ -714,6 +723,7 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         P.steps[7] = c_flood; P.steps[8] = c_fail; P.steps[9] = c_pull; P.steps[10] = c_dfs;
         P.steps[11] = (long long)__builtin_readcyclecounter() - t_begin; P.steps[12] = hazard ? 1 : 0;
         for (int k = 0; k < 5; k++) P.steps[13 + k] = pcf[k];
+        for (int k = 0; k < 10; k++) P.steps[18 + k] = pd[k];
       }
     }
   }

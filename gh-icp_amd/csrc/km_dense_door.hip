@@ -108,18 +108,20 @@ int gh_km_solve_sparse_from_dense(ghicp_ctx* ctx, const double* w, int n, double
   hp.status = status_dev;
   long long* dstats = nullptr;
   if (ctx->km_stats) {  // GHICP_KM_STATS=1 (read once per context): stage counters of the solve
-    GH_TRY(ctx->reserve(B_P_PATTERN, 32, &dstats));
-    GH_HIP(hipMemsetAsync(dstats, 0, 24 * sizeof(long long), s));
+    GH_TRY(ctx->reserve(B_P_PATTERN, 40, &dstats));
+    GH_HIP(hipMemsetAsync(dstats, 0, 32 * sizeof(long long), s));
     hp.steps = dstats;
   }
   GH_HIP(hipMemcpyAsync(dp, &hp, sizeof(hp), hipMemcpyHostToDevice, s));
   GH_TRY(gh_km4_launch(ctx, dp, 1, n));
   if (dstats) {
-    long long h[24];
+    long long h[32];
     GH_HIP(hipMemcpyAsync(h, dstats, sizeof(h), hipMemcpyDeviceToHost, s));
     GH_HIP(hipStreamSynchronize(s));
     fprintf(stderr, "[km4 stats] n=%d activations=%lld phases=%lld failed=%lld pull_rounds=%lld dfs_iterations=%lld flood_rows(failed)=%lld rebuilt_rows=%lld | cycles: flood=%lld failed=%lld pull=%lld dfs=%lld total=%lld | hazard=%lld | flood: levels=%lld flagged_rows=%lld cyc_rows=%lld sweeps=%lld cyc_sweeps=%lld\n",
             n, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17]);
+    fprintf(stderr, "[km4 dfs] iterations by kind (count / cycles): flagged row %lld / %lld, listed-only row %lld / %lld, background-tight row with a list %lld / %lld, march %lld / %lld, pop %lld / %lld\n",
+            h[18], h[23], h[19], h[24], h[20], h[25], h[21], h[26], h[22], h[27]);
   }
   return GHICP_OK;
 }

@@ -12,7 +12,16 @@ inline int gh_pca_chunk() {
   return v;
 }
 
-// CHUNK only sets how many neighbour points are staged per barrier pair: every lane still meets the points of a run in the same order
+// CHUNK only sets how many neighbour points are staged per barrier pair.
+// Lane layout: a 0.5 m cell holds ~16 points, so one lane per query point would leave three quarters of the wave idle in the candidate
+// loops.  The wave is therefore split into np query points x g lanes (g = the largest power of two with np * g <= 64): lane (qi, sl)
+// tests the staged candidates t = sl, sl + g, ... against query qi, and the g partial sums of a query are combined by an xor butterfly
+// (fixed order: deterministic, and the same in the single-cloud and the batched front end).  The sums are f64 and go through N2's
+// rounding onto the f32 grid, so the summation order shows up as an ulp on a few points in 10^5, as before.
+__device__ inline double gh_group_sum(double x, int g) {
+  for (int o = 1; o < g; o <<= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
 template <int CHUNK>
 __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, float* __restrict__ lambda, double* __restrict__ curvature,
                                    int* __restrict__ count, float4* sC, int lane) {
@@ -21,8 +30,12 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
   const int cx = key / (G.d.dim[2] * G.d.dim[1]);
   const unsigned qb = G.start[key], qe = G.start[key + 1];
   for (unsigned q0 = qb; q0 < qe; q0 += 64) {
-    const unsigned q = q0 + lane;
-    const bool live = q < qe;
+    const int np = (int)min(64u, qe - q0);
+    int g = 1;
+    while (g * 2 * np <= 64) g *= 2;
+    const int qi = lane / g, sl = lane % g;
+    const unsigned q = q0 + qi;
+    const bool live = qi < np;
     float4 P = make_float4(0, 0, 0, 0);
     if (live) P = G.pts[q];
     // ---- sweep 1: neighbour count and centroid (pca.h:151, pcl::PCA mean)
@@ -34,7 +47,7 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
         for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
         __syncthreads();
         if (live)
-          for (int t = 0; t < cnt; t++) {
+          for (int t = sl; t < cnt; t += g) {
             const float4 Cc = sC[t];
             const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
             float d2 = dx * dx;
@@ -45,6 +58,8 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
         __syncthreads();
       }
     });
+    for (int o = 1; o < g; o <<= 1) k += __shfl_xor(k, o, 64);
+    sx = gh_group_sum(sx, g); sy = gh_group_sum(sy, g); sz = gh_group_sum(sz, g);
     const double mx = sx / (double)k, my = sy / (double)k, mz = sz / (double)k;
     // ---- sweep 2: de-meaned scatter
     double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
@@ -54,7 +69,7 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
         for (int t = lane; t < cnt; t += 64) sC[t] = G.pts[base + t];
         __syncthreads();
         if (live && k >= 3)
-          for (int t = 0; t < cnt; t++) {
+          for (int t = sl; t < cnt; t += g) {
             const float4 Cc = sC[t];
             const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
             float d2 = dx * dx;
@@ -69,7 +84,9 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
         __syncthreads();
       }
     });
-    if (live) {
+    s00 = gh_group_sum(s00, g); s01 = gh_group_sum(s01, g); s02 = gh_group_sum(s02, g);
+    s11 = gh_group_sum(s11, g); s12 = gh_group_sum(s12, g); s22 = gh_group_sum(s22, g);
+    if (live && sl == 0) {
       const unsigned orig = __float_as_uint(P.w);
       float l1 = 0.f, l2 = 0.f, l3 = 0.f;
       double cv = 0.0;

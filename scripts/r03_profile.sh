@@ -11,7 +11,7 @@ SC="--scene-cache /tmp/scenes"
 B1="python $R/bench.py --steps 1 --warmup 1 --distinct 8 --pairs-per-step 512 --cpu-baseline 0 --fe-batch 32 --fe-batch-streams 1 --fe-streams 1 --pipeline 0 $SC"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_a -o a -- $B1 > $O/r03_bench_rocprof_fe1.json 2> $O/r03_rocprof_a.err
 python $R/scripts/rocprof_summary.py /tmp/prof_a $O/r03_kernel_stats_fe_one_stream.txt "$B1" > /dev/null
-B2="python $R/bench.py --steps 2 --warmup 1 --distinct 16 --pairs-per-step 2048 --cpu-baseline 0 $SC"
+B2="python $R/bench.py --steps 2 --warmup 1 --distinct 16 --pairs-per-step 2048 --cpu-baseline 0 --pipeline 0 $SC"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- $B2 > $O/r03_bench_rocprof_default.json 2> $O/r03_rocprof_b.err
 python $R/scripts/rocprof_summary.py /tmp/prof_b $O/r03_kernel_stats_bench.txt "$B2" > /dev/null
 B3="python $R/bench.py --steps 1 --warmup 1 --distinct 8 --pairs-per-step 256 --cpu-baseline 0 --fe-batch 32 --fe-batch-streams 1 --fe-streams 1 --pipeline 0 $SC"
