@@ -49,7 +49,9 @@ CONFIGS = {
     2: dict(name="cfg2: synthetic ETH-like TLS pairs, 1 M pts/scan", hits=1_000_000, voxel=0.1, r=0.5, R=1.5, feature="BSC", corr="KM", dof=6, iou=0.6, B=5376, distinct=64, scaling="weak"),
     3: dict(name="cfg3: synthetic WHU-like TLS pairs, 5 M pts/scan", hits=5_000_000, voxel=0.1, r=0.5, R=1.5, feature="FPFH", corr="NNR", dof=6, iou=0.6, B=16, distinct=2, scaling="weak"),
     4: dict(name="cfg4: 64 3DMatch-like indoor fragment pairs, 100 k pts", hits=100_000, voxel=0.025, r=0.10, R=0.30, feature="BSC", corr="NN", dof=6, iou=0.6, B=64, distinct=64, scaling="strong"),
-    5: dict(name="cfg5: low-overlap levelled TLS pair, 10 M pts/scan", hits=10_000_000, voxel=0.1, r=0.5, R=1.5, feature="BSC", corr="KM", dof=4, iou=0.3, B=8, distinct=2, scaling="weak"),
+    # (scene 0 of cfg5 never converges -- GPU and oracle both stop at the 200-iteration guard the reference does not have --, so the benchmark
+    # pair is scene 1: 77 iterations on both sides, tests/golden/fullsize.json)
+    5: dict(name="cfg5: low-overlap levelled TLS pair, 10 M pts/scan", hits=10_000_000, voxel=0.1, r=0.5, R=1.5, feature="BSC", corr="KM", dof=4, iou=0.3, B=8, distinct=1, scaling="weak", first=1),
 }
 
 
@@ -210,6 +212,7 @@ def main():
     dynamic = args.queue == "dynamic" and world > 1
     if dynamic:  # any rank may claim any pair: every rank holds the same `distinct` scenes
         manifest = [p % distinct for p in range(n_job)]
+    manifest = [CF.get("first", 0) + sid for sid in manifest]  # scene id = seed offset of the synthetic scene
 
     # ---- scenes this rank needs, generated in parallel BEFORE HIP is initialised (fork-safe), untimed
     mine = pq.pairs_for_rank(n_job, rank, world)

@@ -13,10 +13,12 @@ struct BscConst {
 };
 
 constexpr int BT = 256;
-// The sphere's points are compacted into LDS once (x, y, z, squared distance), so that the covariance sweep and the cell sweep -- 27
-// Gaussian weights, 54 f64 LDS atomics per point -- run on full waves: the 27 grid cells around a keypoint hold ~6.4 x the points of
-// the sqrt(3) R sphere, i.e. five lanes of six used to sit out the expensive part.  Spheres with more points than this keep the
-// three global sweeps.
+// The sphere's points are compacted into LDS once (x, y, z, squared distance; after the covariance sweep: their LCS coordinates).  The
+// cell sweep is then CELL-centric: lane = one of the 49 cells of a projection plane, wave = a quarter of the points, every lane
+// accumulates its cell's Gaussian weights in registers over broadcast LDS reads, and the four partial sums of a cell are added in a
+// fixed order.  (Rounds 1-2 were point-centric: 54 f64 LDS atomics per point into 147 addresses -- the kernel was bound by the
+// LDS atomic rate, 7 ms per 32 clouds, and its sums depended on the atomics' arrival order.)  Spheres with more points than this keep
+// the point-centric global sweeps.
 constexpr int BSC_CAP = 2048;
 
 int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_host, BscConst* out, float* r_search);  // bsc.hip
@@ -38,6 +40,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   __shared__ double s_stat[3][4];  // per plane: avg_d, sd_d, avg_w, sd_w
   __shared__ unsigned s_bits[4][16];
   __shared__ float4 s_pts[BSC_CAP];
+  __shared__ double s_part[4][147][2];
   __shared__ int s_scan[17];
   const int tid = threadIdx.x;
   // the keypoint itself: kp holds ORIGINAL indices; find its coordinates through the original cloud copy kept in pts? -> passed via lcs origin
@@ -187,9 +190,42 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
     }
   };
   if (packed) {
-    for (int t = tid; t < mm; t += BT) {
+    for (int t = tid; t < mm; t += BT) {  // into the LCS (bfe:178-180), in place
       const float4 P = s_pts[t];
-      splat(P.x, P.y, P.z);
+      const float d0 = P.x - qx, d1 = P.y - qy, d2v = P.z - qz;
+      s_pts[t] = make_float4((X0 * d0 + X1 * d1) + X2 * d2v, (Y0 * d0 + Y1 * d1) + Y2 * d2v, (Z0 * d0 + Z1 * d1) + Z2 * d2v, 0.f);
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    double pn[3] = {0.0, 0.0, 0.0}, dsm[3] = {0.0, 0.0, 0.0};
+    if (lane < 49) {
+      const float ci = C.centre[lane % 7], cj = C.centre[lane / 7];
+      for (int t = wave; t < mm; t += 4) {
+        const float4 L = s_pts[t];  // the same address in every lane: a broadcast read
+        const float loc[3] = {L.x, L.y, L.z};
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+          const float a = loc[pl == 2 ? 1 : 0], bb = loc[pl == 0 ? 1 : 2];
+          const float depth = loc[pl == 0 ? 2 : (pl == 1 ? 1 : 0)] + C.R;
+          const float dy = bb - cj;
+          const float dy2 = dy * dy;
+          const float dx = a - ci;
+          float dd = dx * dx;
+          dd += dy2;
+          if (dy2 < C.r2c && dd < C.r2c) {
+            const float ew = (float)exp((double)(-dd / C.den));  // expf, correctly rounded (bfe:239)
+            pn[pl] += (double)ew;
+            dsm[pl] += (double)depth * (double)ew;
+          }
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) { s_part[wave][lane + 49 * pl][0] = pn[pl]; s_part[wave][lane + 49 * pl][1] = dsm[pl]; }
+    }
+    __syncthreads();
+    if (tid < 147) {
+      s_pnum[tid] = ((s_part[0][tid][0] + s_part[1][tid][0]) + s_part[2][tid][0]) + s_part[3][tid][0];
+      s_dsum[tid] = ((s_part[0][tid][1] + s_part[1][tid][1]) + s_part[2][tid][1]) + s_part[3][tid][1];
     }
   } else {
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {

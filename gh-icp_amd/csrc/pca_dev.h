@@ -29,6 +29,20 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
   const int cy = (key / G.d.dim[2]) % G.d.dim[1];
   const int cx = key / (G.d.dim[2] * G.d.dim[1]);
   const unsigned qb = G.start[key], qe = G.start[key + 1];
+  // The candidates of a cell are the points of its 27-cell block: 9 runs, ~430 points at TLS density.  When they fit the tile they are
+  // staged ONCE, run after run, and both sweeps of every pass over the cell read them from LDS (one load phase per cell instead of 18
+  // load-barrier-compute phases); larger blocks go through the tile chunk by chunk.  Either way a lane meets the candidates in the same order.
+  unsigned total = 0;
+  gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) { total += re - rb; });
+  const bool resident = total <= (unsigned)CHUNK;
+  if (resident) {
+    unsigned w = 0;
+    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
+      for (unsigned t = rb + lane; t < re; t += 64) sC[w + (t - rb)] = G.pts[t];
+      w += re - rb;
+    });
+    __syncthreads();
+  }
   for (unsigned q0 = qb; q0 < qe; q0 += 64) {
     const int np = (int)min(64u, qe - q0);
     int g = 1;
@@ -41,6 +55,17 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
     // ---- sweep 1: neighbour count and centroid (pca.h:151, pcl::PCA mean)
     int k = 0;
     double sx = 0, sy = 0, sz = 0;
+    if (resident) {
+      if (live)
+        for (int t = sl; t < (int)total; t += g) {
+          const float4 Cc = sC[t];
+          const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
+          float d2 = dx * dx;
+          d2 += dy * dy;
+          d2 += dz * dz;
+          if (d2 < r2) { k++; sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z; }
+        }
+    } else
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
       for (unsigned base = rb; base < re; base += CHUNK) {
         const int cnt = min((unsigned)CHUNK, re - base);
@@ -63,6 +88,21 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
     const double mx = sx / (double)k, my = sy / (double)k, mz = sz / (double)k;
     // ---- sweep 2: de-meaned scatter
     double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+    if (resident) {
+      if (live && k >= 3)
+        for (int t = sl; t < (int)total; t += g) {
+          const float4 Cc = sC[t];
+          const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
+          float d2 = dx * dx;
+          d2 += dy * dy;
+          d2 += dz * dz;
+          if (d2 < r2) {
+            const double ex = (double)Cc.x - mx, ey = (double)Cc.y - my, ez = (double)Cc.z - mz;
+            s00 += ex * ex; s01 += ex * ey; s02 += ex * ez;
+            s11 += ey * ey; s12 += ey * ez; s22 += ez * ez;
+          }
+        }
+    } else
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
       for (unsigned base = rb; base < re; base += CHUNK) {
         const int cnt = min((unsigned)CHUNK, re - base);
