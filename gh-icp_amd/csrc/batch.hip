@@ -229,15 +229,11 @@ __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__
                                                       const unsigned* __restrict__ cells, const int* __restrict__ ncells, int* __restrict__ counter,
                                                       float r2, float* __restrict__ lambda, double* __restrict__ curvature, int* __restrict__ count) {
   __shared__ float4 sC[CHUNK];
-  __shared__ int s_cell;
   const int lane = threadIdx.x;
   const int nc = *ncells;
-  for (;;) {
-    if (lane == 0) s_cell = atomicAdd(counter, 1);
+  (void)counter;
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {  // static deal of the occupied cells (see pca.hip:k_pca_cells)
     __syncthreads();
-    const int c = __builtin_amdgcn_readfirstlane(s_cell);
-    __syncthreads();
-    if (c >= nc) break;
     const unsigned gkey = cells[c];
     const int b = fb_find_u(D->cb1, D->nb, gkey);
     GridArgs G;

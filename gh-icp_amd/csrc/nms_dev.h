@@ -5,25 +5,49 @@
 #include "devmath.h"
 
 // Exact greedy NMS in ONE launch: a single 256-thread workgroup walks the rank-ordered candidates in chunks of 256.
-//   (1) every candidate of the chunk is tested against the keypoints selected so far (an LDS list read with
-//       broadcast loads; selected keypoints are >= R apart, so there are few -- beyond NMS_SEL_CAP the per-cell linked
-//       lists in global memory take over);
+//   (1) every candidate of the chunk is tested against the keypoints selected so far that lie in the 3 x 3 COLUMNS (x, y cells of side
+//       R, any z) around it: per-column linked lists in LDS, ~2 keypoints to test instead of the several hundred of the whole list
+//       (round 2 swept the whole LDS list: 3.6 ms per cloud at cfg2).  Clouds with more columns than NMS_COL_CAP sweep the list as
+//       before, and beyond NMS_SEL_CAP keypoints the per-cell linked lists in global memory take over;
 //   (2) the four waves then take turns in rank order: a wave first drops lanes that lie within R of a keypoint a
 //       previous wave of this chunk just added, then resolves its own 64 lanes greedily with ballots -- the lowest
 //       surviving lane is selected, its coordinates are broadcast with v_readlane, lanes within R die, repeat;
 //   (3) winners are appended (rank order) to the output, the LDS list and the global grid.
 constexpr int NMS_T = 256;
 constexpr int NMS_SEL_CAP = 3072;  // selected keypoints kept in LDS as float4 (48 KB)
+constexpr int NMS_COL_CAP = 16384; // (x, y) columns with an LDS list head (32 KB): 190 m x 190 m at R = 1.5 m
+constexpr unsigned short NMS_NONE = 0xFFFF;
 // cand[ord[r]] - idx_sub = the point index that is written for rank r (idx_sub: offset of the cloud in a batch's concatenated arrays)
 __device__ inline void gh_nms_greedy_cloud(const float* __restrict__ cpts, int c, const GridDesc& g, float r2, int* __restrict__ head,
                                            int* __restrict__ next, const int* __restrict__ cand, const int* __restrict__ ord,
                                            int* __restrict__ kp, int* __restrict__ kcount, int idx_sub) {
 
   __shared__ float4 sel_pts[NMS_SEL_CAP];
+  __shared__ unsigned short col_head[NMS_COL_CAP], sel_next[NMS_SEL_CAP];
   __shared__ int s_nsel;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncol = g.dim[0] * g.dim[1];
+  const bool cols = ncol <= NMS_COL_CAP;
   if (tid == 0) s_nsel = 0;
+  if (cols)
+    for (int i = tid; i < ncol; i += NMS_T) col_head[i] = NMS_NONE;
   __syncthreads();
+  // keypoints of the 3 x 3 columns around (px, py): anything within R of the point lies there (column side >= R)
+  auto col_hit = [&](float px, float py, float pz) -> bool {
+    const int cx = gh_cell_coord(px, g.mn[0], g.inv, g.dim[0]);
+    const int cy = gh_cell_coord(py, g.mn[1], g.inv, g.dim[1]);
+    for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dim[0] - 1); x++)
+      for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dim[1] - 1); y++)
+        for (unsigned j = col_head[x * g.dim[1] + y]; j != NMS_NONE; j = sel_next[j]) {
+          const float4 q = sel_pts[j];
+          const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+          float d2 = dx * dx;
+          d2 += dy * dy;
+          d2 += dz * dz;
+          if (d2 < r2) return true;
+        }
+    return false;
+  };
   auto grid_hit = [&](float px, float py, float pz) -> bool {
     const int cx = gh_cell_coord(px, g.mn[0], g.inv, g.dim[0]);
     const int cy = gh_cell_coord(py, g.mn[1], g.inv, g.dim[1]);
@@ -48,7 +72,9 @@ __device__ inline void gh_nms_greedy_cloud(const float* __restrict__ cpts, int c
     if (alive) { px = cpts[(size_t)r * 3]; py = cpts[(size_t)r * 3 + 1]; pz = cpts[(size_t)r * 3 + 2]; }
     const int nsel0 = s_nsel;  // keypoints selected before this chunk
     if (alive) {
-      if (nsel0 <= NMS_SEL_CAP) {
+      if (cols && nsel0 <= NMS_SEL_CAP) {
+        alive = !col_hit(px, py, pz);
+      } else if (nsel0 <= NMS_SEL_CAP) {
         // no early exit inside a group of 8: the broadcast ds_read_b128 of a group are issued back to back
         bool hit = false;
         for (int j0 = 0; j0 < nsel0 && !hit; j0 += 8) {
@@ -112,6 +138,17 @@ __device__ inline void gh_nms_greedy_cloud(const float* __restrict__ cpts, int c
           const int cz = gh_cell_coord(pz, g.mn[2], g.inv, g.dim[2]);
           const int old = atomicExch(&head[((unsigned)cx * g.dim[1] + cy) * g.dim[2] + cz], r);
           __hip_atomic_store(&next[r], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cols) {  // the winners of this wave into their column lists, one at a time (two winners may share a column)
+          for (unsigned long long pk = picked; pk; pk &= pk - 1ull) {
+            const int k = (int)__ffsll((long long)pk) - 1;
+            if (lane == k && pos < NMS_SEL_CAP) {
+              const int col = gh_cell_coord(px, g.mn[0], g.inv, g.dim[0]) * g.dim[1] + gh_cell_coord(py, g.mn[1], g.inv, g.dim[1]);
+              sel_next[pos] = col_head[col];
+              col_head[col] = (unsigned short)pos;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
         }
         __threadfence_block();
         if (lane == 0) s_nsel = nsel1 + __popcll(picked);

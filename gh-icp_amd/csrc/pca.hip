@@ -22,15 +22,14 @@ __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __
                                                    int* __restrict__ counter, float r2, float* __restrict__ lambda,
                                                    double* __restrict__ curvature, int* __restrict__ count) {
   __shared__ float4 sC[CHUNK];
-  __shared__ int s_cell;
   const int lane = threadIdx.x;
   const int nc = *ncells;
-  for (;;) {
-    if (lane == 0) s_cell = atomicAdd(counter, 1);
+  (void)counter;
+  // cells are dealt out statically (block b takes cells b, b + grid, ...): the round-2 version popped ONE cell per atomicAdd on a single
+  // global counter, and ~450 k pops per batch of 32 clouds, serialised in L2, were the kernel's whole run time (5.9 ms whatever the
+  // arithmetic inside cost: profiles/r03_kernel_stats_fe_one_stream*.txt)
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
     __syncthreads();
-    const int c = __builtin_amdgcn_readfirstlane(s_cell);
-    __syncthreads();
-    if (c >= nc) break;
     gh_pca_cell<CHUNK>(G, cells[c], r2, lambda, curvature, count, sC, lane);
   }
 }
