@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_fb_cell_start(const unsigned* __restric
 template <int CHUNK>
 __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__ D, const float4* __restrict__ pts, const unsigned* __restrict__ start,
                                                       const unsigned* __restrict__ cells, const int* __restrict__ ncells, int* __restrict__ counter,
-                                                      float r2, float* __restrict__ lambda, double* __restrict__ curvature, int* __restrict__ count) {
+                                                      float r2, double* __restrict__ scat, int* __restrict__ count) {
   __shared__ float4 sC[CHUNK];
   const int lane = threadIdx.x;
   const int nc = *ncells;
@@ -238,8 +238,14 @@ __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__
     const int b = fb_find_u(D->cb1, D->nb, gkey);
     GridArgs G;
     G.d = D->g1[b]; G.pts = pts; G.start = start + D->cb1[b];
-    gh_pca_cell<CHUNK>(G, gkey - D->cb1[b], r2, lambda, curvature, count, sC, lane);
+    gh_pca_cell<CHUNK>(G, gkey - D->cb1[b], r2, scat, count, sC, lane);
   }
+}
+
+__global__ __launch_bounds__(256) void k_fb_pca_eigen(const double* __restrict__ scat, const int* __restrict__ count, int m, float* __restrict__ lambda,
+                                                      double* __restrict__ curvature) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) gh_pca_eigen_point(scat, count, i, lambda, curvature);
 }
 
 // keypoint_detect.hpp:132-147 (pca.hip:k_prune_flags)
@@ -567,12 +573,11 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   ctx->kt_end(KT_FB_GRID, ku);
   const float r2_pca = (float)((double)r_pca * (double)r_pca);  // pcl radiusSearch: static_cast<float>(radius*radius)
   hipEvent_t kt = ctx->kt_begin(KT_PCA);
-  if (gh_pca_chunk() == 256)
-    hipLaunchKernelGGL(k_fb_pca_cells<256>, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells, (const int*)misc,
-                       misc + 1, r2_pca, lambda, curv, count);
-  else
-    hipLaunchKernelGGL(k_fb_pca_cells<PCA_CHUNK>, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells,
-                       (const int*)misc, misc + 1, r2_pca, lambda, curv, count);
+  double* scat;
+  GH_TRY(ctx->reserve(B_FE_SCATTER, (size_t)M * 6 + 6, &scat));
+  hipLaunchKernelGGL(k_fb_pca_cells<PCA_CHUNK>, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells,
+                     (const int*)misc, misc + 1, r2_pca, scat, count);
+  hipLaunchKernelGGL(k_fb_pca_eigen, dim3(cdiv(M, 256)), dim3(256), 0, s, (const double*)scat, (const int*)count, M, lambda, curv);
   ctx->kt_end(KT_PCA, kt);
   hipEvent_t kp = ctx->kt_begin(KT_FB_PRUNE);
   hipLaunchKernelGGL(k_fb_prune_flags, dim3(cdiv(M, 256)), dim3(256), 0, s, lambda, count, M, cfg.ratio_max, cfg.min_neighbors, flags);

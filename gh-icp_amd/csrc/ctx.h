@@ -66,7 +66,7 @@ enum BufSlot {
   B_GRID2_KEYS, B_GRID2_KEYS2, B_GRID2_VALS, B_GRID2_VALS2, B_GRID2_START, B_GRID2_PTS,
   // front end
   B_FE_LAMBDA, B_FE_CURV, B_FE_COUNT, B_FE_CAND, B_FE_STATE, B_FE_KP, B_FE_SORTK, B_FE_SORTK2, B_FE_SORTV, B_FE_SORTV2, B_FE_CPTS,
-  B_FE_FLAGS, B_FE_SCAN,
+  B_FE_FLAGS, B_FE_SCAN, B_FE_SCATTER,
   // pair pipeline
   B_P_KEEP_S, B_P_KEEP_T, B_P_DS_S, B_P_DS_T, B_P_KP_S, B_P_KP_T, B_P_KPXYZ_S, B_P_KPXYZ_T, B_P_FEAT_S, B_P_FEAT_T, B_P_LCS,
   B_P_FD, B_P_MISC, B_P_PATTERN,

@@ -19,8 +19,7 @@ namespace {
 
 template <int CHUNK>
 __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __restrict__ cells, const int* __restrict__ ncells,
-                                                   int* __restrict__ counter, float r2, float* __restrict__ lambda,
-                                                   double* __restrict__ curvature, int* __restrict__ count) {
+                                                   int* __restrict__ counter, float r2, double* __restrict__ scat, int* __restrict__ count) {
   __shared__ float4 sC[CHUNK];
   const int lane = threadIdx.x;
   const int nc = *ncells;
@@ -30,8 +29,14 @@ __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __
   // arithmetic inside cost: profiles/r03_kernel_stats_fe_one_stream*.txt)
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
     __syncthreads();
-    gh_pca_cell<CHUNK>(G, cells[c], r2, lambda, curvature, count, sC, lane);
+    gh_pca_cell<CHUNK>(G, cells[c], r2, scat, count, sC, lane);
   }
+}
+
+__global__ __launch_bounds__(256) void k_pca_eigen(const double* __restrict__ scat, const int* __restrict__ count, long long m, float* __restrict__ lambda,
+                                                   double* __restrict__ curvature) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i < m) gh_pca_eigen_point(scat, count, i, lambda, curvature);
 }
 
 // keypoint_detect.hpp:132-147: float ratios of the (f32-valued) double eigenvalues; NaN fails
@@ -67,8 +72,10 @@ int gh_pca_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float 
   const float r2 = (float)((double)radius * (double)radius);  // pcl radiusSearch: static_cast<float>(radius*radius)
   const int blocks = ctx->num_cu * 20;
   hipEvent_t kt = ctx->kt_begin(KT_PCA);
-  if (gh_pca_chunk() == 256) hipLaunchKernelGGL(k_pca_cells<256>, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, lambda, curvature, count);
-  else hipLaunchKernelGGL(k_pca_cells<PCA_CHUNK>, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, lambda, curvature, count);
+  double* scat;
+  GH_TRY(ctx->reserve(B_FE_SCATTER, (size_t)m * 6 + 6, &scat));
+  hipLaunchKernelGGL(k_pca_cells<PCA_CHUNK>, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, scat, count);
+  hipLaunchKernelGGL(k_pca_eigen, dim3(cdiv(m, 256)), dim3(256), 0, s, (const double*)scat, (const int*)count, m, lambda, curvature);
   ctx->kt_end(KT_PCA, kt);
   GH_HIP(hipGetLastError());
   return GHICP_OK;

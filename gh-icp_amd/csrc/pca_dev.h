@@ -7,10 +7,6 @@
 #include <cstdlib>
 
 constexpr int PCA_CHUNK = 512;  // LDS tile of neighbour points (8 KB: 5 waves per SIMD)
-inline int gh_pca_chunk() {
-  static const int v = PCA_CHUNK;
-  return v;
-}
 
 // CHUNK only sets how many neighbour points are staged per barrier pair.
 // Lane layout: a 0.5 m cell holds ~16 points, so one lane per query point would leave three quarters of the wave idle in the candidate
@@ -23,8 +19,7 @@ __device__ inline double gh_group_sum(double x, int g) {
   return x;
 }
 template <int CHUNK>
-__device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, float* __restrict__ lambda, double* __restrict__ curvature,
-                                   int* __restrict__ count, float4* sC, int lane) {
+__device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, double* __restrict__ scat, int* __restrict__ count, float4* sC, int lane) {
   const int cz = key % G.d.dim[2];
   const int cy = (key / G.d.dim[2]) % G.d.dim[1];
   const int cx = key / (G.d.dim[2] * G.d.dim[1]);
@@ -126,30 +121,43 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, fl
     });
     s00 = gh_group_sum(s00, g); s01 = gh_group_sum(s01, g); s02 = gh_group_sum(s02, g);
     s11 = gh_group_sum(s11, g); s12 = gh_group_sum(s12, g); s22 = gh_group_sum(s22, g);
-    if (live && sl == 0) {
+    if (live && sl == 0) {  // the eigen-solve of the scatter is a kernel of its own (gh_pca_eigen_point): here only np lanes of 64 hold a point
       const unsigned orig = __float_as_uint(P.w);
-      float l1 = 0.f, l2 = 0.f, l3 = 0.f;
-      double cv = 0.0;
-      if (k >= 3) {  // pca.h:209
-        double S[6] = {s00, s01, s02, s11, s12, s22};
-        gh_quant_grid(S, 6);  // N2: pcl::PCA's Matrix3f
-        double a00 = (double)(float)S[0], a01 = (double)(float)S[1], a02 = (double)(float)S[2], a11 = (double)(float)S[3],
-               a12 = (double)(float)S[4], a22 = (double)(float)S[5];
-        double V[9];
-        gh_jacobi3(a00, a01, a02, a11, a12, a22, V);
-        double e0 = a00, e1 = a11, e2 = a22, t;  // ascending sort
-        if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
-        if (e1 > e2) { t = e1; e1 = e2; e2 = t; }
-        if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
-        l1 = (float)e2; l2 = (float)e1; l3 = (float)e0;
-        const double d1 = (double)l1, d2_ = (double)l2, d3 = (double)l3;
-        cv = ((d1 + d2_ + d3) == 0.0) ? 0.0 : d3 / (d1 + d2_ + d3);  // pca.h:240-247
-      }
-      lambda[(size_t)orig * 3] = l1;
-      lambda[(size_t)orig * 3 + 1] = l2;
-      lambda[(size_t)orig * 3 + 2] = l3;
-      curvature[orig] = cv;
+      double* o = scat + (size_t)orig * 6;
+      o[0] = s00; o[1] = s01; o[2] = s02; o[3] = s11; o[4] = s12; o[5] = s22;
       count[orig] = k;
     }
   }
+}
+
+// pcl::PCA's eigenvalues of one point from its neighbourhood's scatter sums (pca.h:218-223) and the curvature of pca.h:232-239: one
+// THREAD per point.  (Inside the per-cell kernel this part -- N2's rounding, 24 Jacobi rotations with their f64 divisions and square
+// roots -- ran on the ~16 lanes of a wave that hold a point and was the kernel's run time: neither the lane split of the candidate
+// loops, nor the resident tile, nor dropping the work counter moved it by 2 %.)
+__device__ inline void gh_pca_eigen_point(const double* __restrict__ scat, const int* __restrict__ count, long long i, float* __restrict__ lambda,
+                                          double* __restrict__ curvature) {
+  const int k = count[i];
+  float l1 = 0.f, l2 = 0.f, l3 = 0.f;
+  double cv = 0.0;
+  if (k >= 3) {  // pca.h:209
+    double S[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) S[t] = scat[(size_t)i * 6 + t];
+    gh_quant_grid(S, 6);  // N2: pcl::PCA's Matrix3f
+    double a00 = (double)(float)S[0], a01 = (double)(float)S[1], a02 = (double)(float)S[2], a11 = (double)(float)S[3],
+           a12 = (double)(float)S[4], a22 = (double)(float)S[5];
+    double V[9];
+    gh_jacobi3(a00, a01, a02, a11, a12, a22, V);
+    double e0 = a00, e1 = a11, e2 = a22, t;  // ascending sort
+    if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
+    if (e1 > e2) { t = e1; e1 = e2; e2 = t; }
+    if (e0 > e1) { t = e0; e0 = e1; e1 = t; }
+    l1 = (float)e2; l2 = (float)e1; l3 = (float)e0;
+    const double d1 = (double)l1, d2_ = (double)l2, d3 = (double)l3;
+    cv = ((d1 + d2_ + d3) == 0.0) ? 0.0 : d3 / (d1 + d2_ + d3);  // pca.h:240-247
+  }
+  lambda[(size_t)i * 3] = l1;
+  lambda[(size_t)i * 3 + 1] = l2;
+  lambda[(size_t)i * 3 + 2] = l3;
+  curvature[i] = cv;
 }
