@@ -13,12 +13,11 @@ struct BscConst {
 };
 
 constexpr int BT = 256;
-// The sphere's points are compacted into LDS once (x, y, z, squared distance; after the covariance sweep: their LCS coordinates).  The
-// cell sweep is then CELL-centric: lane = one of the 49 cells of a projection plane, wave = a quarter of the points, every lane
-// accumulates its cell's Gaussian weights in registers over broadcast LDS reads, and the four partial sums of a cell are added in a
-// fixed order.  (Rounds 1-2 were point-centric: 54 f64 LDS atomics per point into 147 addresses -- the kernel was bound by the
-// LDS atomic rate, 7 ms per 32 clouds, and its sums depended on the atomics' arrival order.)  Spheres with more points than this keep
-// the point-centric global sweeps.
+// The sphere's points are compacted into LDS once (x, y, z, squared distance; after the covariance sweep: their LCS coordinates), and
+// the cell sweep works on (point, plane, 3 x 3 neighbour cell) items so that the f64 exp of the Gaussian weights -- where the kernel's
+// time goes -- runs on nearly full waves (see the sweep).  Measured on 32 cfg2 clouds (profiles/r03_kernel_stats_fe_one_stream*.txt):
+// point-centric with a 7 x 7 scan per point (rounds 1-2) 7.0 ms, lane-per-cell with register sums 6.4 ms -- both evaluate the exp under
+// ~1-in-6 divergence.  Spheres with more points than BSC_CAP keep the point-centric global sweeps.
 constexpr int BSC_CAP = 2048;
 
 int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_host, BscConst* out, float* r_search);  // bsc.hip
@@ -40,7 +39,6 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   __shared__ double s_stat[3][4];  // per plane: avg_d, sd_d, avg_w, sd_w
   __shared__ unsigned s_bits[4][16];
   __shared__ float4 s_pts[BSC_CAP];
-  __shared__ double s_part[4][147][2];
   __shared__ int s_scan[17];
   const int tid = threadIdx.x;
   // the keypoint itself: kp holds ORIGINAL indices; find its coordinates through the original cloud copy kept in pts? -> passed via lcs origin
@@ -196,36 +194,36 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
       s_pts[t] = make_float4((X0 * d0 + X1 * d1) + X2 * d2v, (Y0 * d0 + Y1 * d1) + Y2 * d2v, (Z0 * d0 + Z1 * d1) + Z2 * d2v, 0.f);
     }
     __syncthreads();
+    // Work item = (point, plane, one of the 3 x 3 cells around the point's own cell): a point only reaches cells within 1.5 u of it, i.e.
+    // the cell it projects into and that cell's neighbours, so 9 candidates per plane replace the 49-cell scan and ~7 of the 9 lanes
+    // of an item evaluate a Gaussian weight -- the f64 exp, which is what this kernel's time goes to, runs on ~3/4 full waves instead of
+    // under the 1-in-6 divergence of a lane-per-cell or lane-per-point layout.  7 items per wave (63 lanes).
     const int wave = tid >> 6, lane = tid & 63;
-    double pn[3] = {0.0, 0.0, 0.0}, dsm[3] = {0.0, 0.0, 0.0};
-    if (lane < 49) {
-      const float ci = C.centre[lane % 7], cj = C.centre[lane / 7];
-      for (int t = wave; t < mm; t += 4) {
-        const float4 L = s_pts[t];  // the same address in every lane: a broadcast read
-        const float loc[3] = {L.x, L.y, L.z};
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-          const float a = loc[pl == 2 ? 1 : 0], bb = loc[pl == 0 ? 1 : 2];
-          const float depth = loc[pl == 0 ? 2 : (pl == 1 ? 1 : 0)] + C.R;
-          const float dy = bb - cj;
+    const int sub = lane / 9, slot = lane % 9;
+    const int di = slot % 3 - 1, dj = slot / 3 - 1;
+    const float inv_u = 1.0f / C.u;
+    const int nitem = mm * 3;
+    for (int base = 0; base < nitem; base += 28) {
+      const int w = base + wave * 7 + sub;
+      if (lane < 63 && w < nitem) {
+        const int t = w / 3, pl = w - 3 * t;
+        const float4 L = s_pts[t];
+        const float a = pl == 2 ? L.y : L.x, bb = pl == 0 ? L.y : L.z;
+        const float depth = (pl == 0 ? L.z : (pl == 1 ? L.y : L.x)) + C.R;
+        const int i = (int)floorf((a + C.R) * inv_u) + di, j = (int)floorf((bb + C.R) * inv_u) + dj;
+        if (i >= 0 && i < 7 && j >= 0 && j < 7) {
+          const float dy = bb - C.centre[j];
           const float dy2 = dy * dy;
-          const float dx = a - ci;
+          const float dx = a - C.centre[i];
           float dd = dx * dx;
           dd += dy2;
           if (dy2 < C.r2c && dd < C.r2c) {
             const float ew = (float)exp((double)(-dd / C.den));  // expf, correctly rounded (bfe:239)
-            pn[pl] += (double)ew;
-            dsm[pl] += (double)depth * (double)ew;
+            atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);
+            atomicAdd(&s_dsum[i + 7 * j + 49 * pl], (double)depth * (double)ew);
           }
         }
       }
-#pragma unroll
-      for (int pl = 0; pl < 3; pl++) { s_part[wave][lane + 49 * pl][0] = pn[pl]; s_part[wave][lane + 49 * pl][1] = dsm[pl]; }
-    }
-    __syncthreads();
-    if (tid < 147) {
-      s_pnum[tid] = ((s_part[0][tid][0] + s_part[1][tid][0]) + s_part[2][tid][0]) + s_part[3][tid][0];
-      s_dsum[tid] = ((s_part[0][tid][1] + s_part[1][tid][1]) + s_part[2][tid][1]) + s_part[3][tid][1];
     }
   } else {
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {

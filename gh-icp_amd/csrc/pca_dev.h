@@ -27,15 +27,33 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
   // The candidates of a cell are the points of its 27-cell block: 9 runs, ~430 points at TLS density.  When they fit the tile they are
   // staged ONCE, run after run, and both sweeps of every pass over the cell read them from LDS (one load phase per cell instead of 18
   // load-barrier-compute phases); larger blocks go through the tile chunk by chunk.  Either way a lane meets the candidates in the same order.
-  unsigned total = 0;
-  gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) { total += re - rb; });
+  // the 9 runs of the block, looked up by 9 LANES at once: the cell table is far larger than L2 (tens of millions of cells per batch), so
+  // each lookup is a trip to HBM, and walking the runs one after the other (twice: sizes, then staging) was most of the kernel's time
+  unsigned rb_l = 0, re_l = 0;
+  if (lane < 9) {
+    const int x = cx - 1 + lane / 3, y = cy - 1 + lane % 3;
+    if (x >= 0 && x < G.d.dim[0] && y >= 0 && y < G.d.dim[1]) {
+      const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.d.dim[2] - 1);
+      const unsigned base = ((unsigned)x * G.d.dim[1] + y) * G.d.dim[2];
+      rb_l = G.start[base + z0];
+      re_l = G.start[base + z1 + 1];
+    }
+  }
+  const unsigned len_l = re_l - rb_l;
+  unsigned off_l = len_l;  // inclusive prefix over the lanes (lanes >= 9 add nothing)
+  for (int o = 1; o < 16; o <<= 1) {
+    const unsigned v = __shfl_up(off_l, o, 64);
+    if (lane >= o) off_l += v;
+  }
+  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)off_l, 8);
+  off_l -= len_l;  // exclusive
   const bool resident = total <= (unsigned)CHUNK;
   if (resident) {
-    unsigned w = 0;
-    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
+    for (int r = 0; r < 9; r++) {
+      const unsigned rb = (unsigned)__builtin_amdgcn_readlane((int)rb_l, r), re = (unsigned)__builtin_amdgcn_readlane((int)re_l, r);
+      const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)off_l, r);
       for (unsigned t = rb + lane; t < re; t += 64) sC[w + (t - rb)] = G.pts[t];
-      w += re - rb;
-    });
+    }
     __syncthreads();
   }
   for (unsigned q0 = qb; q0 < qe; q0 += 64) {
