@@ -126,11 +126,12 @@ extern "C" int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8) {
   return GHICP_OK;
 }
 
-// Records of the persistent pair loop (loop.hip:k_pair_loop), one per launch = per LDS-occupancy class of a batch, collected while
-// kernel timing is on:  out[0] launches, [1] slots that ran (sum over launches), [2] solves, [3] mean solve ms, [4] longest solve ms,
-// [5] mean launch span ms (first slot start -> last slot end), [6] idle-slot fraction = 1 - sum(slot lifetimes) / sum(slots x span)
-// (a slot is busy from its start to the moment its queue is empty: what is idle is the tail of a launch), [7] share of the slot
-// lifetimes spent inside Kuhn-Munkres solves (the rest: sweeps, graph build, rigid solve).
+// Records of the persistent pair loop (loop.hip:k_pair_loop), one per BATCH (the launches of its LDS-occupancy classes share it),
+// collected while kernel timing is on:  out[0] batches, [1] workgroups that ran, [2] solves, [3] mean solve ms, [4] longest solve ms,
+// [5] mean batch span ms (first slot start -> last slot end), [6] idle-slot fraction = 1 - sum(slot lifetimes) / sum(capacity x span),
+// capacity = the slots one class can keep resident (the classes compete for the same CUs; a slot is busy from its start to the moment
+// its queue is empty, so what is idle is the tail of a batch, when the last pairs iterate alone), [7] share of the slot lifetimes spent
+// inside Kuhn-Munkres solves (the rest: sweeps, graph build, rigid solve).
 extern "C" int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8) {
   GH_ENTER(ctx);
   GH_ARG(out8 != nullptr);
@@ -149,7 +150,7 @@ extern "C" int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8) {
     if (r[6] == 0) continue;
     const double start = (double)((1ull << 62) - r[0]), span = (double)r[1] - start;
     launches++; slots += (double)r[6]; solves += (double)r[4]; sum_dt += (double)r[2]; mx = std::max(mx, (double)r[3]);
-    sum_span += span; life += (double)r[5]; cap += (double)r[6] * span;
+    sum_span += span; life += (double)r[5]; cap += std::min((double)ctx->km_slots[(size_t)l], (double)r[6]) * span;
   }
   if (launches == 0) return GHICP_OK;
   out8[0] = launches; out8[1] = slots; out8[2] = solves; out8[3] = solves > 0 ? sum_dt / solves * tick_ms : 0.0; out8[4] = mx * tick_ms;

@@ -675,6 +675,14 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
   GH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int kflags = ctx->km_force_hazard ? 4 : 0;  // test hook: sends one phase through the hazard fallback
   GH_HIP(hipMemsetAsync(dqheads, 0, 16 * sizeof(int), s));
+  // one launch record per BATCH: the classes of a batch share it (first slot start, last slot end, sums over all slots), and the batch's
+  // capacity is the largest number of slots one class can have resident (the classes compete for the same CUs)
+  unsigned long long* lstat = nullptr;
+  int batch_slots = 0;
+  if (ctx->kt_on && ctx->km_launches < ghicp_ctx::KM_LSTAT_MAX) {
+    GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W, &lstat));
+    lstat += ctx->km_launches * ghicp_ctx::KM_LSTAT_W;
+  }
   hipEvent_t kt = ctx->kt_begin(KT_PAIR_LOOP);
   GH_HIP(hipEventRecord(ctx->aux_events[0], s));
   for (int c = 0; c < nc; c++) {
@@ -687,13 +695,7 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     if (per_cu <= 0) return ctx->fail(GHICP_ERR_INTERNAL, "pair loop: a workgroup with %zu bytes of LDS does not fit a CU", lds);
     const int slots = per_cu * ctx->num_cu;
     const int grid = std::min(plan.count[c], slots);
-    unsigned long long* lstat = nullptr;
-    if (ctx->kt_on && ctx->km_launches < ghicp_ctx::KM_LSTAT_MAX) {
-      GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W, &lstat));
-      lstat += ctx->km_launches * ghicp_ctx::KM_LSTAT_W;
-      ctx->km_slots.push_back(slots);
-      ctx->km_launches++;
-    }
+    batch_slots = std::max(batch_slots, grid);
     if (prof)
       hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
                          dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
@@ -707,6 +709,10 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     }
   }
   ctx->kt_end(KT_PAIR_LOOP, kt);
+  if (lstat) {
+    ctx->km_slots.push_back(batch_slots);
+    ctx->km_launches++;
+  }
   GH_HIP(hipStreamSynchronize(s));
   return GHICP_OK;
 }

@@ -88,8 +88,8 @@ int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, in
 int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8);
 /* Records of the persistent pair loop (Kuhn-Munkres configurations of ghicp_register_pairs / ghicp_register_clouds: one workgroup =
  * one solve slot runs a pair's whole ghicp_reg loop, src/ghicp_reg.cpp:49-103, and then pops the next pair), collected while kernel
- * timing is on: out8 = { launches (one per LDS-occupancy class of a batch), slots that ran, solves, mean solve ms, longest solve ms,
- * mean launch span ms, idle-slot fraction (tail of a launch), share of the slot lifetimes spent inside Kuhn-Munkres solves }. */
+ * timing is on: out8 = { batches, workgroups that ran, solves, mean solve ms, longest solve ms, mean batch span ms, idle-slot fraction
+ * (1 - slot lifetimes / (resident slots x span): the tail of a batch), share of the slot lifetimes spent inside Kuhn-Munkres solves }. */
 int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8);
 /* Progress of the batched loop (ghicp_register_pairs / ghicp_register_clouds) currently running on this context: pairs that are still
  * iterating and pairs of the batch.  No device work; may be called from another thread while the loop runs (a scheduler can start the

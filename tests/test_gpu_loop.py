@@ -235,7 +235,7 @@ def test_pair_loop_persistent_batch(ctx, api, synth, oracle):
     stats = ctx.pair_loop_stats()
     ms, launches = ctx.kernel_time("pair_loop")
     ctx.kernel_timing(False)
-    assert launches == 1 and stats["launches"] >= 2 and stats["solves"] >= sum(r["iters"] for r in refs if r), stats  # the persistent path ran
+    assert launches == 1 and stats["launches"] == 1 and stats["slots"] >= 7 and stats["solves"] >= sum(r["iters"] for r in refs if r), stats  # the persistent path ran
     for (ks, kt), st, r in zip(shapes, got, refs):
         if r is None:
             assert st.iterations == 0
