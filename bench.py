@@ -435,6 +435,7 @@ def main():
                         cv.wait_for(lambda: (ready[k][g] == n_g if args.pipeline == 1 else sum(ready[k]) == nb) or err)
                     if err:
                         return
+                    loop_ctxs[gp].loop_progress_reset(n_g)  # (round-2 advisor: tail_reached must not see the previous batch's finished state)
                     with cv:
                         started[k][g] = True
                     t = time.perf_counter()

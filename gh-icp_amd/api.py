@@ -46,7 +46,7 @@ class PairStats(C.Structure):
 
 EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_set_cu_mask",
-    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_progress", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
+    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
@@ -205,6 +205,10 @@ class Context:
         a, t = C.c_int64(0), C.c_int64(0)
         self.lib.ghicp_ctx_loop_progress(self.h, C.byref(a), C.byref(t))
         return a.value, t.value
+
+    def loop_progress_reset(self, total):
+        """declare a batch of `total` pairs as about to start (so that other threads never read the previous batch's finished state)"""
+        self._check(self.lib.ghicp_ctx_loop_progress_reset(self.h, C.c_int64(int(total))))
 
     def kernel_time(self, name):
         """(total_ms, launches) of a named kernel since kernel_timing(True)."""

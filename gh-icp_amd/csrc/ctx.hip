@@ -126,6 +126,13 @@ extern "C" int ghicp_ctx_loop_progress(const ghicp_ctx* ctx, int64_t* active, in
   }
   return GHICP_OK;
 }
+extern "C" int ghicp_ctx_loop_progress_reset(ghicp_ctx* ctx, int64_t total) {  // no device work
+  if (!ctx || total < 0) return GHICP_ERR_ARG;
+  ctx->progress_live.store(false, std::memory_order_release);
+  ctx->loop_total.store(total, std::memory_order_relaxed);
+  ctx->loop_active.store(total, std::memory_order_relaxed);
+  return GHICP_OK;
+}
 extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {
   GH_ENTER(ctx);
   GH_ARG(name != nullptr);

@@ -95,6 +95,9 @@ int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8);
  * iterating and pairs of the batch.  No device work; may be called from another thread while the loop runs (a scheduler can start the
  * next batch's front ends when only the slowly converging pairs are left). */
 int ghicp_ctx_loop_progress(const ghicp_ctx* ctx, int64_t* active, int64_t* total);
+/* Declares a batch of `total` pairs as about to start on this context (active = total) -- for a scheduler that publishes "the batch has
+ * started" to other threads BEFORE it calls ghicp_register_clouds, so that they never read the previous batch's finished state. */
+int ghicp_ctx_loop_progress_reset(ghicp_ctx* ctx, int64_t total);
 const char* ghicp_version(void);
 void ghicp_params_default(ghicp_params* p);
 
