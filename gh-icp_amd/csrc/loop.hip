@@ -676,9 +676,10 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
   const int kflags = ctx->km_force_hazard ? 4 : 0;  // test hook: sends one phase through the hazard fallback
   GH_HIP(hipMemsetAsync(dqheads, 0, 16 * sizeof(int), s));
   // one launch record per BATCH: the classes of a batch share it (first slot start, last slot end, sums over all slots), and the batch's
-  // capacity is the largest number of slots one class can have resident (the classes compete for the same CUs)
+  // capacity is what can be resident at once: all its workgroups, but not more than the slots of the roomiest class (the classes compete
+  // for the same CUs)
   unsigned long long* lstat = nullptr;
-  int batch_slots = 0;
+  int batch_slots = 0, batch_grid = 0;
   if (ctx->kt_on && ctx->km_launches < ghicp_ctx::KM_LSTAT_MAX) {
     GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W, &lstat));
     lstat += ctx->km_launches * ghicp_ctx::KM_LSTAT_W;
@@ -695,7 +696,8 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     if (per_cu <= 0) return ctx->fail(GHICP_ERR_INTERNAL, "pair loop: a workgroup with %zu bytes of LDS does not fit a CU", lds);
     const int slots = per_cu * ctx->num_cu;
     const int grid = std::min(plan.count[c], slots);
-    batch_slots = std::max(batch_slots, grid);
+    batch_slots = std::max(batch_slots, slots);
+    batch_grid += grid;
     if (prof)
       hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
                          dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
@@ -710,7 +712,7 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
   }
   ctx->kt_end(KT_PAIR_LOOP, kt);
   if (lstat) {
-    ctx->km_slots.push_back(batch_slots);
+    ctx->km_slots.push_back(std::min(batch_slots, batch_grid));
     ctx->km_launches++;
   }
   GH_HIP(hipStreamSynchronize(s));
