@@ -188,7 +188,7 @@ def main():
                     "-1 = calibrate: time both front ends on a sample before the warm-up and use the faster one")
     ap.add_argument("--fe-batch-size", type=int, default=32, help="clouds per launch sequence when --fe-batch -1 picks the batched front end")
     ap.add_argument("--fe-batch-streams", type=int, default=4, help="worker contexts of the batched front end")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = every logical CPU of the host; the distinct scenes are cycled)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the many-core CPU leg (0 = 64, capped by the host's logical CPUs; the distinct scenes are cycled)")
     ap.add_argument("--scene-cache", default="", help="directory that keeps the generated synthetic scenes between runs (the generation is untimed)")
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"], help="pair queue across ranks: static p mod R, or chunks claimed from a shared counter")
     ap.add_argument("--queue-chunks", type=int, default=8, help="--queue dynamic: claims per rank and step (chunk = job / (ranks x this))")
@@ -712,10 +712,12 @@ def main():
             one.append(r1["seconds"])
         t_pair = float(np.median([o["total"] for o in one]))
         stage_med = {k: round(float(np.median([o[k] for o in one])), 3) for k in one[0]}
-        # (ii) all host cores: the distinct scenes cycled over min(host CPUs, --cpu-procs) processes, started together
+        # (ii) many host cores: the distinct scenes cycled over --cpu-procs processes, started together.  Default 64 of the host's logical
+        # CPUs: the leg is memory bound -- 256 processes on the 256 logical CPUs of the GPU box registered FEWER pairs per second than 64
+        # (1.07 against 1.27, profiles/r03_bench_default.json) and took 4 minutes -- and the default run has to stay bounded
         ids = sorted(by_scene)
         ncpu = os.cpu_count() or 2
-        procs = max(1, min(args.cpu_procs or ncpu, ncpu))
+        procs = max(1, min(args.cpu_procs or 64, ncpu))
         jobs_cpu = [ids[i % len(ids)] for i in range(max(procs, len(ids)))]
         start_at = time.time() + (25.0 if big else 12.0) + 0.1 * len(jobs_cpu)
         with mp.get_context("spawn").Pool(procs) as pool:
@@ -730,7 +732,7 @@ def main():
         cpu = {"value": round(1.0 / t_pair, 5), "unit": "pairs/s", "cores": 1, "kind": "port",
                "sample": "pair %d complete (front end + loop), %s, g++ -O3 -march=native" % (sid0, "1 run" if big else "median of 3"),
                "stages_s": stage_med, "host": "%d logical CPUs, %s" % (ncpu, cpu_model),
-               "all_cores": {"value": round(len(jobs_cpu) / wall, 4), "cores": procs, "pairs": len(jobs_cpu), "wall_s": round(wall, 1)}}
+               "all_cores": {"value": round(len(jobs_cpu) / wall, 4), "cores": procs, "of_logical_cpus": ncpu, "pairs": len(jobs_cpu), "wall_s": round(wall, 1)}}
         workload_stats = {"k_bar": round(float(np.mean([r["k_bar"] for r in ora])), 1), "m_bar": round(float(np.mean([r["m_bar"] for r in ora])), 1)}
         rot, tra, it_ok, kp_ok, ok_ok, bad = [], [], 0, 0, 0, []
         for r in ora:
