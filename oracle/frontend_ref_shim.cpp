@@ -10,6 +10,10 @@
 //                                          839-872  getVoxelNum, getVoxelIndex, contain2DPair
 //                                          947-989  computeEigenVectorsByWeightPCA up to its Eigen::EigenSolver call: f64 centroid, weights
 //                                                   sqrt(2) R - distance, the float 3 x 3 running sums, the division by the weight sum
+//                                          939-1035, 119-155  the whole computeEigenVectorsByWeightPCA and computeLocalCoordinateSystem over a stand-in
+//                                                   Eigen::EigenSolver that returns INJECTED eigenpairs: the selection of the principal / normal
+//                                                   directions (strict compares, first index on ties), middle = principal x normal, x / y / z
+//                                                   axes, their normalisation
 //                                          1156-1165 Comput3DDistanceBetweenPoints
 //   include/filter.hpp                     18-88    CFilter::IDPair, CFilter::voxelfilter (std::sort, Q1 phantom entries)
 //   include/pca.h                          16-45    eigenValue, eigenVector, pcaFeature
@@ -48,6 +52,8 @@ class BSCEncoder : public StereoBinaryFeature {
 #include "bfe_rearrange.inc"
 #include "bfe_private.inc"
  public:
+#include "bfe_wpca.inc"
+#include "bfe_lcs.inc"
   // computeEigenVectorsByWeightPCA (bfe:940-1035) up to the Eigen::EigenSolver call: returns the covariance the solver would be given
   bool weightedCovariance(const typename pcl::PointCloud<PointT>::Ptr& input_cloud, const vector<int>& search_indices, int test_index,
                           Eigen::Matrix<float, 3, 3>& out) {
@@ -180,6 +186,26 @@ int ref_weighted_cov(const float* xyz, int n, const int* idx, int cnt, int test_
   if (!e.weightedCovariance(cloud, si, test_index, c)) return 0;
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) out9[i * 3 + j] = c(i, j);
+  return 1;
+}
+
+// computeLocalCoordinateSystem (bfe:121-155) = computeEigenVectorsByWeightPCA (bfe:940-1035) + axis construction, with the eigen solver's
+// output injected by the caller (values[3], vectors 3 x 3 row-major with eigenvectors in columns).  out12: x, y, z axes and the origin.
+int ref_lcs(const float* xyz, int n, const int* idx, int cnt, int test_index, float R, const float* values3, const float* vectors9, float* out12) {
+  Quiet q;
+  Enc e(R, 7, false);
+  pcl::PointCloud<pcl::PointXYZ>::Ptr cloud(new pcl::PointCloud<pcl::PointXYZ>);
+  cloud->points.resize(n);
+  for (int i = 0; i < n; i++) { cloud->points[i].x = xyz[(size_t)i * 3]; cloud->points[i].y = xyz[(size_t)i * 3 + 1]; cloud->points[i].z = xyz[(size_t)i * 3 + 2]; }
+  std::vector<int> si(idx, idx + cnt);
+  auto& inj = Eigen::EigenSolver<Eigen::Matrix3f>::injected();
+  for (int i = 0; i < 3; i++) inj.values[i] = values3[i];
+  for (int i = 0; i < 9; i++) inj.vectors[i] = vectors9[i];
+  Enc::CoordinateSystem cs;
+  if (!e.computeLocalCoordinateSystem(cloud, test_index, si, cs)) return 0;
+  const Eigen::Vector3f* ax[4] = {&cs.xAxis, &cs.yAxis, &cs.zAxis, &cs.origin};
+  for (int a = 0; a < 4; a++)
+    for (int d = 0; d < 3; d++) out12[a * 3 + d] = (*ax[a])(d);
   return 1;
 }
 

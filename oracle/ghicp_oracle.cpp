@@ -388,6 +388,52 @@ static void bsc_strings(const float* weight147, const float* depth147, int dof, 
   }
 }
 
+// The local coordinate system from the weighted covariance (bfe:990-1035 + 121-155): N3's Jacobi stands in for Eigen::EigenSolver (its
+// output is library arithmetic: eigenvalues as float, eigenvectors with the largest-magnitude component positive, lowest index on ties);
+// then the reference's own steps -- principal / normal direction = eigenvector of the largest / smallest eigenvalue (strict compares, first
+// index wins ties), middle = principal x normal, x = principal, y = middle, z = x x y (before normalisation), x and y normalised.
+// values3 / vectors9 (row-major, eigenvectors in columns, sign convention applied to every column) optionally return what the stand-in
+// solver "returned", for the pin of the steps after it (tests/test_ref_pin_cpu.py).
+static void lcs_from_covariance(const float Cf[6], float X[3], float Y[3], float Z[3], float* values3, float* vectors9) {
+  double a[3][3] = {{Cf[0], Cf[1], Cf[2]}, {Cf[1], Cf[3], Cf[4]}, {Cf[2], Cf[4], Cf[5]}}, v[3][3];
+  jacobi3(a, v);
+  int imax = 0, imin = 0;  // bfe:999-1016 (strict compares, first index wins ties)
+  for (int i = 0; i < 3; i++) {
+    if ((float)a[i][i] > (float)a[imax][imax]) imax = i;
+    if ((float)a[i][i] < (float)a[imin][imin]) imin = i;
+  }
+  // Sign convention (EigenSolver's is implementation-defined, SURVEY.md hard part 3):
+  // the largest-magnitude component of each eigenvector is positive (lowest index on ties).
+  auto pick = [&](int col, float* o) {
+    double e[3] = {v[0][col], v[1][col], v[2][col]};
+    int b = 0;
+    if (std::fabs(e[1]) > std::fabs(e[b])) b = 1;
+    if (std::fabs(e[2]) > std::fabs(e[b])) b = 2;
+    double s = (e[b] < 0) ? -1.0 : 1.0;
+    for (int d = 0; d < 3; d++) o[d] = (float)(s * e[d]);
+  };
+  if (values3 && vectors9)
+    for (int c = 0; c < 3; c++) {
+      float col[3];
+      pick(c, col);
+      values3[c] = (float)a[c][c];
+      for (int r = 0; r < 3; r++) vectors9[r * 3 + c] = col[r];
+    }
+  float P[3], N[3], Mid[3];
+  pick(imax, P);
+  pick(imin, N);
+  Mid[0] = P[1] * N[2] - P[2] * N[1];  // middle = principal x normal (bfe:1026)
+  Mid[1] = P[2] * N[0] - P[0] * N[2];
+  Mid[2] = P[0] * N[1] - P[1] * N[0];
+  for (int d = 0; d < 3; d++) { X[d] = P[d]; Y[d] = Mid[d]; }
+  Z[0] = X[1] * Y[2] - X[2] * Y[1];  // bfe:144 (before normalisation)
+  Z[1] = X[2] * Y[0] - X[0] * Y[2];
+  Z[2] = X[0] * Y[1] - X[1] * Y[0];
+  float nx = std::sqrt((X[0] * X[0] + X[1] * X[1]) + X[2] * X[2]);
+  float ny = std::sqrt((Y[0] * Y[0] + Y[1] * Y[1]) + Y[2] * Y[2]);
+  for (int d = 0; d < 3; d++) { X[d] = X[d] / nx; Y[d] = Y[d] / ny; }  // bfe:151-152
+}
+
 // The covariance computeEigenVectorsByWeightPCA hands to its eigen solver (bfe:947-989), under N2 of the numerics contract: centroid in f64,
 // weights sqrt(2) R - distance (float, Q8: negative beyond sqrt(2) R), the six sums in f64 rounded ONCE onto the f32 grid of the matrix
 // scale (the reference keeps float running sums in the radius search's order), then the division by the float-cast weight sum.
@@ -441,36 +487,7 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
     if (mm >= 3) {
       float Cf[6];
       weighted_covariance(xyz, stride, nb, radius_w, Cf);
-      double a[3][3] = {{Cf[0], Cf[1], Cf[2]}, {Cf[1], Cf[3], Cf[4]}, {Cf[2], Cf[4], Cf[5]}}, v[3][3];
-      jacobi3(a, v);
-      int imax = 0, imin = 0;  // bfe:999-1016 (strict compares, first index wins ties)
-      for (int i = 0; i < 3; i++) {
-        if ((float)a[i][i] > (float)a[imax][imax]) imax = i;
-        if ((float)a[i][i] < (float)a[imin][imin]) imin = i;
-      }
-      // Sign convention (EigenSolver's is implementation-defined, SURVEY.md hard part 3):
-      // the largest-magnitude component of each eigenvector is positive (lowest index on ties).
-      auto pick = [&](int col, float* o) {
-        double e[3] = {v[0][col], v[1][col], v[2][col]};
-        int b = 0;
-        if (std::fabs(e[1]) > std::fabs(e[b])) b = 1;
-        if (std::fabs(e[2]) > std::fabs(e[b])) b = 2;
-        double s = (e[b] < 0) ? -1.0 : 1.0;
-        for (int d = 0; d < 3; d++) o[d] = (float)(s * e[d]);
-      };
-      float P[3], N[3], Mid[3];
-      pick(imax, P);
-      pick(imin, N);
-      Mid[0] = P[1] * N[2] - P[2] * N[1];  // middle = principal x normal (bfe:1026)
-      Mid[1] = P[2] * N[0] - P[0] * N[2];
-      Mid[2] = P[0] * N[1] - P[1] * N[0];
-      for (int d = 0; d < 3; d++) { X[d] = P[d]; Y[d] = Mid[d]; }
-      Z[0] = X[1] * Y[2] - X[2] * Y[1];  // bfe:144 (before normalisation)
-      Z[1] = X[2] * Y[0] - X[0] * Y[2];
-      Z[2] = X[0] * Y[1] - X[1] * Y[0];
-      float nx = std::sqrt((X[0] * X[0] + X[1] * X[1]) + X[2] * X[2]);
-      float ny = std::sqrt((Y[0] * Y[0] + Y[1] * Y[1]) + Y[2] * Y[2]);
-      for (int d = 0; d < 3; d++) { X[d] = X[d] / nx; Y[d] = Y[d] / ny; }  // bfe:151-152
+      lcs_from_covariance(Cf, X, Y, Z, nullptr, nullptr);
     }
     float* o = &lcs[(size_t)kk * 12];
     for (int d = 0; d < 3; d++) { o[d] = X[d]; o[3 + d] = Y[d]; o[6 + d] = Z[d]; o[9 + d] = q[d]; }
@@ -1102,6 +1119,12 @@ float orc_bbx_magnitude(const float* xyz, int n, int stride) {
       if (mx[d] < v) mx[d] = v;
     }
   return (float)(mx[0] - mn[0] + mx[1] - mn[1] + mx[2] - mn[2]);
+}
+
+// test hook: the LCS of a 3 x 3 covariance (row-major, symmetric) + the eigenpairs of the stand-in solver
+void orc_lcs_from_cov(const float* cov9, float* lcs9, float* values3, float* vectors9) {
+  const float Cf[6] = {cov9[0], cov9[1], cov9[2], cov9[4], cov9[5], cov9[8]};
+  orc::lcs_from_covariance(Cf, lcs9, lcs9 + 3, lcs9 + 6, values3, vectors9);
 }
 
 // test hook: the contract's weighted covariance of one keypoint neighbourhood (idx in the radius search's order) -> 3 x 3 row-major

@@ -677,3 +677,24 @@ def adaptive_tail(xyz, lam, cnt, curv, R_nms, ratio_max=0.65, min_n=20, upper=50
     k = lib().orc_adaptive_tail(_p(xyz, C.c_float), xyz.shape[0], xyz.shape[1], _p(lam, C.c_float), _p(curv, C.c_double), _p(cnt, C.c_int),
                                 C.c_float(ratio_max), int(min_n), C.c_float(R_nms), C.c_longlong(upper), C.c_longlong(lower), _p(out, C.c_int))
     return out[:k].copy()
+
+
+def lcs_from_cov(cov):
+    """The contract's LCS of a 3 x 3 weighted covariance: (axes (3, 3) f32 rows x, y, z; eigenvalues (3,) f32; eigenvectors (3, 3) f32 in
+    columns, sign convention applied) -- what the stand-in for Eigen::EigenSolver 'returns' and what the reference's steps make of it."""
+    cov = np.ascontiguousarray(cov, np.float32).reshape(9)
+    axes, vals, vecs = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(9, np.float32)
+    lib().orc_lcs_from_cov(_p(cov, C.c_float), _p(axes, C.c_float), _p(vals, C.c_float), _p(vecs, C.c_float))
+    return axes.reshape(3, 3), vals, vecs.reshape(3, 3)
+
+
+def ref_lcs(xyz, idx, test_index, R, values, vectors):
+    """binary_feature_extraction.hpp:939-1035 + 119-155 themselves over a stand-in Eigen::EigenSolver that returns (values, vectors):
+    (4, 3) f32 rows x axis, y axis, z axis, origin."""
+    xyz = np.ascontiguousarray(_f32(xyz)[:, :3])
+    idx = np.ascontiguousarray(idx, np.int32)
+    values, vectors = np.ascontiguousarray(values, np.float32), np.ascontiguousarray(vectors, np.float32).reshape(9)
+    out = np.zeros(12, np.float32)
+    ok = ref3_lib().ref_lcs(_p(xyz, C.c_float), xyz.shape[0], _p(idx, C.c_int), int(idx.size), int(test_index), C.c_float(R), _p(values, C.c_float),
+                            _p(vectors, C.c_float), _p(out, C.c_float))
+    return out.reshape(4, 3) if ok else None

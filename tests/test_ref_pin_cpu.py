@@ -328,3 +328,41 @@ def test_weighted_covariance_contract_against_the_reference_arithmetic(ref3, syn
         worst_angle = max(worst_angle, float(np.arccos(min(1.0, abs(vo[:, 2] @ vr[:, 2])))))
     assert worst_ulp <= 256 and worst_angle < 1e-4, (worst_ulp, worst_angle)
     assert O.ref_weighted_cov(ds, np.array([0, 1], np.int32), 0, R) is None  # fewer than 3 neighbours: no LCS (bfe:947)
+
+
+def test_local_coordinate_system_steps_after_the_eigen_solver(ref3, synth):
+    """computeEigenVectorsByWeightPCA (bfe:939-1035) and computeLocalCoordinateSystem (bfe:119-155) THEMSELVES, compiled over a stand-in
+    Eigen::EigenSolver that returns injected eigenpairs: what they do with the solver's output -- largest / smallest eigenvalue by strict
+    compares (first index on ties), principal / normal direction, middle = principal x normal, x = principal, y = middle, z = x x y taken
+    BEFORE x and y are normalised, origin = the keypoint -- is bit for bit what the restatement does with the same eigenpairs.  (The solver's
+    own output -- values, order, signs -- is library arithmetic and stays unpinned.)"""
+    from scipy.spatial import cKDTree
+
+    O = ref3
+    scan = synth.tls_pair(120_000, pair_id=6).target
+    ds = scan[O.voxel_filter(scan, 0.1)]
+    kp, _ = O.keypoints(ds, 0.5, 1.5)
+    assert kp.size >= 60
+    tree = cKDTree(ds.astype(np.float64))
+    R = 1.5
+    for p in kp[:60]:
+        idx = np.array(tree.query_ball_point(ds[p].astype(np.float64), np.sqrt(3.0) * R), np.int64)
+        d2 = ((ds[idx] - ds[p]).astype(np.float32) ** 2)
+        idx = idx[np.lexsort((idx, (d2[:, 0] + d2[:, 1]) + d2[:, 2]))].astype(np.int32)
+        axes, vals, vecs = O.lcs_from_cov(O.weighted_cov(ds, idx, int(p), R))
+        got = O.ref_lcs(ds, idx, int(p), R, vals, vecs)
+        np.testing.assert_array_equal(got[:3], axes)
+        np.testing.assert_array_equal(got[3], ds[p])
+    # ties and permuted spectra: every order of three eigenvalues, and two equal ones, through both sides
+    rng = np.random.default_rng(3)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    idx = np.arange(10, dtype=np.int32)
+    for vals in ([3, 2, 1], [1, 2, 3], [2, 3, 1], [2, 2, 1], [1, 2, 2], [2, 1, 2], [5, 5, 5]):
+        vals = np.array(vals, np.float32)
+        vecs = q.astype(np.float32)
+        got = O.ref_lcs(ds, idx, 0, R, vals, vecs)
+        imax, imin = int(np.argmax(vals)), int(np.argmin(vals))  # numpy's argmax / argmin = first index on ties = strict compares
+        P, N = vecs[:, imax], vecs[:, imin]
+        mid = np.cross(P, N).astype(np.float32)
+        np.testing.assert_allclose(got[0], P / np.linalg.norm(P), rtol=1e-6)
+        np.testing.assert_allclose(got[1], mid / np.linalg.norm(mid) if np.linalg.norm(mid) > 0 else got[1], rtol=1e-5, atol=1e-7)
