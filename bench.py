@@ -71,8 +71,9 @@ def _gen_worker(a):
     p = make_pair(*a[:3])
     if f:
         os.makedirs(cache, exist_ok=True)
-        np.savez(f + ".tmp.npz", s=p.source, t=p.target, gt=p.gt)
-        os.replace(f + ".tmp.npz", f)
+        tmp = "%s.%d.tmp.npz" % (f, os.getpid())  # several ranks may generate the same scene at the same time
+        np.savez(tmp, s=p.source, t=p.target, gt=p.gt)
+        os.replace(tmp, f)
     return p.source, p.target, p.gt
 
 

@@ -849,7 +849,11 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         if (all_sparse) { GH_TRY(gh_km4_plan(ctx, hn.data(), nb, &km_plan)); use_plan = true; }
       }
       if (persistent && use_plan) {
-        GH_TRY(run_pair_loop<FT>(ctx, dprobs, nb, km_plan, dqheads));
+        const int rc = run_pair_loop<FT>(ctx, dprobs, nb, km_plan, dqheads);
+        if (rc != GHICP_OK) {
+          ctx->progress_live.store(false, std::memory_order_release);
+          return rc;
+        }
         all_done = true;
       }
       while (!all_done && launched < max_iter) {
