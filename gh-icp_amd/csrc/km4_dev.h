@@ -48,7 +48,7 @@ typedef __attribute__((address_space(1))) const int* k4_gint;
 typedef __attribute__((address_space(1))) const double* k4_gf64;
 typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
 
-enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NUM = 16 };
+enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_NUM = 16 };
 
 struct K4 {
   double *lx, *ly, *slack, *red;
@@ -170,11 +170,73 @@ __device__ inline void k4_revalidate(const K4& s, int tid) {
   }
 }
 
-__device__ inline double k4_wave_min(double v) {
+// R5, flagged rows: S should hold a flagged row only if the row can be good -- one of its tight entries lies in a column of S, or it
+// is background-tight to the best column of S -- not unconditionally (round 2 and the first half of round 3 did that, and the DFS then
+// descended into flagged rows that lead nowhere: 28 % of its iterations were the pops that followed, profiles/r03_km_dfs_kinds.txt).
+// The S rounds cannot afford a CSR scan per flagged row per round, so the rows' tight columns are gathered ONCE per augmenting
+// phase into a pool: the flood's queue stx is dead by then and the DFS has not started, so stx is the pool (region r = `region`
+// u16 per flagged row: count, then the columns, ascending) and sty holds the list of flagged rows.  A row with more tight entries than
+// its region holds joins S unconditionally, as before (any superset of good is valid, R5).  16 lanes per row, as in k4_bulk.
+__device__ inline void k4_pool_build(const K4& s, int nf, int region, int wave, int lane) {
+  const int grp = lane >> 4, lig = lane & 15, capf = region - 1;
+  for (int base = 0; base < nf; base += 16) {
+    const int i = base + wave * 4 + grp;
+    int x = -1;
+    if (i < nf) x = s.sty[i];
+    unsigned cb = 0, ce = 0;
+    double lxr = 0.0;
+    if (x >= 0) { cb = s.rptr[x]; ce = s.rptr[x + 1]; lxr = s.lx[x]; }
+    int cnt = 0;
+    for (unsigned off = 0; __ballot(cb + off < ce); off += 64) {
+      int col[4];
+      double val[4];
+      unsigned c[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
+      for (int j = 0; j < 4; j++) {
+        c[j] = cb + off + 16u * j + lig;
+        col[j] = 0; val[j] = 0.0;
+        if (ce > cb) { const unsigned cc = min(c[j], ce - 1u); col[j] = s.cols[cc]; val[j] = s.vals[cc]; }
+      }
+      double lyv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) lyv[j] = s.ly[col[j]];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool td = (int)(c[j] < ce) & (int)(((lxr + lyv[j]) - val[j]) < s.eps);
+        const unsigned gb = (unsigned)(__ballot(td) >> (grp * 16)) & 0xffffu;
+        if (td) {
+          const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
+          if (rk < capf) s.stx[i * region + 1 + rk] = (unsigned short)col[j];
+        }
+        cnt += __popc(gb);
+      }
+    }
+    if (lig == 0 && x >= 0) {
+      if (cnt > capf) { atomicOr(&s.good[x >> 5], 1u << (x & 31)); cnt = 0; }
+      s.stx[i * region] = (unsigned short)cnt;
+    }
+  }
 }
+
+// Minimum over the wave, in every lane.  Four DPP steps (quad_perm [1,0,3,2] and [2,3,0,1], row_ror:4, row_ror:8) leave the minimum of
+// each row of 16 in all its lanes, v_readlane fetches the four rows.  (The __shfl_xor butterfly this replaces is twelve dependent
+// ds_bpermute_b32, ~1000 cycles for a wave that runs alone; a flood level or an S round is only a few thousand.)
+#define K4_DPP_MIN(V, CTRL)                                                                                   \
+  V = fmin(V, __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(V), CTRL, 0xf, 0xf, false),     \
+                               __builtin_amdgcn_update_dpp(0, __double2loint(V), CTRL, 0xf, 0xf, false)))
+__device__ inline double k4_wave_min(double v) {
+  K4_DPP_MIN(v, 0xb1);
+  K4_DPP_MIN(v, 0x4e);
+  K4_DPP_MIN(v, 0x124);
+  K4_DPP_MIN(v, 0x128);
+  const int hi = __double2hiint(v), lo = __double2loint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return fmin(fmin(r0, r1), fmin(r2, r3));
+}
+#undef K4_DPP_MIN
 
 // ---- R3: the flood (wave 0), level by level.  Returns true when a free column is reachable; the visited rows are stx[0 .. *qt_out).
 // A column is claimed by the returning ds_or on its visited bit (two rows reaching it in the same instruction are serialised by
@@ -227,7 +289,7 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
         const bool want = (int)(k < t) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
         K4_CLAIM(want, lc[k], mc[k]);
       }
-      if (act && (lxr - s.bg) < s.eps) lcand = fmin(lcand, lxr);
+      if (act && (lxr - s.bg) < s.eps && lxr < lflood) lcand = fmin(lcand, lxr);
       unsigned long long ob = __ballot(act && tn == K4_OVER);
       if (PROF) pc[1] += __popcll(ob);
       while (ob) {  // flagged rows: every tight entry of the CSR row
@@ -246,10 +308,10 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
         }
       }
     }
-    lcand = k4_wave_min(lcand);
     const long long tl1 = PROF ? (long long)__builtin_readcyclecounter() : 0;
     if (PROF) pc[2] += tl1 - tl0;
-    if (lcand < lflood) {  // T_L of the smallest label so far contains T_L of every larger one
+    if (__ballot(lcand < lflood)) {  // a label below every one swept so far (rare: a reduction per level was a third of a level's time);
+      lcand = k4_wave_min(lcand);    // T_L of the smallest label contains T_L of every larger one
       lflood = lcand;
       if (PROF) pc[3]++;
       for (int y0 = 0; y0 < n; y0 += 256) {  // four independent windows per round
@@ -617,21 +679,36 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         continue;
       }
       // ---- R5: augmenting phase.  S by pull rounds ...
-      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = s.ovf[w]; s.goody[w] = s.freey[w]; }
+      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = 0u; s.goody[w] = s.freey[w]; }
       if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; }
+      if (wave == 0) {  // the flagged rows, ascending, into sty
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+          const int x = base + lane;
+          const bool f = x < n && k4_bit(s.ovf, x);
+          const unsigned long long b = __ballot(f);
+          if (f) s.sty[cnt + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)x;
+          cnt += __popcll(b);
+        }
+        if (lane == 0) s.sh[SH_NF] = cnt;
+      }
       __syncthreads();
+      const int nf = s.sh[SH_NF];
+      const int region = nf > 0 ? min(64, (n + 2) / nf) : 0;  // u16 of stx per flagged row: count + columns (region 1: every flagged row stays in S)
+      if (nf > 0) {
+        k4_pool_build(s, nf, region, wave, lane);
+        __syncthreads();
+      }
       for (int round = 0;; round++) {
         if (PROF) q_rounds++;
-        double gm = INFINITY;
         for (int base = tid; base < n; base += 4 * K4_T) {  // columns: S gains the columns whose owner is in S
           int yy[4], mm[4];
           unsigned gw[4];
-          double lyv[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             yy[k] = base + k * K4_T;
             const int yc = min(yy[k], n - 1);
-            gw[k] = s.goody[yc >> 5]; mm[k] = s.match[yc]; lyv[k] = s.ly[yc];
+            gw[k] = s.goody[yc >> 5]; mm[k] = s.match[yc];
           }
           unsigned ow[4];
 #pragma unroll
@@ -639,16 +716,12 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             if (yy[k] >= n) continue;
-            bool g = (gw[k] >> (yy[k] & 31)) & 1u;
-            if (!g && mm[k] != K4_NONE && ((ow[k] >> (mm[k] & 31)) & 1u)) { atomicOr(&s.goody[yy[k] >> 5], 1u << (yy[k] & 31)); g = true; }
-            if (g) gm = fmin(gm, lyv[k]);
+            const bool g = (gw[k] >> (yy[k] & 31)) & 1u;
+            if (!g && mm[k] != K4_NONE && ((ow[k] >> (mm[k] & 31)) & 1u)) atomicOr(&s.goody[yy[k] >> 5], 1u << (yy[k] & 31));
           }
         }
-        gm = k4_wave_min(gm);
-        if (lane == 0) s.red[8 + wave] = gm;
         __syncthreads();
         if (tid == 0) s.sh[SH_CH0 + ((round + 1) & 1)] = 0;
-        const double gmin = fmin(fmin(s.red[8], s.red[9]), fmin(s.red[10], s.red[11]));
         bool ch = false;
         for (int base = tid; base < n; base += 4 * K4_T) {  // rows: background-tight to the best column of S, or a listed entry in S
           int xx[4], tn[4], lc[4][K4_CAP];
@@ -670,12 +743,22 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             if (xx[k] >= n || ((gdw[k] >> (xx[k] & 31)) & 1u)) continue;
-            bool g = (int)((lxv[k] - bg) < eps) & (int)(((lxv[k] + gmin) - bg) < eps);
+            bool g = (lxv[k] - bg) < eps;  // background-tight to a free column: those are in S and their label is still 0, the smallest there is
             const int t = k4_cnt(tn[k]);
 #pragma unroll
             for (int e = 0; e < K4_CAP; e++) g |= (int)(e < t) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);  // listed = tight (R2)
             if (g) { atomicOr(&s.good[xx[k] >> 5], 1u << (xx[k] & 31)); ch = true; }
           }
+        }
+        for (int fb = 0; fb < nf; fb += 16) {  // flagged rows: a pooled tight column in S (16 lanes per row)
+          const int i = fb + wave * 4 + (lane >> 4), lig = lane & 15;
+          int x = -1, cnt = 0;
+          if (i < nf) { x = s.sty[i]; cnt = s.stx[i * region]; }
+          bool hit = false;
+          if (x >= 0 && !k4_bit(s.good, x))
+            for (int e = lig; e < cnt; e += 16) hit |= k4_bit(s.goody, s.stx[i * region + 1 + e]);
+          const unsigned gb = (unsigned)(__ballot(hit) >> (lane & 48)) & 0xffffu;
+          if (gb && lig == 0) { atomicOr(&s.good[x >> 5], 1u << (x & 31)); ch = true; }
         }
         if (ch) s.sh[SH_CH0 + (round & 1)] = 1;
         __syncthreads();

@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <type_traits>
 
@@ -119,6 +120,22 @@ template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64
   return hipsim::shfl_from(v, (src >= 0 && src / width == lane / width) ? src : lane, line);
 }
 static inline int __builtin_amdgcn_readlane(int v, int lane, int line = __builtin_LINE()) { return hipsim::shfl_from(v, lane, line); }
+// v_mov_b32_dpp with row_mask = bank_mask = 0xf: the source lane of every lane for the controls the kernels use (quad_perm, row_shl /
+// row_shr / row_ror, row_mirror, row_half_mirror); a lane without a valid source keeps `old` (bound_ctrl = false) or reads 0 (true)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, int line = __builtin_LINE()) {
+  const int lane = hipsim::cur->lane, row = lane & ~15, r = lane & 15;
+  int from = -1;
+  if (ctrl < 0x100) from = (lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl >= 0x101 && ctrl <= 0x10f) from = r + (ctrl & 15) < 16 ? lane + (ctrl & 15) : -1;
+  else if (ctrl >= 0x111 && ctrl <= 0x11f) from = r - (ctrl & 15) >= 0 ? lane - (ctrl & 15) : -1;
+  else if (ctrl >= 0x121 && ctrl <= 0x12f) from = row + ((r - (ctrl & 15)) & 15);
+  else if (ctrl == 0x140) from = row + 15 - r;
+  else if (ctrl == 0x141) from = (lane & ~7) + 7 - (lane & 7);
+  else { fprintf(stderr, "hipsim: dpp control 0x%x is not modelled\n", ctrl); abort(); }
+  if (row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipsim: dpp row/bank masks are not modelled\n"); abort(); }
+  const int got = hipsim::shfl_from(src, from < 0 ? lane : from, line);
+  return from < 0 ? (bound_ctrl ? 0 : old) : got;
+}
 static inline int __builtin_amdgcn_readfirstlane(int v, int line = __builtin_LINE()) {
   return (int)(uint32_t)hipsim::wave_collective(hipsim::OP_FIRST, line, (uint32_t)v, 0);
 }
@@ -147,6 +164,9 @@ HIPSIM_BITCAST(__uint_as_float, unsigned, float)
 HIPSIM_BITCAST(__int_as_float, int, float)
 HIPSIM_BITCAST(__double_as_longlong, double, long long)
 HIPSIM_BITCAST(__longlong_as_double, long long, double)
+static inline int __double2hiint(double v) { return (int)(uint32_t)((uint64_t)__double_as_longlong(v) >> 32); }
+static inline int __double2loint(double v) { return (int)(uint32_t)(uint64_t)__double_as_longlong(v); }
+static inline double __hiloint2double(int hi, int lo) { return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo)); }
 static inline float __fmaf_rn(float a, float b, float c) { return std::fma(a, b, c); }
 static inline double __fma_rn(double a, double b, double c) { return std::fma(a, b, c); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
