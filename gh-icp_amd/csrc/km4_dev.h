@@ -23,10 +23,13 @@
 //       an edge sits within an ulp of eps) sends the problem to the literal single-lane solver at the end of this file.
 //   R5  augmenting phase: good = rows that reach a free column in the tight graph.  findpath() of a row that is not good
 //       fails whatever has been visited and visits only rows that are not good, so the reference's DFS may skip columns
-//       whose owner lies outside any superset S of good without changing its path.  S = fixed point of "background-tight to
-//       the good column of smallest ly, or a listed tight entry in a good column" (256 threads, one row each per round,
-//       ~4 rounds), flagged rows included.  Wave 0 then runs the reference's DFS restricted to S: E7 pointer, E9 march
-//       (km2.hip), all in LDS; what is left of the search is essentially the augmenting path itself.
+//       whose owner lies outside any superset S of good without changing its path.  S = fixed point of "(lx - bg) < eps
+//       (background-tight to a free column: free columns were never relabelled, their ly is 0 and no ly is negative), or a tight
+//       explicit entry in a column of S" (256 threads, one row each per round, ~4 rounds).  Listed rows test their list; flagged
+//       rows test their tight columns, gathered once per phase into a pool (k4_pool_build) -- until the second half of round 3
+//       they were simply members of S, and 28 % of the DFS iterations were pops out of flagged rows that lead nowhere.  Wave 0
+//       then runs the reference's DFS restricted to S: E7 pointer, E9 march (km2.hip), all in LDS; what is left of the search
+//       is essentially the augmenting path itself.
 // (device code; included by km4.hip -- the stand-alone solve kernel -- and by loop.hip -- the persistent pair loop)
 #pragma once
 #include "ctx.h"
