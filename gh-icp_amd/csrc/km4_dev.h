@@ -77,24 +77,16 @@ template <bool REBUILD, bool PUSH, bool ONLY_UNPUSHED>
 __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int count, int wave, int lane) {
   const int grp = lane >> 4, lig = lane & 15;
   unsigned long long* sl = reinterpret_cast<unsigned long long*>(s.slack);
-  // the extents of the NEXT 16 rows are fetched while this batch streams its entries: one global latency per pass, not one per batch
-  int xn = -1;
-  unsigned cbn = 0, cen = 0;
-  auto fetch = [&](int i) {
-    xn = -1; cbn = 0; cen = 0;
-    if (i < count) {
-      xn = list[i];
-      if (ONLY_UNPUSHED && k4_bit(s.pushed, xn)) xn = -1;
-    }
-    if (xn >= 0) { cbn = s.rptr[xn]; cen = s.rptr[xn + 1]; }
-  };
-  fetch(wave * 4 + grp);
   for (int base = 0; base < count; base += 16) {
-    const int x = xn;
-    const unsigned cb = cbn, ce = cen;
-    fetch(base + 16 + wave * 4 + grp);
+    const int i = base + wave * 4 + grp;
+    int x = -1;
+    if (i < count) {
+      x = list[i];
+      if (ONLY_UNPUSHED && k4_bit(s.pushed, x)) x = -1;
+    }
+    unsigned cb = 0, ce = 0;
     double lxr = 0.0;
-    if (x >= 0) lxr = s.lx[x];
+    if (x >= 0) { cb = s.rptr[x]; ce = s.rptr[x + 1]; lxr = s.lx[x]; }
     int cnt = 0;
     for (unsigned off = 0; __ballot(cb + off < ce); off += 64) {
       int col[4];
