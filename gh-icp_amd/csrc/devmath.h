@@ -144,12 +144,6 @@ __host__ __device__ inline float gh_atan2f(float yf, float xf) {
 }
 
 // ---- reductions (fixed tree order => run-to-run deterministic)
-// gh_together(a, b, ...): every operand has to be in its register HERE.  Put behind a group of independent LDS (or global) loads it
-// makes the group ONE round trip: the compiler may neither sink one of the loads into the branch that uses it nor wait for the first
-// before it issues the next (both seen in k4_dfs's ISA: five dependent LDS latencies per search step where the source says two).
-template <class T> __device__ __forceinline__ void gh_keep(T& v) { asm volatile("" : "+v"(v)); }
-template <class... T> __device__ __forceinline__ void gh_together(T&... v) { (gh_keep(v), ...); }
-
 __device__ inline double gh_wave_sum(double x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);

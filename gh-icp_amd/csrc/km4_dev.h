@@ -215,9 +215,8 @@ __device__ inline void k4_pool_build(const K4& s, int nf, int region, int wave, 
       }
     }
     if (lig == 0 && x >= 0) {
-      if (cnt > capf) { atomicOr(&s.good[x >> 5], 1u << (x & 31)); cnt = K4_NONE; }  // not pooled: in S, and the DFS scans its CSR row
+      if (cnt > capf) { atomicOr(&s.good[x >> 5], 1u << (x & 31)); cnt = 0; }
       s.stx[i * region] = (unsigned short)cnt;
-      s.tlc[x * K4_CAP] = (unsigned short)i;  // the row's region (a flagged row's list slots are free; i < n keeps them valid indices)
     }
   }
 }
@@ -246,16 +245,12 @@ __device__ inline double k4_wave_min(double v) {
 // A column is claimed by the returning ds_or on its visited bit (two rows reaching it in the same instruction are serialised by
 // the LDS); every matched row owns exactly one column, so the claim of a column is also the one enqueue of its owner, and the
 // queue tail lives in a register (ballot ranks, no LDS counter).
-// (K4_TRY: the returning ds_or alone; K4_ENQ: what follows from its result -- a group of independent claims issues its atomics back to
-// back and pays ONE LDS round trip, in the order the claims would have had one by one)
-#define K4_TRY(OLD, WANT, COL)                                                              \
+#define K4_CLAIM(WANT, COL, OWNER)                                                          \
   do {                                                                                      \
-    OLD = 0u;                                                                               \
-    if (WANT) OLD = atomicOr(&s.visy[(COL) >> 5], 1u << ((COL) & 31));                      \
-  } while (0)
-#define K4_ENQ(OLD, WANT, COL, OWNER)                                                       \
-  do {                                                                                      \
-    const bool fresh_ = (WANT) && !((OLD) & (1u << ((COL) & 31)));                          \
+    unsigned old_ = 0u;                                                                     \
+    const unsigned bit_ = 1u << ((COL) & 31);                                               \
+    if (WANT) old_ = atomicOr(&s.visy[(COL) >> 5], bit_);                                   \
+    const bool fresh_ = (WANT) && !(old_ & bit_);                                           \
     free_l |= fresh_ && (OWNER) == K4_NONE;                                                 \
     const bool enq_ = fresh_ && (OWNER) != K4_NONE;                                         \
     const unsigned long long eb_ = __ballot(enq_);                                          \
@@ -264,12 +259,6 @@ __device__ inline double k4_wave_min(double v) {
       atomicOr(&s.visx[(OWNER) >> 5], 1u << ((OWNER) & 31));                                \
     }                                                                                       \
     qt += __popcll(eb_);                                                                    \
-  } while (0)
-#define K4_CLAIM(WANT, COL, OWNER)                                                          \
-  do {                                                                                      \
-    unsigned old_;                                                                          \
-    K4_TRY(old_, WANT, COL);                                                                \
-    K4_ENQ(old_, WANT, COL, OWNER);                                                         \
   } while (0)
 
 template <bool PROF>
@@ -289,30 +278,20 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
       const int i = base + lane;
       const bool act = i < qe;
       const int xr = s.stx[min(i, qe - 1)];
-      // three LDS round trips per pass: the row records, the visited words and owners of their listed columns, the claims
-      double lxr = s.lx[xr];
-      int tn = s.tln[xr];
+      const double lxr = s.lx[xr];
+      const int tn = s.tln[xr];
       int lc[K4_CAP], mc[K4_CAP];
-      unsigned vw[K4_CAP], old[K4_CAP];
-      bool want[K4_CAP];
+      unsigned vw[K4_CAP];
 #pragma unroll
       for (int k = 0; k < K4_CAP; k++) lc[k] = s.tlc[xr * K4_CAP + k];
-      gh_together(lxr, tn, lc[0], lc[1], lc[2]);
-      static_assert(K4_CAP == 3, "the groups of loads below are written out for three listed columns");
-      int rb = 0, re = 0;
-      if (act && tn == K4_OVER) { rb = (int)s.rptr[xr]; re = (int)s.rptr[xr + 1]; }  // flagged rows: extents of the CSR rows, all at once
 #pragma unroll
       for (int k = 0; k < K4_CAP; k++) { vw[k] = s.visy[lc[k] >> 5]; mc[k] = s.match[lc[k]]; }
-      gh_together(vw[0], vw[1], vw[2], mc[0], mc[1], mc[2]);
       const int t = act ? k4_cnt(tn) : 0;
 #pragma unroll
       for (int k = 0; k < K4_CAP; k++) {  // listed entries are tight (R2): unvisited is all that is asked
-        want[k] = (int)(k < t) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
-        K4_TRY(old[k], want[k], lc[k]);
+        const bool want = (int)(k < t) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
+        K4_CLAIM(want, lc[k], mc[k]);
       }
-      gh_together(old[0], old[1], old[2]);
-#pragma unroll
-      for (int k = 0; k < K4_CAP; k++) K4_ENQ(old[k], want[k], lc[k], mc[k]);
       if (act && (lxr - s.bg) < s.eps && lxr < lflood) lcand = fmin(lcand, lxr);
       unsigned long long ob = __ballot(act && tn == K4_OVER);
       if (PROF) pc[1] += __popcll(ob);
@@ -321,7 +300,7 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
         ob &= ob - 1ull;
         const int xo = __builtin_amdgcn_readlane(xr, l);
         const double lxo = s.lx[xo];
-        const unsigned cb = (unsigned)__builtin_amdgcn_readlane(rb, l), ce = (unsigned)__builtin_amdgcn_readlane(re, l);
+        const unsigned cb = s.rptr[xo], ce = s.rptr[xo + 1];
         for (unsigned c0 = cb; c0 < ce; c0 += 64) {
           const unsigned c = c0 + lane, cc = min(c, ce - 1u);
           const int col = s.cols[cc];
@@ -349,12 +328,12 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
           m[k] = s.match[yc];
           c[k] = (int)(y < n) & (int)(((vw >> (yc & 31)) & 1u) == 0u) & (int)(((lcand + lv) - s.bg) < s.eps);
         }
-        unsigned o[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) K4_TRY(o[k], c[k], min(y0 + k * 64 + lane, n - 1));  // c[k] is false beyond n
-        gh_together(o[0], o[1], o[2], o[3]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) K4_ENQ(o[k], c[k], min(y0 + k * 64 + lane, n - 1), m[k]);
+        for (int k = 0; k < 4; k++) {
+          if (y0 + k * 64 >= n) break;
+          const int y = min(y0 + k * 64 + lane, n - 1);
+          K4_CLAIM(c[k], y, m[k]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -366,20 +345,16 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
   return false;
 }
 #undef K4_CLAIM
-#undef K4_TRY
-#undef K4_ENQ
 
 // ---- R5: the reference's DFS restricted to S (wave 0).  Returns false only on an internal error.
 // One iteration == one findpath() activation or resumption (km.cpp:13-37) and costs two dependent LDS round trips: (1) the
 // row record (label, listed columns), (2) everything the verdict needs -- the visited / S words and the owner of the <= 3 listed
 // columns, and for a 64-column window of background candidates at the E7 pointer of the row's label: ly, visited / S words, owner.
 template <bool PROF>
-__device__ inline bool k4_dfs(const K4& s, int root, int region, int lane, long long* q_iter, long long* q_act, long long* pd) {
+__device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter, long long* q_act, long long* pd) {
   const int n = s.n;
   const double bg = s.bg, eps = s.eps;
-  // the stack holds COLUMNS only (sty): the row of frame f > 0 is the owner of the column frame f - 1 chose, and match[] does not change
-  // before the augmentation -- so stx stays free for the pool of the flagged rows' tight columns (k4_pool_build), which this search reads
-  if (lane == 0) s.sty[0] = (unsigned short)K4_NONE;
+  if (lane == 0) { s.stx[0] = (unsigned short)root; s.sty[0] = (unsigned short)K4_NONE; }
   __builtin_amdgcn_wave_barrier();
   int sp = 0, x = root, ystart = 0;
   double ck = __longlong_as_double(0x7ff8000000000000ll);  // E7 cache, one label per lane: NaN never matches
@@ -390,11 +365,9 @@ __device__ inline bool k4_dfs(const K4& s, int root, int region, int lane, long 
     const long long t_it0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
     int it_type = 0;  // PROF: 0 flagged row, 1 listed-only row, 2 background-tight row with a list, 3 march, 4 ended in a pop
     // ---- round trip 1: the row record
-    double lxv = s.lx[x];
-    int tnv = s.tln[x];
-    int lc = s.tlc[x * K4_CAP + lk];
-    gh_together(lxv, tnv, lc);
-    const int tn = __builtin_amdgcn_readfirstlane(tnv);  // x is wave uniform: branches on the row's kind are scalar
+    const double lxv = s.lx[x];
+    const int tn = s.tln[x];
+    const int lc = s.tlc[x * K4_CAP + lk];
     const int ncnt = k4_cnt(tn);
     const bool bgt = (lxv - bg) < eps;
     if (PROF) it_type = tn == K4_OVER ? 0 : (!bgt ? 1 : (tn != 0 ? 2 : 3));
@@ -412,23 +385,14 @@ __device__ inline bool k4_dfs(const K4& s, int root, int region, int lane, long 
       }
     }
     // ---- round trip 2: listed entries and the first window, issued together
-    // flagged row: its region of the pool (slot in the row's first list entry, k4_pool_build), count and columns in the same round trip
-    const bool pooled = tn == K4_OVER && region > 1;
-    const int pbase = pooled ? __builtin_amdgcn_readlane(lc, 0) * region : 0;
-    int pcnt = s.stx[pbase], pcol = s.stx[pbase + 1 + min(lane, max(region - 2, 0))];
-    unsigned vwL = s.visy[lc >> 5], gwL = s.goody[lc >> 5];
-    int mL = s.match[lc];
+    const unsigned vwL = s.visy[lc >> 5], gwL = s.goody[lc >> 5];
+    const int mL = s.match[lc];
     int yw = p + lane, ywc = min(yw, n - 1);
     unsigned vwW = s.visy[ywc >> 5], gwW = s.goody[ywc >> 5];
     double lyW = s.ly[ywc];
     int mW = s.match[ywc];
-    gh_together(pcnt, pcol, vwL, gwL, mL, vwW, gwW, lyW, mW);
     int best = INT_MAX, mbest = K4_NONE;
-    if (pooled && pcnt != K4_NONE) {  // flagged row, pooled: its tight columns, ascending, are in LDS
-      const bool t = (int)(lane < pcnt) & (int)(pcol >= ystart) & (int)!k4_bit(s.visy, pcol) & (int)k4_bit(s.goody, pcol);
-      const unsigned long long b = __ballot(t);
-      if (b) { best = __builtin_amdgcn_readlane(pcol, (int)__ffsll((long long)b) - 1); mbest = s.match[best]; }
-    } else if (tn == K4_OVER) {  // flagged row, not pooled: lowest tight unvisited good column of the CSR row
+    if (tn == K4_OVER) {  // flagged row: lowest tight unvisited good column of the CSR row
       const unsigned cb = s.rptr[x], ce = s.rptr[x + 1];
       for (unsigned c0 = cb; c0 < ce; c0 += 64) {
         const unsigned c = c0 + lane, cc = min(c, ce - 1u);
@@ -479,9 +443,11 @@ __device__ inline bool k4_dfs(const K4& s, int root, int region, int lane, long 
           const unsigned long long R = bw & (~0ull >> (63 - jstar));  // the picks of this window, in column order
           const unsigned long long below = R & ((1ull << lane) - 1ull);
           const int rank = __popcll(below);
+          const int pm = __shfl(mW, below ? 63 - __clzll((long long)below) : 0, 64);
           if ((R >> lane) & 1ull) {
             atomicOr(&s.visy[yw >> 5], 1u << (yw & 31));
             s.sty[sp + rank] = (unsigned short)yw;
+            if (rank > 0) s.stx[sp + rank] = (unsigned short)pm;  // the row that picked this column (frame sp holds x)
           }
           const int k = __popcll(R), lastlane = 63 - __clzll((long long)R);
           const int mlast = __builtin_amdgcn_readlane(mW, lastlane);
@@ -490,7 +456,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int region, int lane, long 
           p += lastlane + 1;
           if (mlast == K4_NONE) { outcome = 1; break; }
           sp++;
-          if (lane == 0) s.sty[sp] = (unsigned short)K4_NONE;
+          if (lane == 0) { s.stx[sp] = (unsigned short)mlast; s.sty[sp] = (unsigned short)K4_NONE; }
           x = mlast; ystart = 0;
           if (stop) { outcome = 2; break; }  // the owner of the last pick is not part of the chain
           if (PROF) ++*q_act;                // ... it is: its activation continues the march
@@ -517,13 +483,12 @@ __device__ inline bool k4_dfs(const K4& s, int root, int region, int lane, long 
       if (lane == 0) { atomicOr(&s.visy[best >> 5], 1u << (best & 31)); s.sty[sp] = (unsigned short)best; }
       if (mbest == K4_NONE) break;
       sp++;
-      if (lane == 0) s.sty[sp] = (unsigned short)K4_NONE;
+      if (lane == 0) { s.stx[sp] = (unsigned short)mbest; s.sty[sp] = (unsigned short)K4_NONE; }
       x = mbest; ystart = 0;
     } else {
       sp--;
       if (sp < 0) return false;
-      ystart = (int)s.sty[sp] + 1;
-      x = sp ? (int)s.match[s.sty[sp - 1]] : root;
+      x = s.stx[sp]; ystart = (int)s.sty[sp] + 1;
       if (PROF) { pd[4]++; pd[9] += (long long)__builtin_readcyclecounter() - t_it0; }
     }
     __builtin_amdgcn_wave_barrier();
@@ -531,15 +496,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int region, int lane, long 
   // augment: match[y] = x on every level of the recursion (km.cpp:26-29); the last column is no longer free
   __builtin_amdgcn_wave_barrier();
   const int ylast = s.sty[sp];
-  for (int hi = sp; hi >= 0; hi -= 64) {  // top down: a frame reads the owner of the column below it before that column changes hands
-    const int f = hi - lane;
-    int col = 0, row = root;
-    if (f >= 0) col = s.sty[f];
-    if (f > 0) row = s.match[s.sty[f - 1]];
-    __builtin_amdgcn_wave_barrier();
-    if (f >= 0) s.match[col] = (unsigned short)row;
-    __builtin_amdgcn_wave_barrier();
-  }
+  for (int f = lane; f <= sp; f += 64) s.match[s.sty[f]] = s.stx[f];
   if (lane == 0) atomicAnd(&s.freey[ylast >> 5], ~(1u << (ylast & 31)));
   return true;
 }
@@ -800,7 +757,6 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
           const int i = fb + wave * 4 + (lane >> 4), lig = lane & 15;
           int x = -1, cnt = 0;
           if (i < nf) { x = s.sty[i]; cnt = s.stx[i * region]; }
-          if (cnt == K4_NONE) cnt = 0;  // not pooled (already in S)
           bool hit = false;
           if (x >= 0 && !k4_bit(s.good, x))
             for (int e = lig; e < cnt; e += 16) hit |= k4_bit(s.goody, s.stx[i * region + 1 + e]);
@@ -820,7 +776,7 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
       if (PROF) c_pull += t2 - t1;
       // ... then the DFS (wave 0)
       if (wave == sw) {
-        const bool ok = k4_dfs<PROF>(s, root, region, lane, &q_iter, &q_act, pd);
+        const bool ok = k4_dfs<PROF>(s, root, lane, &q_iter, &q_act, pd);
         if (!ok && lane == 0) s.sh[SH_BAD] = 3;
       }
       __syncthreads();
