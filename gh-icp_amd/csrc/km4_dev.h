@@ -42,7 +42,10 @@ namespace {
 
 
 constexpr int K4_CAP = 3;
-constexpr int K4_OVER = 255;  // tln: 0..3 = listed entries; 255 = flagged (more than 3 tight entries when the list was built)
+constexpr int K4_OVER = 255;  // tln: 0..3 = listed entries; above = flagged (more than 3 tight entries when the list was built):
+                              // 4..6 = so many, and their COLUMNS are kept as hints (rule R5); 255 = more than 6
+constexpr int K4_HINT = 2 * K4_CAP;
+constexpr bool K4_POOL = true;  // flagged rows without hints: gather their tight columns once per augmenting phase (else: members of S)
 constexpr int K4_T = 256;
 constexpr int K4_NONE = 0xFFFF;
 constexpr double K4_INF = 1000.0;  // km.cpp:42
@@ -67,7 +70,8 @@ struct K4 {
 };
 
 __device__ inline bool k4_bit(const unsigned* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
-__device__ inline int k4_cnt(int tn) { return tn == K4_OVER ? 0 : tn; }  // listed entries (0 for flagged rows)
+__device__ inline bool k4_flagged(int tn) { return tn > K4_CAP; }
+__device__ inline int k4_cnt(int tn) { return tn > K4_CAP ? 0 : tn; }  // listed entries (0 for flagged rows)
 
 // Bulk pass over rows list[0..count), all 4 waves: REBUILD writes the rows' lists (R2), PUSH sends the slack minima of their
 // non-tight entries (R4), ONLY_UNPUSHED skips rows whose minima are already in slack.  16 lanes per row, so a wave instruction works
@@ -113,12 +117,18 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
             const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
             if (rk < K4_CAP) { s.tlc[x * K4_CAP + rk] = (unsigned short)col[j]; s.tlo[x * K4_CAP + rk] = (unsigned short)(c[j] - cb); }
           }
+          // entries 4..6 of a row that turns out flagged: their columns over the offsets, which a flagged row never uses.  A separate
+          // store AFTER the one above: entries 1..3 come earlier in the row, so in program order the hints land last
+          if (in && td) {
+            const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
+            if (rk >= K4_CAP && rk < K4_HINT) s.tlo[x * K4_CAP + rk - K4_CAP] = (unsigned short)col[j];
+          }
           cnt += __popc(gb);
         }
       }
     }
     if (REBUILD && lig == 0 && x >= 0) {
-      const int tn = cnt > K4_CAP ? K4_OVER : cnt;
+      const int tn = cnt > K4_HINT ? K4_OVER : cnt;
       const bool over = tn == K4_OVER, was = s.tln[x] == K4_OVER;
       s.tln[x] = (unsigned char)tn;
       if (over != was) {
@@ -154,7 +164,7 @@ __device__ inline void k4_revalidate(const K4& s, int tid) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int i = base + k * K4_T;
-      if (i >= s.n || tn[k] == 0 || tn[k] == K4_OVER || ((px[k] >> (i & 31)) & 1u)) continue;
+      if (i >= s.n || tn[k] == 0 || k4_flagged(tn[k]) || ((px[k] >> (i & 31)) & 1u)) continue;
       bool hit = false;
 #pragma unroll
       for (int e = 0; e < K4_CAP; e++) hit |= (int)(e < tn[k]) & (int)((pv[k][e] >> (lc[k][e] & 31)) & 1u);
@@ -293,7 +303,7 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
         K4_CLAIM(want, lc[k], mc[k]);
       }
       if (act && (lxr - s.bg) < s.eps && lxr < lflood) lcand = fmin(lcand, lxr);
-      unsigned long long ob = __ballot(act && tn == K4_OVER);
+      unsigned long long ob = __ballot(act && k4_flagged(tn));
       if (PROF) pc[1] += __popcll(ob);
       while (ob) {  // flagged rows: every tight entry of the CSR row
         const int l = (int)__ffsll((long long)ob) - 1;
@@ -370,7 +380,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
     const int lc = s.tlc[x * K4_CAP + lk];
     const int ncnt = k4_cnt(tn);
     const bool bgt = (lxv - bg) < eps;
-    if (PROF) it_type = tn == K4_OVER ? 0 : (!bgt ? 1 : (tn != 0 ? 2 : 3));
+    if (PROF) it_type = k4_flagged(tn) ? 0 : (!bgt ? 1 : (tn != 0 ? 2 : 3));
     int slot = 0, p = n;
     if (bgt) {  // E7: one scan pointer per distinct label value; everything below ystart is dead for this label as well
       const unsigned long long hit = __ballot(ck == lxv);
@@ -392,7 +402,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
     double lyW = s.ly[ywc];
     int mW = s.match[ywc];
     int best = INT_MAX, mbest = K4_NONE;
-    if (tn == K4_OVER) {  // flagged row: lowest tight unvisited good column of the CSR row
+    if (k4_flagged(tn)) {  // flagged row: lowest tight unvisited good column of the CSR row
       const unsigned cb = s.rptr[x], ce = s.rptr[x + 1];
       for (unsigned c0 = cb; c0 < ce; c0 += 64) {
         const unsigned c = c0 + lane, cc = min(c, ce - 1u);
@@ -682,9 +692,9 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         continue;
       }
       // ---- R5: augmenting phase.  S by pull rounds ...
-      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = 0u; s.goody[w] = s.freey[w]; }
-      if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; }
-      if (wave == 0) {  // the flagged rows, ascending, into sty
+      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = K4_POOL ? 0u : s.ovf[w]; s.goody[w] = s.freey[w]; }
+      if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; s.sh[SH_NF] = 0; }
+      if (K4_POOL && wave == 0) {  // the flagged rows without hints, ascending, into sty
         int cnt = 0;
         for (int base = 0; base < n; base += 64) {
           const int x = base + lane;
@@ -726,30 +736,32 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         __syncthreads();
         if (tid == 0) s.sh[SH_CH0 + ((round + 1) & 1)] = 0;
         bool ch = false;
-        for (int base = tid; base < n; base += 4 * K4_T) {  // rows: background-tight to the best column of S, or a listed entry in S
-          int xx[4], tn[4], lc[4][K4_CAP];
-          unsigned gdw[4];
-          double lxv[4];
+        for (int base = tid; base < n; base += 2 * K4_T) {  // rows (two per thread and pass: the hints doubled the registers a row needs): background-tight to the best column of S, or a listed entry in S
+          int xx[2], tn[2], lc[2][K4_HINT];
+          unsigned gdw[2];
+          double lxv[2];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < 2; k++) {
             xx[k] = base + k * K4_T;
             const int xc = min(xx[k], n - 1);
             gdw[k] = s.good[xc >> 5]; lxv[k] = s.lx[xc]; tn[k] = s.tln[xc];
 #pragma unroll
-            for (int e = 0; e < K4_CAP; e++) lc[k][e] = s.tlc[xc * K4_CAP + e];
+            for (int e = 0; e < K4_CAP; e++) { lc[k][e] = s.tlc[xc * K4_CAP + e]; lc[k][K4_CAP + e] = s.tlo[xc * K4_CAP + e]; }
           }
-          unsigned gyw[4][K4_CAP];
+          unsigned gyw[2][K4_HINT];
 #pragma unroll
-          for (int k = 0; k < 4; k++)
+          for (int k = 0; k < 2; k++)
 #pragma unroll
-            for (int e = 0; e < K4_CAP; e++) gyw[k][e] = s.goody[lc[k][e] >> 5];
+            for (int e = 0; e < K4_HINT; e++) gyw[k][e] = s.goody[lc[k][e] >> 5];  // (a listed row's slots 4..6 hold CSR offsets: < n, any word will do)
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < 2; k++) {
             if (xx[k] >= n || ((gdw[k] >> (xx[k] & 31)) & 1u)) continue;
             bool g = (lxv[k] - bg) < eps;  // background-tight to a free column: those are in S and their label is still 0, the smallest there is
-            const int t = k4_cnt(tn[k]);
+            // listed entries are tight (R2); the hints of a flagged row are the columns that WERE tight when its list was built -- entries
+            // only leave between two rebuilds of a row, so "a hint in S" is necessary for the row to be good (R5)
+            const int t = tn[k] <= K4_HINT ? tn[k] : 0;
 #pragma unroll
-            for (int e = 0; e < K4_CAP; e++) g |= (int)(e < t) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);  // listed = tight (R2)
+            for (int e = 0; e < K4_HINT; e++) g |= (int)(e < t) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);
             if (g) { atomicOr(&s.good[xx[k] >> 5], 1u << (xx[k] & 31)); ch = true; }
           }
         }
