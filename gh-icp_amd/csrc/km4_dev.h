@@ -9,8 +9,8 @@
 //       i.e. for columns visited by a failed phase: rows that were not visited but list such a column re-test their entries (one
 //       value load through the stored offset) right after the relabelling.  So a listed entry needs no value and no test at use:
 //       the flood, the DFS and the S rounds read columns only.  (Round 2 kept (column, weight) pairs as a superset and re-tested at
-//       every use: 61.75 B per row, three problems per CU.)  Rows with more than 3 tight entries are flagged (scanned from the CSR
-//       row with the test, never pruned).
+//       every use: 61.75 B per row, three problems per CU.)  Rows with more than 3 tight entries are flagged (the flood and the
+//       DFS scan their CSR row with the test).
 //   R3  every phase starts with an order-free flood from the root (wave 0; lists + one sweep of
 //       T_L = {y : fl(fl(L+ly[y]) - bg) < eps} for the smallest label met -- T_L is nested in L).  No free column reached:
 //       the phase FAILS and the visited sets are the reference's (a failed findpath() visits exactly the reachable set).
@@ -25,11 +25,15 @@
 //       fails whatever has been visited and visits only rows that are not good, so the reference's DFS may skip columns
 //       whose owner lies outside any superset S of good without changing its path.  S = fixed point of "(lx - bg) < eps
 //       (background-tight to a free column: free columns were never relabelled, their ly is 0 and no ly is negative), or a tight
-//       explicit entry in a column of S" (256 threads, one row each per round, ~4 rounds).  Listed rows test their list; flagged
-//       rows test their tight columns, gathered once per phase into a pool (k4_pool_build) -- until the second half of round 3
-//       they were simply members of S, and 28 % of the DFS iterations were pops out of flagged rows that lead nowhere.  Wave 0
-//       then runs the reference's DFS restricted to S: E7 pointer, E9 march (km2.hip), all in LDS; what is left of the search
-//       is essentially the augmenting path itself.
+//       explicit entry in a column of S" (256 threads, two rows each per pass, ~5 rounds).  Listed rows test their list.  A
+//       flagged row with 4..6 tight entries when its list was built keeps their COLUMNS (entries 4..6 in the offset slots, which
+//       a flagged row never uses): entries only leave the tight set between two rebuilds of a row (R2), so "one of these hints
+//       lies in S" is NECESSARY for the row to be good, and the generic round tests it like a list of six.  Rows with more than
+//       six test their tight columns, gathered once per phase into a pool (k4_pool_build; ~7 rows per phase on the cfg2
+//       matrices).  Until the second half of round 3 every flagged row was simply a member of S, and 28 % of the DFS iterations
+//       were pops out of flagged rows that lead nowhere (profiles/r03_km4_second_half.txt: 58 / 104 / 44 -> 49 / 85 / 37 ms).
+//       Wave 0 then runs the reference's DFS restricted to S: E7 pointer, E9 march (km2.hip), all in LDS; what is left of
+//       the search is essentially the augmenting path itself.
 // (device code; included by km4.hip -- the stand-alone solve kernel -- and by loop.hip -- the persistent pair loop)
 #pragma once
 #include "ctx.h"
@@ -183,9 +187,11 @@ __device__ inline void k4_revalidate(const K4& s, int tid) {
   }
 }
 
-// R5, flagged rows: S should hold a flagged row only if the row can be good -- one of its tight entries lies in a column of S, or it
-// is background-tight to the best column of S -- not unconditionally (round 2 and the first half of round 3 did that, and the DFS then
-// descended into flagged rows that lead nowhere: 28 % of its iterations were the pops that followed, profiles/r03_km_dfs_kinds.txt).
+// R5, flagged rows without hints (more than K4_HINT tight entries): S should hold such a row only if the row can be good -- one of its
+// tight entries lies in a column of S, or it is background-tight to a free column -- not unconditionally (round 2 and the first half
+// of round 3 did that for every flagged row, and the DFS then descended into flagged rows that lead nowhere: 28 % of its iterations were
+// the pops that followed, profiles/r03_km_dfs_kinds.txt).  Pooling EVERY flagged row cost more in the S rounds than it saved in the DFS
+// (profiles/r03_km4_second_half.txt, v1); with the hints only the few rows beyond six entries come here.
 // The S rounds cannot afford a CSR scan per flagged row per round, so the rows' tight columns are gathered ONCE per augmenting
 // phase into a pool: the flood's queue stx is dead by then and the DFS has not started, so stx is the pool (region r = `region`
 // u16 per flagged row: count, then the columns, ascending) and sty holds the list of flagged rows.  A row with more tight entries than

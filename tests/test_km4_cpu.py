@@ -25,6 +25,13 @@ def test_km4_model_real_matrices(oracle, it):
         assert m is not None, "hazard on a real matrix"
         np.testing.assert_array_equal(m, ref)
         assert st["failed"] in (727, 3193, 784) and (cap != 3 or st["dfs_steps"] < 200_000)
+    # the kernel's treatment of flagged rows (hints for 4..6 tight entries, the others tested exactly): same matching, and the
+    # activation / round counts are the ones k_km4 itself reports on these matrices (GHICP_KM_STATS, profiles/r03_km4_second_half.txt)
+    m, st = oracle.km4_model(w, cap=3, hint=6, exact_rest=True)
+    np.testing.assert_array_equal(m, ref)
+    assert (st["dfs_steps"], st["pull_rounds"]) == {0: (156555, 4324), 10: (14409, 4208), 30: (58440, 2928)}[it]
+    base = oracle.km4_model(w, cap=3)[1]
+    assert st["dfs_pops"] * 2 < base["dfs_pops"]  # what the rule is for: the pops out of flagged rows that lead nowhere
 
 
 def test_km4_model_fuzz(oracle):
@@ -37,6 +44,10 @@ def test_km4_model_fuzz(oracle):
             m, _ = oracle.km4_model(w, cap=cap, prune=prune)
             assert m is not None
             np.testing.assert_array_equal(m, ref, err_msg="t=%d n=%d cap=%d prune=%s" % (t, n, cap, prune))
+        for kw in (dict(hint=6, exact_rest=True), dict(hint=6), dict(exact_s=True), dict(cap=1, hint=2, exact_rest=True)):
+            m, _ = oracle.km4_model(w, **kw)  # returns status 6 (raises) if the best column of S ever has a label other than 0
+            assert m is not None
+            np.testing.assert_array_equal(m, ref, err_msg="t=%d n=%d %r" % (t, n, kw))
 
 
 def test_km4_model_kat_and_degenerate(oracle):
