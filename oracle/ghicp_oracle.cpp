@@ -930,6 +930,11 @@ void orc_rigid_svd(const double* src, const double* tgt, int c, double* Rt16) {
 //   FD      : ks x kt f64 row-major (calFD_* output) or NULL for feature None.
 //   trace   : max_iter records; matchlist: max_iter x ks ints (T index or -1) or NULL.
 // Returns the number of iterations executed.
+// Test hook: called with every Kuhn-Munkres weight matrix a registration solves (iteration, n, n x n row-major weights, penalty) --
+// scripts/km_hazard_survey.py feeds them to the model of the GPU solver to see which rules fire on real registrations.
+static void (*g_km_observer)(int, int, const double*, double) = nullptr;
+void orc_set_km_observer(void (*cb)(int, int, const double*, double)) { g_km_observer = cb; }
+
 int orc_register(const orc_params* P, const double* kpS_in, int ks, const double* kpT, int kt, const double* FD, double* Rt_final,
                  orc_iter* trace, int* matchlist, double* km_seconds) {
   const int BSC = 0, NONE = 3, NN = 0, NNR = 1, KMc = 2;
@@ -1005,6 +1010,7 @@ int orc_register(const orc_params* P, const double* kpS_in, int ks, const double
       std::vector<double> gw((size_t)n * n, -penalty);
       for (int i = 0; i < ks; i++)
         for (int j = 0; j < kt; j++) if (CD[(size_t)i * kt + j] < penalty) gw[(size_t)i * n + j] = -CD[(size_t)i * kt + j];
+      if (g_km_observer) g_km_observer(it, n, gw.data(), penalty);
       orc::KM km;
       km.n = n; km.w = gw.data(); km.eps = P->km_eps;
       km.solve();
