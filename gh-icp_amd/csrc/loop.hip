@@ -589,6 +589,12 @@ __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restric
   volatile int* s_idx = ired + 18;  // (no static LDS in this kernel: the launch may ask for all 160 KB as dynamic LDS)
   const unsigned long long t_slot0 = lstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned long long t_solve = 0ull, t_solve_max = 0ull, n_solve = 0ull;
+  // A slot is one wave's dependent instruction stream for most of its life (the solver's flood and DFS), and in the tail of a batch it
+  // shares its SIMD with the throughput kernels of the next batch's front end: behind 7 ALU-bound waves it would get every eighth issue
+  // slot.  The heaviest matrices of the 64 bench scenes are the LATE iterations of the slowest pairs -- exactly the tail --, ~240 ms
+  // alone by the model (scripts/km_hazard_survey.py; none of 2220 solves takes the hazard fallback), yet default runs show single solves
+  // of 1-4 s (pair_loop_stats.longest_solve_ms).  Highest wave priority: the slot wins the arbitration whenever it can issue at all.
+  __builtin_amdgcn_s_setprio(3);
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) *s_idx = atomicAdd(qhead, 1);

@@ -87,6 +87,7 @@ static inline void __threadfence() {}
 static inline void __builtin_amdgcn_wave_barrier(int line = __builtin_LINE()) { hipsim::wave_collective(hipsim::OP_BARRIER, line, 0, 0); }
 static inline void __builtin_amdgcn_s_barrier() { hipsim::sync_threads(); }
 static inline void __builtin_amdgcn_s_sleep(int) { hipsim::yield(); }
+static inline void __builtin_amdgcn_s_setprio(int) {}  // issue arbitration between the waves of a SIMD: nothing to model
 static inline unsigned long long __ballot(int pred, int line = __builtin_LINE()) {
   return hipsim::wave_collective(hipsim::OP_BALLOT, line, pred ? 1 : 0, 0);
 }
