@@ -75,10 +75,13 @@ def test_gpu_reproduces_golden(ctx, api, gold, gin):
         np.testing.assert_allclose(r["Rt"], gold["loop"][name + "_Rt"], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("it", [0, 10, 30])
-def test_real_km_matrices_sparse_goldens_oracle(oracle, it):
-    """The three real cfg2 weight matrices kept as sparse goldens: the restatement and the reference's own km.cpp agree on them."""
-    z = np.load(os.path.join(GOLD, "km_cfg2_it%d.npz" % it))
+REAL_KM = ["it0", "it10", "it30", "s22_it46", "s53_it0"]  # scene 0 iterations 0 / 10 / 30; the heaviest and the largest matrix of the 64 bench scenes
+
+
+@pytest.mark.parametrize("name", REAL_KM)
+def test_real_km_matrices_sparse_goldens_oracle(oracle, name):
+    """Real cfg2 weight matrices kept as sparse goldens: the restatement and the reference's own km.cpp agree on them."""
+    z = np.load(os.path.join(GOLD, "km_cfg2_%s.npz" % name))
     n = int(z["n"])
     w = np.full((n, n), float(z["bg"]))
     w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
@@ -90,9 +93,9 @@ def test_real_km_matrices_sparse_goldens_oracle(oracle, it):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("it", [0, 10, 30])
-def test_real_km_matrices_gpu(ctx, oracle, it):
-    z = np.load(os.path.join(GOLD, "km_cfg2_it%d.npz" % it))
+@pytest.mark.parametrize("name", REAL_KM)
+def test_real_km_matrices_gpu(ctx, oracle, name):
+    z = np.load(os.path.join(GOLD, "km_cfg2_%s.npz" % name))
     n = int(z["n"])
     w = np.full((n, n), float(z["bg"]))
     w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]

@@ -34,6 +34,20 @@ def test_km4_model_real_matrices(oracle, it):
     assert st["dfs_pops"] * 2 < base["dfs_pops"]  # what the rule is for: the pops out of flagged rows that lead nowhere
 
 
+@pytest.mark.parametrize("name,counts", [("s22_it46", (26328, 8446, 6943)), ("s53_it0", (354958, 5176, 424))])
+def test_km4_model_heaviest_and_largest_matrix(oracle, name, counts):
+    """The heaviest (scene 22, iteration 46: 6943 failed phases) and the largest (scene 53, n = 1131) of the 2220 matrices the 64 bench
+    scenes solve (scripts/km_hazard_survey.py): no hazard, the reference's matching, the counts the survey reported."""
+    z = np.load(os.path.join(GOLD, "km_cfg2_%s.npz" % name))
+    n = int(z["n"])
+    w = np.full((n, n), float(z["bg"]))
+    w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
+    m, st = oracle.km4_model(w, cap=3, hint=6, exact_rest=True)
+    assert m is not None
+    np.testing.assert_array_equal(m, oracle.km(w)[0])
+    assert (st["dfs_steps"], st["pull_rounds"], st["failed"]) == counts
+
+
 def test_km4_model_fuzz(oracle):
     rng = np.random.default_rng(20260925)
     for t in range(400):

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # the slow ones stay on the GPU (and on `GHICP_SIM=1 python -m pytest tests -m gpu` when a kernel is being changed)
 SLOW = ["register_pairs_batch_equals_single", "pair_pipeline_vs_oracle", "pair_pipeline_fpfh_nnr", "cached_clouds_match_pair_api", "beyond_the_lds",
-        "sbf_dump_round_trip", "icp_after_coarse", "km_kat_and_random", "cpp_dropin", "full_size", "multiview", "large_extent", "cfg4_all_64", "fixture"]
+        "sbf_dump_round_trip", "icp_after_coarse", "km_kat_and_random", "cpp_dropin", "full_size", "multiview", "large_extent", "cfg4_all_64", "fixture", "s22_it46"]
 
 
 def test_package_never_loads_the_simulated_library():
