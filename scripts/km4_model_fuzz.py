@@ -43,15 +43,16 @@ def main():
         n = int(rng.choice([3, 5, 8, 17, 40, 65, 100, 130, 200]))
         w = gen(rng, n, t % 5)
         ref, _ = O.km(w)
-        for cap, prune in ((1, True), (3, True), (3, False), (6, True)):
-            m, _st = O.km4_model(w, cap=cap, prune=prune)
+        for cap, prune, kw in ((1, True, {}), (3, True, {}), (3, False, {}), (6, True, {}), (3, True, dict(hint=6, exact_rest=True)),
+                               (3, True, dict(hint=6, exact_rest=True, seed=True))):  # the kernel's rule R5; R3' (groundwork, self-checked)
+            m, _st = O.km4_model(w, cap=cap, prune=prune, **kw)
             if m is None:
                 hazards += 1
                 continue
             if not (m == ref).all():
                 bad += 1
                 np.save('/tmp/km4_counterexample_%d.npy' % t, w)
-                print('MISMATCH t', t, 'n', n, 'kind', t % 5, 'cap', cap, 'prune', prune, flush=True)
+                print('MISMATCH t', t, 'n', n, 'kind', t % 5, 'cap', cap, 'prune', prune, kw, flush=True)
     print('matrices', N, 'mismatches', bad, 'hazard reports', hazards, 'seconds %.1f' % (time.time() - t0))
 
 

@@ -3,7 +3,8 @@ solve to the rule-level model of the GPU solver (oracle/km4_model.inc, the kerne
 Answers what a default bench run cannot: how often rule R4's hazard fires on real registrations (the kernel then re-solves the whole
 problem on one lane -- the suspected source of the 1-4 s solves), and how the phase / flood / DFS counts that drive a
 solve's time are distributed over the iterations of a pair.
-    python scripts/km_hazard_survey.py [first_pair] [pairs] [procs]      -> one line per pair + a summary; --json FILE keeps the records"""
+    python scripts/km_hazard_survey.py [first_pair] [pairs] [procs]      -> one line per pair + a summary; --json FILE keeps the records;
+    --seed runs the model with the seeded flood (R3', design groundwork) and reports how many floods could not be certified"""
 import ctypes as C
 import importlib
 import json
@@ -14,7 +15,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-NAMES = ("phases", "failed", "flood_rows", "push_rows", "rebuild_rows", "pull_rounds", "dfs_steps", "dfs_pops", "overflow_rows")
+NAMES = ("phases", "failed", "flood_rows", "push_rows", "rebuild_rows", "pull_rounds", "dfs_steps", "dfs_pops", "overflow_rows", "seeded", "unseeded")
+SEED = "--seed" in sys.argv  # rule R3' of the model (seeded flood with a tree-edge certificate; self-checked: status 7 on a wrong closure)
 
 
 def work(pair_id):
@@ -33,10 +35,10 @@ def work(pair_id):
     @C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double)
     def observer(it, n, w, penalty):
         match = np.empty(n, np.int32)
-        st = np.zeros(9, np.int64)
+        st = np.zeros(11, np.int64)
         t = time.perf_counter()
         rc = lib.orc_km4_model(w, n, C.c_double(0.01), match.ctypes.data_as(C.POINTER(C.c_int)), st.ctypes.data_as(C.POINTER(C.c_longlong)),
-                               3 | (6 << 10) | 0x10000)
+                               3 | (6 << 10) | 0x10000 | (0x20000 if SEED else 0))
         a = np.ctypeslib.as_array(w, shape=(n * n,))
         recs.append(dict(it=it, n=n, rc=rc, nnz=int((a != -penalty).sum()), model_s=time.perf_counter() - t, **dict(zip(NAMES, (int(v) for v in st)))))
 
@@ -73,6 +75,9 @@ def main():
                                                           min(k["failed"] for k in km), sum(k["failed"] for k in km) / len(km), max(k["failed"] for k in km),
                                                           max(k["flood_rows"] for k in km), max(k["dfs_steps"] for k in km)), flush=True)
     print("solves %d, hazard reports %d (%.2f %%)" % (solves, hazards, 100.0 * hazards / max(1, solves)))
+    if SEED:
+        print("seeded floods %d, not certified (flood from the root) %d, flood rows %d" % (sum(k["seeded"] for r in res for k in r["km"]),
+              sum(k["unseeded"] for r in res for k in r["km"]), sum(k["flood_rows"] for r in res for k in r["km"])))
     worst.sort(reverse=True, key=lambda t: t[0])
     for _, pair, k in worst[:3]:
         print("heaviest solve: pair %d iteration %d n %d: %s" % (pair, k["it"], k["n"], {n: k[n] for n in NAMES}))

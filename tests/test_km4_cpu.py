@@ -32,6 +32,12 @@ def test_km4_model_real_matrices(oracle, it):
     assert (st["dfs_steps"], st["pull_rounds"]) == {0: (156555, 4324), 10: (14409, 4208), 30: (58440, 2928)}[it]
     base = oracle.km4_model(w, cap=3)[1]
     assert st["dfs_pops"] * 2 < base["dfs_pops"]  # what the rule is for: the pops out of flagged rows that lead nowhere
+    # design groundwork (not in the kernel): the seeded flood of rule R3' -- same matching, every failed-phase flood certified,
+    # the closure checked against a flood from the root inside the model, and what it is for: the rows a flood has to visit
+    m2, s2 = oracle.km4_model(w, cap=3, hint=6, exact_rest=True, seed=True)
+    np.testing.assert_array_equal(m2, ref)
+    assert s2["unseeded"] == 0 and s2["seeded"] == s2["failed"] and s2["flood_rows"] * 1.9 < st["flood_rows"]
+    assert all(s2[k] == st[k] for k in ("phases", "failed", "push_rows", "rebuild_rows", "pull_rounds", "dfs_steps"))
 
 
 @pytest.mark.parametrize("name,counts", [("s22_it46", (26328, 8446, 6943)), ("s53_it0", (354958, 5176, 424))])
@@ -58,7 +64,8 @@ def test_km4_model_fuzz(oracle):
             m, _ = oracle.km4_model(w, cap=cap, prune=prune)
             assert m is not None
             np.testing.assert_array_equal(m, ref, err_msg="t=%d n=%d cap=%d prune=%s" % (t, n, cap, prune))
-        for kw in (dict(hint=6, exact_rest=True), dict(hint=6), dict(exact_s=True), dict(cap=1, hint=2, exact_rest=True)):
+        for kw in (dict(hint=6, exact_rest=True), dict(hint=6), dict(exact_s=True), dict(cap=1, hint=2, exact_rest=True),
+                   dict(hint=6, exact_rest=True, seed=True), dict(prune=False, seed=True)):  # seed: R3', self-checked (status 7 raises)
             m, _ = oracle.km4_model(w, **kw)  # returns status 6 (raises) if the best column of S ever has a label other than 0
             assert m is not None
             np.testing.assert_array_equal(m, ref, err_msg="t=%d n=%d %r" % (t, n, kw))
