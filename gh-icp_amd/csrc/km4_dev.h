@@ -2,7 +2,7 @@
 // reference's depth-first search wherever its outcome is order independent.  One 256-thread workgroup per problem, all
 // solver state in LDS (44 B per row: 4 problems per CU up to n = 930), the CSR of the explicit entries streamed from global
 // memory only by the bulk passes of failed phases.  Rules (oracle/km4_model.inc states them sequentially and is fuzzed against
-// the reference traversal; R1 = E1-E3 of km2.hip):
+// the reference traversal; R1 = E1-E3 of round 1's solver, whose rules E1-E12 oracle/km_model.inc still states):
 //   R2  per row a list of <= 3 columns in LDS, ascending, EXACTLY the row's tight explicit entries (fl(fl(lx+ly) - w) < eps), plus
 //       each entry's offset in its CSR row.  An explicit entry can only BECOME tight when its row label drops, i.e. for rows visited
 //       by a failed phase: those lists are rebuilt after the relabelling.  It can only STOP being tight when its column label rises,
@@ -32,7 +32,7 @@
 //       six test their tight columns, gathered once per phase into a pool (k4_pool_build; ~7 rows per phase on the cfg2
 //       matrices).  Until the second half of round 3 every flagged row was simply a member of S, and 28 % of the DFS iterations
 //       were pops out of flagged rows that lead nowhere (profiles/r03_km4_second_half.txt: 58 / 104 / 44 -> 49 / 85 / 37 ms).
-//       Wave 0 then runs the reference's DFS restricted to S: E7 pointer, E9 march (km2.hip), all in LDS; what is left of
+//       Wave 0 then runs the reference's DFS restricted to S: E7 pointer, E9 march (oracle/km_model.inc), all in LDS; what is left of
 //       the search is essentially the augmenting path itself.
 // (device code; included by km4.hip -- the stand-alone solve kernel -- and by loop.hip -- the persistent pair loop)
 #pragma once
@@ -447,7 +447,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
           if (lane == slot) cp = best;
         } else if (lane == slot) cp = max(p, lim);
       } else {
-        // ---- E9 march (km2.hip): a chain of rows without tight explicit entries that share the label L picks the members of
+        // ---- E9 march (oracle/km_model.inc): a chain of rows without tight explicit entries that share the label L picks the members of
         // T_L in column order, up to 64 activations per window (lim == n here: the row has no listed entry)
         int outcome = bw ? 3 : 0;
         if (!bw) p = n;  // the skip loop above has covered every column below n

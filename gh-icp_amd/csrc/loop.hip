@@ -1,17 +1,20 @@
 // GH-ICP iteration loop on gfx950: replaces GHRegistration::ghicp_reg and its private helpers
 // (reference src/ghicp_reg.cpp:24-112, 114-139, 216-341, 343-460, 548-578, 605-927).
 //
-// The loop is BATCHED: every kernel takes an array of per-pair descriptors (LoopProb) and one launch
-// advances all pairs of the batch by one stage; a pair that has converged makes its blocks exit at once.
-// Independent scan pairs are the parallel axis of this problem -- the per-pair KM solve is a
-// dependency chain, so throughput comes from many pairs in flight, one wave each (km2.hip).
-//
-// Per iteration, for all pairs (no host round-trip; the host polls the `done` flags every 2nd iteration):
-//   k_cd_rowmin      fused calED + calCD_* + row arg-min (+ column arg-min sweep for NNR) + sum / sum^2 over
+// Independent scan pairs are the parallel axis of this problem: the per-pair Kuhn-Munkres solve is one wave's dependency
+// chain for most of its time, so throughput comes from many pairs in flight.  Every stage is a device function over a per-pair
+// descriptor (LoopProb), used in two ways:
+//   * Kuhn-Munkres batches whose graphs fit the LDS-resident solver: the PERSISTENT pair loop k_pair_loop -- one 256-thread workgroup is
+//     one solve slot, pops a pair from its class queue and runs the pair's whole ghicp_reg loop, iteration after iteration, before it
+//     pops the next;
+//   * NN / NNR batches and graphs beyond LDS: one launch per stage advances all pairs of the batch by one stage (thin kernel wrappers
+//     around the same device functions); a pair that has converged makes its blocks exit at once, the host polls the `done` flags.
+// Stages of one iteration:
+//   dev_cd_rowmin    fused calED + calCD_* + row arg-min (+ column arg-min sweep for NNR) + sum / sum^2 over
 //                    K_S x K_T; no f64 ED/CD matrix is ever materialised                        (S5, HBM-bound)
-//   k_penalty        CDmean / CDstd -> penalty (calCD_* tails)                                    (scalar)
-//   [KM] k_km_csr x2 + scan + k_km2 (sparse exact Kuhn-Munkres, km2.hip)                          (S5 KM)
-//   k_solve          accept correspondences, RMSE/FDM/FDstd, float-Umeyama rigid solve, apply to all source
+//   dev_penalty      CDmean / CDstd -> penalty (calCD_* tails)                                    (scalar)
+//   [KM] dev_km_csr x2 + dev_km_scan_desc + k4_solve_block (sparse exact Kuhn-Munkres, km4_dev.h)  (S5 KM)
+//   dev_solve        accept correspondences, RMSE/FDM/FDstd, float-Umeyama rigid solve, apply to all source
 //                    keypoints, RMSE-after, Euler convergence test, adjustweight, Rt product       (S6)
 #include "ctx.h"
 #include "devmath.h"
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void k_km_weights(const LoopProb* __restrict__
   P.kmw[(size_t)i * C.n + j] = out;
 }
 
-// Sparse KM input (km2.hip): per row the explicit entries (j, -CD) with CD < penalty (ghicp_reg.cpp:358-365);
+// Sparse KM input (km_prob.h): per row the explicit entries (j, -CD) with CD < penalty (ghicp_reg.cpp:358-365);
 // every other entry of the n x n graph is the background -penalty.  One wave per row, two passes (count, fill).
 template <int FT, int FILL>
 __device__ inline void dev_km_csr(const LoopProb& P, const int bx) {
