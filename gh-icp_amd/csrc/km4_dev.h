@@ -49,7 +49,6 @@ constexpr int K4_CAP = 3;
 constexpr int K4_OVER = 255;  // tln: 0..3 = listed entries; above = flagged (more than 3 tight entries when the list was built):
                               // 4..6 = so many, and their COLUMNS are kept as hints (rule R5); 255 = more than 6
 constexpr int K4_HINT = 2 * K4_CAP;
-constexpr bool K4_POOL = true;  // flagged rows without hints: gather their tight columns once per augmenting phase (else: members of S)
 constexpr int K4_T = 256;
 constexpr int K4_NONE = 0xFFFF;
 constexpr double K4_INF = 1000.0;  // km.cpp:42
@@ -698,9 +697,9 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         continue;
       }
       // ---- R5: augmenting phase.  S by pull rounds ...
-      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = K4_POOL ? 0u : s.ovf[w]; s.goody[w] = s.freey[w]; }
+      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = 0u; s.goody[w] = s.freey[w]; }
       if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; s.sh[SH_NF] = 0; }
-      if (K4_POOL && wave == 0) {  // the flagged rows without hints, ascending, into sty
+      if (wave == 0) {  // the flagged rows without hints, ascending, into sty (without the pool they would all be members of S: measured, v4)
         int cnt = 0;
         for (int base = 0; base < n; base += 64) {
           const int x = base + lane;
