@@ -44,7 +44,8 @@ struct LoopConst {
 struct LoopProb {
   LoopConst C;
   LoopState* st;
-  double* kpS;
+  double* kpS;            // the pair's own copy (the loop transforms it in place)
+  const double* kpS_src;  // where it is copied from when the batch starts
   const double* kpT;
   const void* FD;   // [ks][kt]
   const void* FDt;  // [kt][ks]
@@ -520,7 +521,20 @@ __global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ pro
   dev_solve<FT>(P, red, ired, sh);
 }
 
-template <typename T> __global__ void k_transpose(const T* __restrict__ in, int rows, int cols, T* __restrict__ out) {
+// Hand-over of a batch in two launches instead of two per pair (5376 pairs a step: the per-pair copies, memsets and transposes were a
+// launch-bound tail of every step, profiles/r03_kernel_stats_bench_default.txt): every pair's source keypoints into its own buffer ...
+__global__ __launch_bounds__(256) void k_pairs_copy_kps(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.y];
+  const int n = P.C.ks * 3;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) P.kpS[i] = P.kpS_src[i];
+}
+// ... and every pair's feature-distance matrix transposed once so that the row sweep reads it coalesced (tiles beyond a pair's extent exit)
+template <typename T> __global__ void k_pairs_transpose(const LoopProb* __restrict__ probs) {
+  const LoopProb& P = probs[blockIdx.z];
+  const int rows = P.C.ks, cols = P.C.kt;
+  if (rows <= 0 || cols <= 0 || (int)blockIdx.x * 32 >= cols || (int)blockIdx.y * 32 >= rows) return;
+  const T* __restrict__ in = reinterpret_cast<const T*>(P.FD);
+  T* __restrict__ out = const_cast<T*>(reinterpret_cast<const T*>(P.FDt));
   __shared__ T tile[32][33];
   const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
   for (int r = threadIdx.y; r < 32; r += blockDim.y)
@@ -530,6 +544,7 @@ template <typename T> __global__ void k_transpose(const T* __restrict__ in, int 
   for (int r = threadIdx.y; r < 32; r += blockDim.y)
     if (ox < rows && oy0 + r < cols) out[(size_t)(oy0 + r) * rows + ox] = tile[threadIdx.x][r];
 }
+
 
 __global__ void k_collect_done(const LoopProb* __restrict__ probs, int n, int* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -759,7 +774,10 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
     LoopProb* dprobs = cv.take<LoopProb>(nb);
     int* dflags = cv.take<int>((size_t)nb * 2);
     int* dqheads = cv.take<int>(16);  // queue heads of the persistent pair loop, one per class
-    Km2Problem* d_descs = cv.take<Km2Problem>(nb);  // contiguous: one k_km2 launch solves every pair's matching concurrently
+    Km2Problem* d_descs = cv.take<Km2Problem>(nb);  // contiguous: the dense-fallback path launches one solve kernel over all of them
+    LoopState* dstates = cv.take<LoopState>(nb);    // contiguous states and solver status words: ONE upload / memset / download per batch
+    int* dkmst = cv.take<int>((size_t)nb + 1);
+    int max_ks = 1, max_kt = 1;
     for (int b = 0; b < nb; b++) {
       const gh_loop_job& J = jobs[b];
       const ghicp_params* p = J.p;
@@ -778,7 +796,9 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       max_rowsB = std::max(max_rowsB, cdiv(kt > 0 ? kt : 1, ROWS)); max_chunkA = std::max(max_chunkA, C.nchunk_a);
       max_n = std::max(max_n, C.n);
       L.wfd = wfd;
-      L.st = cv.take<LoopState>(1);
+      L.st = dstates + b;
+      L.kpS_src = J.kpS;
+      max_ks = std::max(max_ks, ks); max_kt = std::max(max_kt, kt);
       L.kpS = cv.take<double>((size_t)ks * 3 + 3);
       L.kpT = J.kpT; L.FD = J.FD;
       L.pminA = cv.take<double>((size_t)C.nchunk_b * ks + 1);
@@ -797,7 +817,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       if (FT != GHICP_FEATURE_NONE) L.FDt = cv.take<char>((size_t)ks * kt * (FT == GHICP_FEATURE_BSC ? 2 : 4) + 16);
       if (corr == GHICP_CORR_KM) {
         L.kmmatch = cv.take<int>((size_t)C.n + 1);
-        L.km_status = cv.take<int>(4);
+        L.km_status = dkmst + b;
         if (gh_km4_fits(C.n)) {
           L.km_cnt = cv.take<unsigned>((size_t)C.n + 1);
           L.km_rptr = cv.take<unsigned>((size_t)C.n + 2);
@@ -821,19 +841,17 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         h.RMS = 99999; h.para1 = jobs[b].p->para1; h.para2 = jobs[b].p->para2;  // ghicp_reg.h:98, 33-34
         for (int d = 0; d < 4; d++) h.Rt_till[d * 5] = 1.0;
         if (jobs[b].ks <= 0 || jobs[b].kt <= 0) h.done = 1;
-        GH_HIP(hipMemcpyAsync(hp[b].st, &h, sizeof(h), hipMemcpyHostToDevice, s));
-        if (jobs[b].ks > 0) GH_HIP(hipMemcpyAsync(hp[b].kpS, jobs[b].kpS, (size_t)jobs[b].ks * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-        if (hp[b].km_status) GH_HIP(hipMemsetAsync(hp[b].km_status, 0, sizeof(int), s));
-        // the feature matrix transposed once so that the row sweep reads it coalesced
-        if (FT != GHICP_FEATURE_NONE && jobs[b].ks > 0 && jobs[b].kt > 0) {
-          dim3 g(cdiv(jobs[b].kt, 32), cdiv(jobs[b].ks, 32)), blk(32, 8);
-          if (FT == GHICP_FEATURE_BSC)
-            hipLaunchKernelGGL(k_transpose<uint16_t>, g, blk, 0, s, (const uint16_t*)jobs[b].FD, jobs[b].ks, jobs[b].kt, (uint16_t*)hp[b].FDt);
-          else
-            hipLaunchKernelGGL(k_transpose<float>, g, blk, 0, s, (const float*)jobs[b].FD, jobs[b].ks, jobs[b].kt, (float*)hp[b].FDt);
-        }
       }
+      GH_HIP(hipMemcpyAsync(dstates, hst.data(), (size_t)nb * sizeof(LoopState), hipMemcpyHostToDevice, s));
+      GH_HIP(hipMemsetAsync(dkmst, 0, ((size_t)nb + 1) * sizeof(int), s));
       GH_HIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)nb * sizeof(LoopProb), hipMemcpyHostToDevice, s));
+      // the hand-over of the whole batch: source keypoints into the pairs' own buffers, feature matrices transposed (k_pairs_*)
+      hipLaunchKernelGGL(k_pairs_copy_kps, dim3(std::min(cdiv(max_ks * 3, 256), 8), nb), dim3(256), 0, s, (const LoopProb*)dprobs);
+      if (FT == GHICP_FEATURE_BSC)
+        hipLaunchKernelGGL(k_pairs_transpose<uint16_t>, dim3(cdiv(max_kt, 32), cdiv(max_ks, 32), nb), dim3(32, 8), 0, s, (const LoopProb*)dprobs);
+      else if (FT == GHICP_FEATURE_FPFH)
+        hipLaunchKernelGGL(k_pairs_transpose<float>, dim3(cdiv(max_kt, 32), cdiv(max_ks, 32), nb), dim3(32, 8), 0, s, (const LoopProb*)dprobs);
+      GH_HIP(hipGetLastError());
 
       // ---- iterate
       ctx->loop_total.store(nb, std::memory_order_relaxed);
@@ -901,7 +919,9 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       ctx->loop_active.store(0, std::memory_order_relaxed);
       ctx->progress_live.store(false, std::memory_order_release);
       // ---- results
-      for (int b = 0; b < nb; b++) GH_HIP(hipMemcpyAsync(&hst[b], hp[b].st, sizeof(LoopState), hipMemcpyDeviceToHost, s));
+      std::vector<int> hkmst((size_t)nb + 1, 0);
+      GH_HIP(hipMemcpyAsync(hst.data(), dstates, (size_t)nb * sizeof(LoopState), hipMemcpyDeviceToHost, s));
+      GH_HIP(hipMemcpyAsync(hkmst.data(), dkmst, ((size_t)nb + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
       GH_HIP(hipStreamSynchronize(s));
       for (int b = 0; b < nb; b++) {
         const gh_loop_job& J = jobs[b];
@@ -914,11 +934,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       GH_HIP(hipStreamSynchronize(s));
       int kmst = 0;
       for (int b = 0; b < nb; b++)
-        if (hp[b].km_status) {
-          int v = 0;
-          GH_HIP(hipMemcpy(&v, hp[b].km_status, sizeof(int), hipMemcpyDeviceToHost));
-          kmst |= v;
-        }
+        if (hp[b].km_status) kmst |= hkmst[(size_t)b];
       if (any_dense && ctx->buf[B_KM_MISC].p) {  // the dense fallback reports through the context's own status word
         int v = 0;
         GH_HIP(hipMemcpy(&v, ctx->buf[B_KM_MISC].p, sizeof(int), hipMemcpyDeviceToHost));
