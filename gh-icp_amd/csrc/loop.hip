@@ -529,8 +529,8 @@ __global__ __launch_bounds__(256) void k_pairs_copy_kps(const LoopProb* __restri
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) P.kpS[i] = P.kpS_src[i];
 }
 // ... and every pair's feature-distance matrix transposed once so that the row sweep reads it coalesced (tiles beyond a pair's extent exit)
-template <typename T> __global__ void k_pairs_transpose(const LoopProb* __restrict__ probs) {
-  const LoopProb& P = probs[blockIdx.z];
+template <typename T> __global__ void k_pairs_transpose(const LoopProb* __restrict__ probs, int pair0) {
+  const LoopProb& P = probs[pair0 + blockIdx.z];
   const int rows = P.C.ks, cols = P.C.kt;
   if (rows <= 0 || cols <= 0 || (int)blockIdx.x * 32 >= cols || (int)blockIdx.y * 32 >= rows) return;
   const T* __restrict__ in = reinterpret_cast<const T*>(P.FD);
@@ -847,10 +847,15 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       GH_HIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)nb * sizeof(LoopProb), hipMemcpyHostToDevice, s));
       // the hand-over of the whole batch: source keypoints into the pairs' own buffers, feature matrices transposed (k_pairs_*)
       hipLaunchKernelGGL(k_pairs_copy_kps, dim3(std::min(cdiv(max_ks * 3, 256), 8), nb), dim3(256), 0, s, (const LoopProb*)dprobs);
-      if (FT == GHICP_FEATURE_BSC)
-        hipLaunchKernelGGL(k_pairs_transpose<uint16_t>, dim3(cdiv(max_kt, 32), cdiv(max_ks, 32), nb), dim3(32, 8), 0, s, (const LoopProb*)dprobs);
-      else if (FT == GHICP_FEATURE_FPFH)
-        hipLaunchKernelGGL(k_pairs_transpose<float>, dim3(cdiv(max_kt, 32), cdiv(max_ks, 32), nb), dim3(32, 8), 0, s, (const LoopProb*)dprobs);
+      if (FT != GHICP_FEATURE_NONE) {
+        const int tx = cdiv(max_kt, 32), ty = cdiv(max_ks, 32);
+        const int zmax = (int)std::max<long long>(1, std::min<long long>(65535, (1ll << 22) / ((long long)tx * ty)));  // <= 4 M workgroups (2^30 threads) a launch
+        for (int b0 = 0; b0 < nb; b0 += zmax) {
+          const dim3 g(tx, ty, std::min(zmax, nb - b0));
+          if (FT == GHICP_FEATURE_BSC) hipLaunchKernelGGL(k_pairs_transpose<uint16_t>, g, dim3(32, 8), 0, s, (const LoopProb*)dprobs, b0);
+          else hipLaunchKernelGGL(k_pairs_transpose<float>, g, dim3(32, 8), 0, s, (const LoopProb*)dprobs, b0);
+        }
+      }
       GH_HIP(hipGetLastError());
 
       // ---- iterate
