@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libghicp_hip.so")
+# GHICP_LIB: another in-tree build of the same library (variants of a kernel timed side by side, scripts/km_variant_lib.sh)
+LIB_PATH = os.environ.get("GHICP_LIB") or os.path.join(_HERE, "libghicp_hip.so")
 
 FEATURE_BSC, FEATURE_ROPS, FEATURE_FPFH, FEATURE_NONE = 0, 1, 2, 3
 CORR_NN, CORR_NNR, CORR_KM = 0, 1, 2
@@ -47,9 +48,9 @@ class PairStats(C.Structure):
 EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_set_cu_mask",
     "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
-    "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_pca_curvature", "ghicp_prune",
+    "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_cloud_bounds", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
-    "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_transform_cloud", "ghicp_register_pair",
+    "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_loop_create", "ghicp_iterate", "ghicp_loop_result", "ghicp_loop_destroy", "ghicp_transform_cloud", "ghicp_transform_clouds", "ghicp_register_pair",
     "ghicp_register_pairs",
     "ghicp_icp_params_default", "ghicp_cal_overlap", "ghicp_icp", "ghicp_knn_normals", "ghicp_nn_search", "ghicp_inv_transform",
     "ghicp_transform_cloud_f32",
@@ -74,6 +75,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.ghicp_last_error.restype = C.c_char_p
         _lib.ghicp_version.restype = C.c_char_p
+        _lib.ghicp_loop_destroy.restype = None
     return _lib
 
 
@@ -278,6 +280,38 @@ class Context:
         return dict(Rt=np.array(Rt[:]).reshape(4, 4), iters=it, trace=tr,
                     matchlist=None if ml is None else ml[:it].cpu().numpy())
 
+    def register_stepwise(self, params: Params, kpS, kpT, FD=None, max_steps=None, extra_calls=0):
+        """The same registration through ghicp_loop_create + ghicp_iterate (one iteration of ghicp_reg.cpp:49-103 per call) +
+        ghicp_loop_result.  Same return value as register(..., want_matchlist=True)."""
+        t = self.torch
+        kpS, kpT = self._dev(kpS, t.float64), self._dev(kpT, t.float64)
+        ks, kt = kpS.shape[0], kpT.shape[0]
+        if FD is not None:
+            assert tuple(FD.shape) == (ks, kt) and FD.is_contiguous()
+        loop = C.c_void_p()
+        self._check(self.lib.ghicp_loop_create(self.h, C.byref(params), _ptr(kpS), C.c_int64(ks), _ptr(kpT), C.c_int64(kt), _ptr(FD), C.byref(loop)))
+        try:
+            tr, rows = [], []
+            for _ in range(max_steps or params.max_iter):
+                rec = Iter()
+                row = t.full((max(ks, 1),), -2, dtype=t.int32, device=self.dev)
+                self._check(self.lib.ghicp_iterate(self.h, loop, C.byref(rec), _ptr(row)))
+                d = {k: getattr(rec, k) for k, _ in Iter._fields_ if k != "Rt"}
+                d["Rt"] = np.array(rec.Rt[:]).reshape(4, 4)
+                tr.append(d)
+                rows.append(row[:ks].cpu().numpy())
+                if rec.converged:
+                    break
+            for _ in range(extra_calls):  # (tests: iterating a converged loop is an argument error)
+                self._check(self.lib.ghicp_iterate(self.h, loop, C.byref(Iter()), None))
+            Rt = (C.c_double * 16)()
+            n_iter, conv, ra = C.c_int32(0), C.c_int32(0), C.c_double(0)
+            self._check(self.lib.ghicp_loop_result(loop, Rt, C.byref(n_iter), C.byref(conv), C.byref(ra)))
+        finally:
+            self.lib.ghicp_loop_destroy(loop)
+        return dict(Rt=np.array(Rt[:]).reshape(4, 4), iters=n_iter.value, trace=tr, converged=conv.value, rmse_after=ra.value,
+                    matchlist=np.stack(rows) if rows else np.zeros((0, ks), np.int32))
+
     # ---------------------------------------------------------------- front end
     def _xyz(self, xyz):
         t = self.torch
@@ -299,6 +333,13 @@ class Context:
         out = C.c_float(0)
         self._check(self.lib.ghicp_bbx_magnitude(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], C.byref(out)))
         return out.value
+
+    def cloud_bounds(self, xyz):
+        """CloudUtility::getCloudBound (utility.h:153-183): (min_x, min_y, min_z, max_x, max_y, max_z)"""
+        x = self._xyz(xyz)
+        out = (C.c_double * 6)()
+        self._check(self.lib.ghicp_cloud_bounds(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], out))
+        return np.array(out[:], np.float64)
 
     def pca_curvature(self, xyz, radius):
         t = self.torch
@@ -381,6 +422,20 @@ class Context:
         out = t.empty((x.shape[0], 3), dtype=t.float32, device=self.dev)
         self._check(self.lib.ghicp_transform_cloud(self.h, _ptr(x), C.c_int64(x.shape[0]), x.shape[1], Rt.ctypes.data_as(C.POINTER(C.c_double)), _ptr(out)))
         return out
+
+    def transform_clouds(self, clouds, Rts, outs):
+        """S7 (main:153) of a batch in one launch: device clouds (n_i, stride) under Rts[i] (4x4) into the device tensors outs[i] (n_i, 3) f32."""
+        n = len(clouds)
+        if n == 0:
+            return
+        stride = clouds[0].shape[1]
+        assert all(c.shape[1] == stride and c.is_contiguous() and c.dtype == self.torch.float32 for c in clouds)
+        assert all(o.is_contiguous() and o.dtype == self.torch.float32 and o.shape == (c.shape[0], 3) for c, o in zip(clouds, outs))
+        xs = (C.c_void_p * n)(*[c.data_ptr() for c in clouds])
+        os_ = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        ns = (C.c_int64 * n)(*[c.shape[0] for c in clouds])
+        R = np.ascontiguousarray(np.asarray(Rts, dtype=np.float64).reshape(n, 16))
+        self._check(self.lib.ghicp_transform_clouds(self.h, C.c_int32(n), xs, ns, C.c_int(stride), R.ctypes.data_as(C.POINTER(C.c_double)), os_))
 
     # ---------------------------------------------------------------- fine registration (common_reg)
     def cal_overlap(self, c1, c2, thre_dis):

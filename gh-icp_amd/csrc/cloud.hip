@@ -202,6 +202,7 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
   if (ctx->pairbuf.size() < (size_t)n_pairs * 3) ctx->pairbuf.resize((size_t)n_pairs * 3);
   std::vector<ghicp_params> reg(n_pairs);
   std::vector<gh_loop_job> jobs(n_pairs);
+  std::vector<gh_fd_bsc_job> fdj(n_pairs);
   std::vector<int32_t> iters(n_pairs, 0), conv(n_pairs, 0);
   hipEvent_t e0, e1, e2;
   GH_HIP(hipEventCreate(&e0)); GH_HIP(hipEventCreate(&e1)); GH_HIP(hipEventCreate(&e2));
@@ -218,11 +219,14 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
     reg[i] = cfg->reg;
     reg[i].bbx_magnitude = a->bbx;
     DevBuf& fd = ctx->pairbuf[(size_t)i * 3 + 2];
-    const void* FD = nullptr;
+    const void *FD = nullptr, *FDt = nullptr;
     if (cfg->reg.feature == GHICP_FEATURE_BSC) {
-      GH_HIP(fd.reserve(((size_t)a->k * b->k + 8) * sizeof(uint16_t)));
-      GH_TRY(gh_fd_bsc_dev(ctx, a->feat.as<uint8_t>(), (int)a->k, a->V, b->feat.as<uint8_t>(), (int)b->k, fd.as<uint16_t>()));
+      // matrix and transposed copy side by side; every pair of the call goes through ONE launch of the MFMA Hamming kernel below
+      const size_t cells = ((size_t)a->k * b->k + 15) & ~(size_t)7;
+      GH_HIP(fd.reserve(2 * cells * sizeof(uint16_t)));
       FD = fd.p;
+      FDt = fd.as<uint16_t>() + cells;
+      fdj[i] = {a->feat.as<uint8_t>(), b->feat.as<uint8_t>(), fd.as<uint16_t>(), fd.as<uint16_t>() + cells, (int)a->k, (int)b->k, a->V};
     } else if (cfg->reg.feature == GHICP_FEATURE_FPFH) {
       GH_HIP(fd.reserve(((size_t)a->k * b->k + 8) * sizeof(float)));
       GH_TRY(gh_fd_fpfh_dev(ctx, a->feat.as<float>(), (int)a->k, b->feat.as<float>(), (int)b->k, fd.as<float>()));
@@ -230,9 +234,10 @@ extern "C" int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cf
     }
     gh_loop_job& J = jobs[i];
     memset(&J, 0, sizeof(J));
-    J.p = &reg[i]; J.kpS = a->kpx.as<double>(); J.ks = (int)a->k; J.kpT = b->kpx.as<double>(); J.kt = (int)b->k; J.FD = FD; J.Rt16 = stats[i].Rt;
+    J.p = &reg[i]; J.kpS = a->kpx.as<double>(); J.ks = (int)a->k; J.kpT = b->kpx.as<double>(); J.kt = (int)b->k; J.FD = FD; J.FDt = FDt; J.Rt16 = stats[i].Rt;
     J.n_iter = &iters[i]; J.converged = &conv[i]; J.rmse_after = &stats[i].rmse_after;
   }
+  if (cfg->reg.feature == GHICP_FEATURE_BSC) GH_TRY(gh_fd_bsc_batch_dev(ctx, n_pairs, fdj.data()));
   GH_HIP(hipEventRecord(e1, s));
   GH_TRY(gh_register_batch_dev(ctx, n_pairs, jobs.data()));
   GH_HIP(hipEventRecord(e2, s));

@@ -69,7 +69,7 @@ enum BufSlot {
   B_FE_FLAGS, B_FE_SCAN, B_FE_SCATTER,
   // pair pipeline
   B_P_KEEP_S, B_P_KEEP_T, B_P_DS_S, B_P_DS_T, B_P_KP_S, B_P_KP_T, B_P_KPXYZ_S, B_P_KPXYZ_T, B_P_FEAT_S, B_P_FEAT_T, B_P_LCS,
-  B_P_FD, B_P_MISC, B_P_PATTERN,
+  B_P_FD, B_P_MISC, B_P_PATTERN, B_FD_JOBS, B_TRANSFORM_JOBS,
   B_KM_LX, B_KM_MISC, B_KM_SLACK, B_KM_LSTAT, B_KM_ORDER,
   // batched front end (batch.hip)
   B_FB_DESC, B_FB_HEADPOS, B_FB_DS, B_FB_ORD,
@@ -84,9 +84,10 @@ enum BufSlot {
 enum KtSlot { KT_PCA = 0, KT_BSC, KT_KM_SOLVE, KT_CD_ROWMIN, KT_KM_WEIGHTS, KT_FD_BSC, KT_NMS_ROUND, KT_VOXEL_SORT,
               KT_FB_VOXEL, KT_FB_GRID, KT_FB_PRUNE, KT_FB_RANK, KT_FB_OUT,  // stages of the batched front end (batch.hip) around the kernels above
               KT_PAIR_LOOP,                                                  // the persistent pair loop (loop.hip): all classes of a batch, fork -> join
+              KT_TRANSFORM,                                                  // S7 of a batch (ghicp_transform_clouds)
               KT_NUM };
 static const char* const kKtNames[KT_NUM] = {"pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort",
-                                             "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out", "pair_loop"};
+                                             "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out", "pair_loop", "transform"};
 
 struct ghicp_ctx {
   // optional per-kernel timing
@@ -229,12 +230,20 @@ struct gh_loop_job {
   const double* kpT;
   int kt;
   const void* FD;
+  const void* FDt;     // optional: the transposed feature-distance matrix [kt][ks], when the caller already holds it (gh_fd_bsc_batch_dev)
   double* Rt16;
   ghicp_iter* trace;
   int32_t* n_iter;
   int32_t* converged;
   int32_t* matchlist;
   double* rmse_after;  // host, optional: RMSEafter of the last iteration (ghicp_reg.cpp:905, the value behind "Registration Succeed.")
+  // resumed loops (ghicp_iterate): scalar loop state in / out (host, opaque LoopState of loop.hip), the moved source keypoints out (device),
+  // the last iteration's record (host), and the iteration whose matches go to matchlist row 0
+  const void* resume_in;
+  void* resume_out;
+  double* kpS_out;
+  ghicp_iter* trace_last;
+  int ml_row0;
 };
 int gh_register_batch_dev(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs);
 // the reference's own verdict at convergence (src/ghicp_reg.cpp:918-924): "Registration Succeed." iff RMSEafter < 1.5 * nonmax
@@ -245,6 +254,8 @@ static inline int gh_registered_ok(int converged, double rmse_after, float radiu
 
 // ---- internal (device-pointer) entry points shared between translation units
 int gh_fd_bsc_dev(ghicp_ctx* ctx, const uint8_t* featS, int ks, int V, const uint8_t* featT, int kt, uint16_t* FD);
+struct gh_fd_bsc_job { const uint8_t* featS; const uint8_t* featT; uint16_t* FD; uint16_t* FDt; int ks, kt, V; };  // FDt may be null
+int gh_fd_bsc_batch_dev(ghicp_ctx* ctx, int nb, const gh_fd_bsc_job* jobs);  // one launch for every pair of a batch (fd.hip)
 int gh_register_dev(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int ks, const double* kpT, int kt, const void* FD,
                     double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist);
 int gh_knn_normals_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, int k, float* normals);

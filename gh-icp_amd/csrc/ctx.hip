@@ -201,6 +201,41 @@ __global__ __launch_bounds__(256) void k_transform(const float* __restrict__ xyz
   }
 }
 
+// S7 of a whole batch of pairs in one launch: job (blockIdx.y + job0) = one raw cloud under its pair's final transform.  Packed clouds
+// (stride 3) move as float4s -- four points are three 16-byte loads and three 16-byte stores per lane --, the arithmetic per point is
+// k_transform's, so the result is bit-identical to ghicp_transform_cloud.
+struct TransformJob { const float* xyz; float* out; long long n; M34 M; };
+__device__ __forceinline__ void transform_point(const M34& M, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
+  oy = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
+  oz = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
+}
+__global__ __launch_bounds__(256) void k_transform_batch(const TransformJob* __restrict__ jobs, int job0, int stride) {
+  const TransformJob J = jobs[job0 + blockIdx.y];
+  const long long n = J.n;
+  if (stride == 3 && ((reinterpret_cast<uintptr_t>(J.xyz) | reinterpret_cast<uintptr_t>(J.out)) & 15) == 0) {
+    const long long n4 = n >> 2;
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(J.xyz);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(J.out);
+    for (long long g = blockIdx.x * 256ll + threadIdx.x; g < n4; g += (long long)gridDim.x * 256) {
+      const float4 a = in4[g * 3], b = in4[g * 3 + 1], c = in4[g * 3 + 2];
+      float4 oa, ob, oc;
+      transform_point(J.M, a.x, a.y, a.z, oa.x, oa.y, oa.z);
+      transform_point(J.M, a.w, b.x, b.y, oa.w, ob.x, ob.y);
+      transform_point(J.M, b.z, b.w, c.x, ob.z, ob.w, oc.x);
+      transform_point(J.M, c.y, c.z, c.w, oc.y, oc.z, oc.w);
+      out4[g * 3] = oa; out4[g * 3 + 1] = ob; out4[g * 3 + 2] = oc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+      const long long i = (n4 << 2) + threadIdx.x;
+      transform_point(J.M, J.xyz[i * 3], J.xyz[i * 3 + 1], J.xyz[i * 3 + 2], J.out[i * 3], J.out[i * 3 + 1], J.out[i * 3 + 2]);
+    }
+    return;
+  }
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    transform_point(J.M, J.xyz[i * stride], J.xyz[i * stride + 1], J.xyz[i * stride + 2], J.out[i * 3], J.out[i * 3 + 1], J.out[i * 3 + 2]);
+}
+
 __global__ __launch_bounds__(256) void k_gather4(const float* __restrict__ xyz, int stride, const int* __restrict__ idx, long long m,
                                                  float4* __restrict__ out) {
   const long long i = blockIdx.x * 256ll + threadIdx.x;
@@ -255,6 +290,18 @@ int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float
     int i = h[k] >= 0 ? h[k] : h[k] ^ 0x7fffffff;
     memcpy(&mm_host6[k], &i, 4);
   }
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_cloud_bounds(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, double* out6) {
+  GH_ENTER(ctx);
+  GH_ARG(out6 != nullptr && n > 0 && stride >= 3);
+  Stager sg(ctx);
+  const float* d;
+  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  float mm[6];
+  GH_TRY(gh_bbox_dev(ctx, d, n, stride, mm));
+  for (int k = 0; k < 6; k++) out6[k] = (double)mm[k];
   return GHICP_OK;
 }
 
@@ -341,6 +388,35 @@ extern "C" int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n
     GH_HIP(hipGetLastError());
   }
   return sg.finish();
+}
+
+extern "C" int ghicp_transform_clouds(ghicp_ctx* ctx, int32_t n_clouds, const float* const* xyz, const int64_t* n, int stride, const double* Rt16,
+                                      float* const* out) {
+  GH_ENTER(ctx);
+  GH_ARG(n_clouds >= 0 && stride >= 3 && (n_clouds == 0 || (xyz && n && Rt16 && out)));
+  if (ctx->host_ptrs) return ctx->fail(GHICP_ERR_ARG, "ghicp_transform_clouds: device-pointer mode only (use ghicp_transform_cloud per cloud)");
+  if (n_clouds == 0) return GHICP_OK;
+  std::vector<TransformJob> h((size_t)n_clouds);
+  int64_t nmax = 0;
+  for (int i = 0; i < n_clouds; i++) {
+    GH_ARG(n[i] >= 0 && (n[i] == 0 || (xyz[i] && out[i])));
+    h[i].xyz = xyz[i]; h[i].out = out[i]; h[i].n = n[i];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) h[i].M.m[r * 4 + c] = (float)Rt16[(size_t)i * 16 + r * 4 + c];  // Rt_final.cast<float>() (main:153)
+    nmax = std::max<int64_t>(nmax, n[i]);
+  }
+  TransformJob* d;
+  GH_TRY(ctx->reserve(B_TRANSFORM_JOBS, h.size(), &d));
+  GH_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(TransformJob), hipMemcpyHostToDevice, ctx->stream));
+  if (nmax > 0) {
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nmax, 256 * 8), 2048));
+    hipEvent_t kev = ctx->kt_begin(KT_TRANSFORM);
+    for (int j0 = 0; j0 < n_clouds; j0 += 65535)
+      hipLaunchKernelGGL(k_transform_batch, dim3(bx, std::min(65535, n_clouds - j0)), dim3(256), 0, ctx->stream, (const TransformJob*)d, j0, stride);
+    ctx->kt_end(KT_TRANSFORM, kev);
+    GH_HIP(hipGetLastError());
+  }
+  return GHICP_OK;
 }
 
 extern "C" int ghicp_gather_points(ghicp_ctx* ctx, const float* xyz, int stride, const int32_t* idx, int64_t m, float* out) {

@@ -49,11 +49,13 @@ struct LoopProb {
   const double* kpT;
   const void* FD;   // [ks][kt]
   const void* FDt;  // [kt][ks]
+  int fdt_given;    // the job came with its transposed matrix (k_pairs_transpose skips it)
   const double* wfd;
   double *pminA, *pminB, *psum;
   int *pidxA, *pidxB, *SP, *TP, *SVs, *TVs;
   ghicp_iter* trace;
   int* matchlist;
+  int ml_row0;  // matchlist row of iteration `it` is it - ml_row0 (a resumed loop hands over one row per call)
   // KM
   unsigned *km_cnt, *km_rptr;
   int *km_cols, *kmmatch, *km_status;
@@ -312,7 +314,7 @@ __device__ inline void dev_solve(const LoopProb& P, double* red, int* ired, doub
   const double penalty = st->penalty;
   int* matchlist = P.matchlist;
   if (matchlist)
-    for (int i = tid; i < C.ks; i += nt) matchlist[(size_t)it * C.ks + i] = -1;
+    for (int i = tid; i < C.ks; i += nt) matchlist[(size_t)(it - P.ml_row0) * C.ks + i] = -1;
 
   // ---- correspondences, in the reference's emission order
   int cor = 0;
@@ -383,7 +385,7 @@ __device__ inline void dev_solve(const LoopProb& P, double* red, int* ired, doub
   }
   __syncthreads();
   if (matchlist)
-    for (int c = tid; c < cor; c += nt) matchlist[(size_t)it * C.ks + SP[c]] = TP[c];
+    for (int c = tid; c < cor; c += nt) matchlist[(size_t)(it - P.ml_row0) * C.ks + SP[c]] = TP[c];
 
   // ---- RMSE, FDM, FDstd (ghicp_reg.cpp:548-578)
   double rm = 0, fm = 0;
@@ -523,8 +525,8 @@ __global__ __launch_bounds__(1024) void k_solve(const LoopProb* __restrict__ pro
 
 // Hand-over of a batch in two launches instead of two per pair (5376 pairs a step: the per-pair copies, memsets and transposes were a
 // launch-bound tail of every step, profiles/r03_kernel_stats_bench_default.txt): every pair's source keypoints into its own buffer ...
-__global__ __launch_bounds__(256) void k_pairs_copy_kps(const LoopProb* __restrict__ probs) {
-  const LoopProb& P = probs[blockIdx.y];
+__global__ __launch_bounds__(256) void k_pairs_copy_kps(const LoopProb* __restrict__ probs, int pair0) {
+  const LoopProb& P = probs[pair0 + blockIdx.y];
   const int n = P.C.ks * 3;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) P.kpS[i] = P.kpS_src[i];
 }
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256) void k_pairs_copy_kps(const LoopProb* __restri
 template <typename T> __global__ void k_pairs_transpose(const LoopProb* __restrict__ probs, int pair0) {
   const LoopProb& P = probs[pair0 + blockIdx.z];
   const int rows = P.C.ks, cols = P.C.kt;
-  if (rows <= 0 || cols <= 0 || (int)blockIdx.x * 32 >= cols || (int)blockIdx.y * 32 >= rows) return;
+  if (rows <= 0 || cols <= 0 || (int)blockIdx.x * 32 >= cols || (int)blockIdx.y * 32 >= rows || P.fdt_given) return;
   const T* __restrict__ in = reinterpret_cast<const T*>(P.FD);
   T* __restrict__ out = const_cast<T*>(reinterpret_cast<const T*>(P.FDt));
   __shared__ T tile[32][33];
@@ -778,6 +780,7 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
     LoopState* dstates = cv.take<LoopState>(nb);    // contiguous states and solver status words: ONE upload / memset / download per batch
     int* dkmst = cv.take<int>((size_t)nb + 1);
     int max_ks = 1, max_kt = 1;
+    bool need_transpose = false;
     for (int b = 0; b < nb; b++) {
       const gh_loop_job& J = jobs[b];
       const ghicp_params* p = J.p;
@@ -814,7 +817,12 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       L.TVs = cv.take<int>((size_t)kt + ks + 2);
       L.trace = cv.take<ghicp_iter>((size_t)p->max_iter + 1);
       L.matchlist = J.matchlist;
-      if (FT != GHICP_FEATURE_NONE) L.FDt = cv.take<char>((size_t)ks * kt * (FT == GHICP_FEATURE_BSC ? 2 : 4) + 16);
+      L.ml_row0 = J.ml_row0;
+      if (FT != GHICP_FEATURE_NONE) {
+        if (J.FDt) L.FDt = J.FDt;  // the caller's batched feature-distance kernel wrote the transposed copy already
+        else { L.FDt = cv.take<char>((size_t)ks * kt * (FT == GHICP_FEATURE_BSC ? 2 : 4) + 16); need_transpose = true; }
+        L.fdt_given = J.FDt != nullptr;
+      }
       if (corr == GHICP_CORR_KM) {
         L.kmmatch = cv.take<int>((size_t)C.n + 1);
         L.km_status = dkmst + b;
@@ -840,14 +848,19 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         memset(&h, 0, sizeof(h));
         h.RMS = 99999; h.para1 = jobs[b].p->para1; h.para2 = jobs[b].p->para2;  // ghicp_reg.h:98, 33-34
         for (int d = 0; d < 4; d++) h.Rt_till[d * 5] = 1.0;
+        if (jobs[b].resume_in) {  // ghicp_iterate: the loop continues from the state the previous call left
+          memcpy(&h, jobs[b].resume_in, sizeof(h));
+          h.done = 0;
+        }
         if (jobs[b].ks <= 0 || jobs[b].kt <= 0) h.done = 1;
       }
       GH_HIP(hipMemcpyAsync(dstates, hst.data(), (size_t)nb * sizeof(LoopState), hipMemcpyHostToDevice, s));
       GH_HIP(hipMemsetAsync(dkmst, 0, ((size_t)nb + 1) * sizeof(int), s));
       GH_HIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)nb * sizeof(LoopProb), hipMemcpyHostToDevice, s));
       // the hand-over of the whole batch: source keypoints into the pairs' own buffers, feature matrices transposed (k_pairs_*)
-      hipLaunchKernelGGL(k_pairs_copy_kps, dim3(std::min(cdiv(max_ks * 3, 256), 8), nb), dim3(256), 0, s, (const LoopProb*)dprobs);
-      if (FT != GHICP_FEATURE_NONE) {
+      for (int b0 = 0; b0 < nb; b0 += 65535)  // gridDim.y <= 65535
+        hipLaunchKernelGGL(k_pairs_copy_kps, dim3(std::min(cdiv(max_ks * 3, 256), 8), std::min(65535, nb - b0)), dim3(256), 0, s, (const LoopProb*)dprobs, b0);
+      if (FT != GHICP_FEATURE_NONE && need_transpose) {
         const int tx = cdiv(max_kt, 32), ty = cdiv(max_ks, 32);
         const int zmax = (int)std::max<long long>(1, std::min<long long>(65535, (1ll << 22) / ((long long)tx * ty)));  // <= 4 M workgroups (2^30 threads) a launch
         for (int b0 = 0; b0 < nb; b0 += zmax) {
@@ -935,6 +948,9 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         if (J.converged) *J.converged = hst[b].converged_flag;
         if (J.rmse_after) *J.rmse_after = hst[b].rmse_after;
         if (J.trace && hst[b].it > 0) GH_HIP(hipMemcpyAsync(J.trace, hp[b].trace, (size_t)hst[b].it * sizeof(ghicp_iter), hipMemcpyDeviceToHost, s));
+        if (J.trace_last && hst[b].it > 0) GH_HIP(hipMemcpyAsync(J.trace_last, hp[b].trace + (hst[b].it - 1), sizeof(ghicp_iter), hipMemcpyDeviceToHost, s));
+        if (J.kpS_out && J.ks > 0) GH_HIP(hipMemcpyAsync(J.kpS_out, hp[b].kpS, (size_t)J.ks * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (J.resume_out) memcpy(J.resume_out, &hst[b], sizeof(LoopState));
       }
       GH_HIP(hipStreamSynchronize(s));
       int kmst = 0;
@@ -996,4 +1012,87 @@ extern "C" int ghicp_register(ghicp_ctx* ctx, const ghicp_params* p, const doubl
   GH_TRY(sg.out(matchlist, (size_t)p->max_iter * ks, &dml));
   GH_TRY(gh_register_dev(ctx, p, dS, (int)ks, dT, (int)kt, dFD, Rt16, trace, n_iter, dml));
   return sg.finish();
+}
+
+// ---- One step at a time (ghicp_iterate = one pass of calED ... adjustweight, src/ghicp_reg.cpp:49-103).  The state object owns
+// the moving source keypoints and the scalar loop state (Rt_tillnow, RMS, FDM, FDstd, IoU, para1/2, iteration number) between calls; an
+// iteration runs through the SAME batch path as ghicp_register (a batch of one pair, max_iter = it + 1), so a sequence of ghicp_iterate calls
+// reproduces ghicp_register's trace bit for bit (tests/test_gpu_loop.py::test_iterate_equals_register).
+struct ghicp_loop {
+  ghicp_ctx* ctx;
+  ghicp_params p;
+  int ks, kt;
+  DevBuf kpS, kpT, FD;  // own device copies: the caller's arrays may go away between two calls
+  LoopState st;
+  bool started, finished;
+};
+
+extern "C" int ghicp_loop_create(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int64_t ks, const double* kpT, int64_t kt, const void* FD,
+                                 ghicp_loop** out) {
+  GH_ENTER(ctx);
+  GH_ARG(p != nullptr && out != nullptr && ks >= 0 && kt >= 0 && ks < (1 << 24) && kt < (1 << 24));
+  GH_ARG(p->corr == GHICP_CORR_NN || p->corr == GHICP_CORR_NNR || p->corr == GHICP_CORR_KM);
+  const bool has_fd = p->feature == GHICP_FEATURE_BSC || p->feature == GHICP_FEATURE_FPFH;
+  if (has_fd) GH_ARG(FD != nullptr || ks == 0 || kt == 0);
+  *out = nullptr;
+  ghicp_loop* L = new ghicp_loop();
+  L->ctx = ctx; L->p = *p; L->ks = (int)ks; L->kt = (int)kt; L->started = false; L->finished = false;
+  memset(&L->st, 0, sizeof(L->st));
+  const hipMemcpyKind kind = ctx->host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const size_t esz = p->feature == GHICP_FEATURE_BSC ? 2 : 4;
+  hipError_t e = L->kpS.reserve((size_t)ks * 24 + 32);
+  if (e == hipSuccess) e = L->kpT.reserve((size_t)kt * 24 + 32);
+  if (e == hipSuccess && has_fd) e = L->FD.reserve((size_t)ks * kt * esz + 32);
+  if (e == hipSuccess && ks > 0) e = hipMemcpyAsync(L->kpS.p, kpS, (size_t)ks * 24, kind, ctx->stream);
+  if (e == hipSuccess && kt > 0) e = hipMemcpyAsync(L->kpT.p, kpT, (size_t)kt * 24, kind, ctx->stream);
+  if (e == hipSuccess && has_fd && ks > 0 && kt > 0) e = hipMemcpyAsync(L->FD.p, FD, (size_t)ks * kt * esz, kind, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    L->kpS.release(); L->kpT.release(); L->FD.release();
+    delete L;
+    return ctx->fail(GHICP_ERR_HIP, "ghicp_loop_create: %s", hipGetErrorString(e));
+  }
+  *out = L;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_iterate(ghicp_ctx* ctx, ghicp_loop* L, ghicp_iter* out, int32_t* match_row) {
+  GH_ENTER(ctx);
+  GH_ARG(L != nullptr && L->ctx == ctx && out != nullptr);
+  if (L->finished) return ctx->fail(GHICP_ERR_ARG, "ghicp_iterate: the loop has converged (or has no keypoints); create a new one");
+  ghicp_params p = L->p;
+  p.max_iter = (L->started ? L->st.it : 0) + 1;  // exactly one more iteration
+  Stager sg(ctx);
+  int32_t* dml;
+  GH_TRY(sg.out(match_row, (size_t)L->ks, &dml));
+  double Rt16[16];
+  int32_t n_iter = 0, conv = 0;
+  gh_loop_job J;
+  memset(&J, 0, sizeof(J));
+  J.p = &p; J.kpS = L->kpS.as<double>(); J.ks = L->ks; J.kpT = L->kpT.as<double>(); J.kt = L->kt; J.FD = L->FD.p; J.Rt16 = Rt16;
+  J.n_iter = &n_iter; J.converged = &conv; J.matchlist = dml; J.ml_row0 = p.max_iter - 1;
+  J.resume_in = L->started ? &L->st : nullptr; J.resume_out = &L->st; J.kpS_out = L->kpS.as<double>(); J.trace_last = out;
+  memset(out, 0, sizeof(*out));
+  GH_TRY(gh_register_batch_dev(ctx, 1, &J));
+  GH_HIP(hipStreamSynchronize(ctx->stream));
+  L->started = true;
+  if (L->ks <= 0 || L->kt <= 0 || conv) L->finished = true;
+  if (L->ks <= 0 || L->kt <= 0) out->converged = 1;
+  return sg.finish();
+}
+
+extern "C" int ghicp_loop_result(const ghicp_loop* L, double* Rt16, int32_t* n_iter, int32_t* converged, double* rmse_after) {
+  if (!L || !Rt16) return GHICP_ERR_ARG;
+  for (int d = 0; d < 16; d++) Rt16[d] = L->started ? L->st.Rt_till[d] : (d % 5 == 0 ? 1.0 : 0.0);
+  if (n_iter) *n_iter = L->started ? L->st.it : 0;
+  if (converged) *converged = L->started ? L->st.converged_flag : 0;
+  if (rmse_after) *rmse_after = L->started ? L->st.rmse_after : 0.0;
+  return GHICP_OK;
+}
+
+extern "C" void ghicp_loop_destroy(ghicp_loop* L) {
+  if (!L) return;
+  (void)hipSetDevice(L->ctx->device);
+  L->kpS.release(); L->kpT.release(); L->FD.release();
+  delete L;
 }

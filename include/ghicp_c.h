@@ -109,6 +109,9 @@ int ghicp_voxel_filter(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, 
 int ghicp_gather_points(ghicp_ctx* ctx, const float* xyz, int stride, const int32_t* idx, int64_t m, float* out_xyz4);
 /* bbx_magnitude of test/ghicp_main.cpp:91-93 (CloudUtility::getCloudBound, utility.h:153-183). [host] out */
 int ghicp_bbx_magnitude(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float* bbx);
+/* CloudUtility::getCloudBound (include/utility.h:153-183): min_x, min_y, min_z, max_x, max_y, max_z as doubles holding the float
+ * extremes. [host] out6; n == 0 is an argument error (the reference reads cloud[0]). */
+int ghicp_cloud_bounds(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, double* out6);
 
 /* PrincipleComponentAnalysis::CalculatePcaFeaturesOfPointCloud(cloud, features, float radius)
  * (include/pca.h:133-165, 202-250).  lambda: m x 3 f32 (descending), curvature: m f64, count: m i32. */
@@ -171,8 +174,27 @@ int ghicp_rigid_svd_host(const double* src, const double* tgt, int64_t c, double
 int ghicp_register(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int64_t ks, const double* kpT, int64_t kt, const void* FD,
                    double* Rt16, ghicp_iter* trace, int32_t* n_iter, int32_t* matchlist);
 
+/* One iteration at a time: the body of the while loop of GHRegistration::ghicp_reg (src/ghicp_reg.cpp:49-103) -- calED, calCD_*, the
+ * correspondence search, transformestimation (which moves the source keypoints and accumulates Rt_tillnow), adjustweight -- as one call.
+ * ghicp_loop_create copies the inputs (same meaning as ghicp_register's) into a state object; every ghicp_iterate runs exactly one
+ * iteration on it and returns that iteration's record (`out`, [host]; out->converged is the loop's exit test, ghicp_reg.cpp:796-803,
+ * 909-914) and, when match_row is not NULL, its correspondences (ks int32: T index or -1).  A sequence of ghicp_iterate calls until
+ * out->converged reproduces ghicp_register's trace bit for bit; calling it again after convergence is an argument error.
+ * ghicp_loop_result: the accumulated 4x4 (Rt_tillnow), iterations done, the converged flag, RMSE-after of the last iteration. */
+typedef struct ghicp_loop ghicp_loop;
+int ghicp_loop_create(ghicp_ctx* ctx, const ghicp_params* p, const double* kpS, int64_t ks, const double* kpT, int64_t kt, const void* FD,
+                      ghicp_loop** out);
+int ghicp_iterate(ghicp_ctx* ctx, ghicp_loop* loop, ghicp_iter* out, int32_t* match_row);
+int ghicp_loop_result(const ghicp_loop* loop, double* Rt16, int32_t* n_iter, int32_t* converged, double* rmse_after);
+void ghicp_loop_destroy(ghicp_loop* loop);
+
 /* pcl::transformPointCloud(cloud, out, Rt.cast<float>()) (test/ghicp_main.cpp:153). out: n x 3 packed f32. */
 int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, const double* Rt16_host, float* out_xyz);
+/* The same for the raw sources of a whole batch of registered pairs in one launch: cloud i (xyz[i], n[i] rows of `stride` floats) under
+ * Rt16_host[16 i .. 16 i + 15] into out[i] (n[i] x 3 packed f32).  [host] pointer tables and matrices, device clouds; bit-identical to
+ * ghicp_transform_cloud cloud by cloud.  Device-pointer mode only. */
+int ghicp_transform_clouds(ghicp_ctx* ctx, int32_t n_clouds, const float* const* xyz, const int64_t* n, int stride, const double* Rt16_host,
+                           float* const* out_xyz);
 
 /* ------------------------------------------------------------------ whole pair (test/ghicp_main.cpp:86-153) */
 typedef struct ghicp_pair_config {

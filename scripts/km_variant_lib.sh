@@ -10,11 +10,11 @@ make -C "$root/gh-icp_amd/csrc" -j8 >/dev/null
 d=$(mktemp -d)
 git -C "$root" archive "$ref" gh-icp_amd/csrc include | tar -x -C "$d"
 mkdir -p "$d/gh-icp_amd/csrc/build"
-for f in km4 km_dense_door loop; do
+for f in km km4 km_dense_door loop; do
   ( cd "$d/gh-icp_amd/csrc" && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -c $f.hip -o build/$f.o ) &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/gh-icp_amd/libghicp_var_$name.so" \
-  $(ls "$root"/gh-icp_amd/csrc/build/*.o | grep -v "/km4.o\|/km_dense_door.o\|/loop.o") "$d"/gh-icp_amd/csrc/build/{km4,km_dense_door,loop}.o
+  $(ls "$root"/gh-icp_amd/csrc/build/*.o | grep -v "/km.o\|/km4.o\|/km_dense_door.o\|/loop.o") "$d"/gh-icp_amd/csrc/build/{km,km4,km_dense_door,loop}.o
 rm -rf "$d"
 echo "built gh-icp_amd/libghicp_var_$name.so from $ref"

@@ -1,11 +1,14 @@
 // Exercises the reference-named C++ classes (include/*.h) end to end on the GPU: the code below is what
-// test/ghicp_main.cpp:95-151 does, minus file I/O.  Prints the final 4x4 and a few counters for the pytest wrapper.
+// test/ghicp_main.cpp:86-153 does, minus file I/O -- voxel filter and bounds (CFilter), keypoints, BSC or FPFH features, GHRegistration,
+// the final transform of the raw source.  Prints the final 4x4 and a few counters for the pytest wrapper.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 
 #include "binary_feature_extraction.hpp"
 #include "common_reg.h"
+#include "filter.hpp"
+#include "fpfh.hpp"
 #include "ghicp_reg.h"
 #include "keypoint_detect.hpp"
 #include "km.h"
@@ -42,10 +45,17 @@ int main(int argc, char** argv) {
     km.output(SP, TP, SPo, TPo);
     printf("KMKAT %d %d %d energy %g\n", SP[0], SP[1], SP[2], km.Calenergy());
   }
-  pcl::PointCloud<Point_T>::Ptr T = load(argv[1]), S = load(argv[2]);
-  const char corr = argv[3][0];
-  float bbx = 0;
-  if (ghicp_bbx_magnitude(detail::ctx(), detail::xyz(*S), (int64_t)S->size(), detail::stride<Point_T>(), &bbx) != GHICP_OK) return 3;
+  pcl::PointCloud<Point_T>::Ptr Traw = load(argv[1]), Sraw = load(argv[2]);
+  const char corr = argv[3][0];  // N: BSC + NN, K: BSC + KM, R: FPFH + NNR (main:118-127)
+  // Downsampling + bbx_magnitude (main:86-93)
+  CFilter<Point_T> cfilter;
+  pcl::PointCloud<Point_T>::Ptr T(new pcl::PointCloud<Point_T>()), S(new pcl::PointCloud<Point_T>());
+  cfilter.voxelfilter(Traw, T, 0.1f);
+  cfilter.voxelfilter(Sraw, S, 0.1f);
+  Bounds s_cloud_bbx;
+  cfilter.getCloudBound(*S, s_cloud_bbx);
+  float bbx = s_cloud_bbx.max_x - s_cloud_bbx.min_x + s_cloud_bbx.max_y - s_cloud_bbx.min_y + s_cloud_bbx.max_z - s_cloud_bbx.min_z;
+  printf("DS %zu %zu BBX %.9g FIRST %.9g %.9g %.9g\n", T->points.size(), S->points.size(), bbx, S->points[1].x, S->points[1].y, S->points[1].z);
   CKeypointDetect<Point_T> ckpd(0.5f, 0.65f, 20, 1.5f);
   pcl::PointIndicesPtr kT, kS;
   ckpd.keypointDetectionBasedOnCurvature(T, kT);
@@ -56,14 +66,25 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < kT->indices.size(); i++) { const Point_T& p = T->points[kT->indices[i]]; kpT(i, 0) = p.x; kpT(i, 1) = p.y; kpT(i, 2) = p.z; }
   Keypoints Kp;
   Kp.setCoordinate(kpS, kpT);
-  BSCEncoder<Point_T> bsc(1.5f, 7, true);  // glibc rand() sample pattern (Q2)
-  doubleVectorSBF bscT, bscS;
-  bsc.extractBinaryFeatures(T, kT, 0, bscT);
-  bsc.extractBinaryFeatures(S, kS, 6, bscS);
-  Kp.setBSCfeature(bscS, bscT);
+  if (corr == 'R') {  // FPFH feature (main:118-127)
+    FPFHfeature<Point_T> fpfh(1.5f);
+    fpfhFeaturePtr fpfhT(new fpfhFeature), fpfhS(new fpfhFeature), fpfhT_k(new fpfhFeature), fpfhS_k(new fpfhFeature);
+    fpfh.compute_fpfh_feature(T, fpfhT);
+    fpfh.compute_fpfh_feature(S, fpfhS);
+    fpfh.keyfpfh(fpfhS, fpfhT, kS, kT, fpfhS_k, fpfhT_k);
+    Kp.setFPFHfeature(fpfhS_k, fpfhT_k);
+    if (!fpfhS_k->points.empty() && !fpfhT_k->points.empty())
+      printf("FPFHD %.9g\n", fpfh.compute_fpfh_distance(fpfhS_k->points[0].histogram, fpfhT_k->points[0].histogram));
+  } else {
+    BSCEncoder<Point_T> bsc(1.5f, 7, true);  // glibc rand() sample pattern (Q2)
+    doubleVectorSBF bscT, bscS;
+    bsc.extractBinaryFeatures(T, kT, 0, bscT);
+    bsc.extractBinaryFeatures(S, kS, 6, bscS);
+    Kp.setBSCfeature(bscS, bscT);
+  }
   Energyfunction Ef;
   Ef.init((int)kS->indices.size(), (int)kT->indices.size(), bbx);
-  GHRegistration reg(Kp, Ef, BSC, corr == 'K' ? KM : NN, 1.5f, 1.1f, 0.1f, 6, 0.6f);
+  GHRegistration reg(Kp, Ef, corr == 'R' ? FPFH : BSC, corr == 'K' ? KM : (corr == 'R' ? NNR : NN), 1.5f, 1.1f, 0.1f, 6, 0.6f);
   reg.set_max_iterations(80);
   Eigen::Matrix4d Rt;
   reg.ghicp_reg(Rt);
@@ -71,6 +92,13 @@ int main(int argc, char** argv) {
   printf("RT");
   for (int i = 0; i < 16; i++) printf(" %.17g", Rt(i / 4, i % 4));
   printf("\n");
+  {  // pcl::transformPointCloud(*pointCloudS, *pointCloudS_reg, Rt_final.cast<float>()) (main:153) on the RAW source
+    std::vector<float> reg3(Sraw->points.size() * 3);
+    double Rt16[16];
+    for (int i = 0; i < 16; i++) Rt16[i] = Rt(i / 4, i % 4);
+    if (ghicp_transform_cloud(detail::ctx(), detail::xyz(*Sraw), (int64_t)Sraw->points.size(), detail::stride<Point_T>(), Rt16, reg3.data()) != GHICP_OK) return 4;
+    printf("REG %.9g %.9g %.9g\n", reg3[3 * 11], reg3[3 * 11 + 1], reg3[3 * 11 + 2]);
+  }
   // fine registration after GH-ICP (CRegistration, common_reg.h): coarse-aligned source -> trimmed point-to-point ICP
   {
     CRegistration<Point_T> creg;

@@ -177,6 +177,26 @@ static void resolve(Lane* L, int l0, int l1, int n_live) {
         break;
       }
       case OP_FIRST: L[i].result = L[first].payload; break;
+      case OP_MFMA_I32_32X32X32_I8: {  // the lowest lane computes the whole block into every lane's operand record
+        if (i != first) break;
+        if (n != 64 || l1 - l0 != 64) { fprintf(stderr, "hipsim: MFMA executed by %d lanes of a wave (needs all 64)\n", n); abort(); }
+        int d[64][16];
+        for (int l = 0; l < 64; l++) {
+          const MfmaI8* ml = reinterpret_cast<const MfmaI8*>((uintptr_t)L[l0 + l].payload);
+          for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+            int acc = ml->c[r];
+            for (int h = 0; h < 2; h++) {
+              const MfmaI8* ma = reinterpret_cast<const MfmaI8*>((uintptr_t)L[l0 + row + 32 * h].payload);
+              const MfmaI8* mb = reinterpret_cast<const MfmaI8*>((uintptr_t)L[l0 + col + 32 * h].payload);
+              for (int k = 0; k < 16; k++) acc += (int)ma->a[k] * (int)mb->b[k];
+            }
+            d[l][r] = acc;
+          }
+        }
+        for (int l = 0; l < 64; l++) memcpy(reinterpret_cast<MfmaI8*>((uintptr_t)L[l0 + l].payload)->c, d[l], sizeof(d[l]));
+        break;
+      }
       default: L[i].result = 0;
     }
   }

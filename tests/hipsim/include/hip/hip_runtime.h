@@ -51,7 +51,8 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 
 // ------------------------------------------------------------------------------------------------ lane / block state
 namespace hipsim {
-enum WaveOp { OP_BALLOT = 1, OP_SHFL = 2, OP_BARRIER = 3, OP_FIRST = 4 };
+enum WaveOp { OP_BALLOT = 1, OP_SHFL = 2, OP_BARRIER = 3, OP_FIRST = 4, OP_MFMA_I32_32X32X32_I8 = 5 };
+struct MfmaI8 { signed char a[16], b[16]; int c[16]; };  // one lane's operands of v_mfma_i32_32x32x32_i8 (payload of the collective = its address)
 struct Lane {
   void* sp;
   uint3 tid;
@@ -136,6 +137,17 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
   if (row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipsim: dpp row/bank masks are not modelled\n"); abort(); }
   const int got = hipsim::shfl_from(src, from < 0 ? lane : from, line);
   return from < 0 ? (bound_ctrl ? 0 : old) : got;
+}
+// v_mfma_i32_32x32x32_i8: D = A B + C over a 32 x 32 x 32 block held by the 64 lanes of a wave.  Lane l supplies 16 int8 of A's row (l & 31) and
+// of B's column (l & 31) at K-offset (l >> 5) * 16; C/D register r of lane l is element (row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31).
+typedef int hipsim_v4i __attribute__((vector_size(16)));
+typedef int hipsim_v16i __attribute__((vector_size(64)));
+static inline hipsim_v16i __builtin_amdgcn_mfma_i32_32x32x32_i8(hipsim_v4i a, hipsim_v4i b, hipsim_v16i c, int, int, int, int line = __builtin_LINE()) {
+  hipsim::MfmaI8 m;
+  __builtin_memcpy(m.a, &a, 16); __builtin_memcpy(m.b, &b, 16); __builtin_memcpy(m.c, &c, 64);
+  hipsim::wave_collective(hipsim::OP_MFMA_I32_32X32X32_I8, line, (uint64_t)(uintptr_t)&m, 0);
+  __builtin_memcpy(&c, m.c, 64);
+  return c;
 }
 static inline int __builtin_amdgcn_readfirstlane(int v, int line = __builtin_LINE()) {
   return (int)(uint32_t)hipsim::wave_collective(hipsim::OP_FIRST, line, (uint32_t)v, 0);

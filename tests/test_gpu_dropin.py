@@ -18,7 +18,7 @@ def _dump(path, pts):
         f.write(np.ascontiguousarray(pts, np.float32).tobytes())
 
 
-@pytest.mark.parametrize("corr,types", [("N", "shim"), ("K", "shim"), ("K", "pcl-eigen-interface")])
+@pytest.mark.parametrize("corr,types", [("N", "shim"), ("K", "shim"), ("K", "pcl-eigen-interface"), ("R", "shim"), ("R", "pcl-eigen-interface")])
 def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr, types):
     """`types`: the repo's stand-in PCL / Eigen types, or -DGHICP_WITH_PCL against interface-only fakes of the real libraries
     (column-major Eigen, 16-byte PointXYZI): the same caller code, the same results."""
@@ -30,29 +30,42 @@ def test_cpp_dropin_pipeline(ctx, oracle, synth, tmp_path, corr, types):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include")] + extra + [os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
                            "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", str(exe)])
     p = synth.tls_pair(100_000, pair_id=5)
+    _dump(tmp_path / "T.bin", p.target)   # RAW clouds: the voxel filter is CFilter::voxelfilter's (include/filter.hpp)
+    _dump(tmp_path / "S.bin", p.source)
     dsT = p.target[oracle.voxel_filter(p.target, 0.1)]
     dsS = p.source[oracle.voxel_filter(p.source, 0.1)]
-    _dump(tmp_path / "T.bin", dsT)
-    _dump(tmp_path / "S.bin", dsS)
-    out = subprocess.run([str(exe), str(tmp_path / "T.bin"), str(tmp_path / "S.bin"), corr], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([str(exe), str(tmp_path / "T.bin"), str(tmp_path / "S.bin"), corr], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l.split()[0] in ("KMKAT", "KP", "RT", "OVERLAP", "ICP", "INV", "S1")}
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l.split()[0] in ("KMKAT", "DS", "KP", "RT", "REG", "FPFHD", "OVERLAP", "ICP", "INV", "S1")}
     assert lines["KMKAT"][:3] == ["0", "2", "1"] and float(lines["KMKAT"][4]) == 12.0  # km.cpp:237-259
-    # BSCEncoder(..., true) draws the pattern from rand() and writes it like the reference (bfe:75-101); the sequence
-    # depends on how often the process called rand() before (the HIP runtime does), so the oracle is fed the written file.
-    pat = np.loadtxt(tmp_path / "sample_pattern.txt", dtype=np.int32)
-    assert pat.shape == (49, 2) and pat.min() >= 0 and pat.max() <= 48 and (pat[:, 0] != pat[:, 1]).all()
-    assert len({tuple(sorted(r)) for r in pat.tolist()}) == 49  # contain2DPair: no repeated pair (bfe:856-871)
+    # CFilter::voxelfilter + CloudUtility::getCloudBound (main:86-93): sizes, the first real voxel's point, bbx_magnitude
+    assert [int(v) for v in lines["DS"][:2]] == [len(dsT), len(dsS)]
+    assert np.float32(lines["DS"][3]) == np.float32(oracle.bbx_magnitude(dsS))
+    np.testing.assert_array_equal(np.array([float(v) for v in lines["DS"][5:8]], np.float32), dsS[1])
     kpT, _ = oracle.keypoints(dsT, 0.5, 1.5)
     kpS, _ = oracle.keypoints(dsS, 0.5, 1.5)
-    fT, _, _ = oracle.bsc(dsT, kpT, 1.5, 0, pat)
-    fS, _, _ = oracle.bsc(dsS, kpS, 1.5, 6, pat)
     assert [int(v) for v in lines["KP"][:2]] == [kpS.size, kpT.size]
-    P = oracle.default_params(oracle.BSC, oracle.KM if corr == "K" else oracle.NN, 6, 0.6, 1.5, oracle.bbx_magnitude(dsS), max_iter=80)
-    ro = oracle.register(P, dsS[kpS].astype(np.float64), dsT[kpT].astype(np.float64), oracle.fd_bsc(fS, fT[0]))
+    if corr == "R":  # FPFHfeature (include/fpfh.hpp) + NNR, main:118-127
+        hT, hS = oracle.fpfh(dsT)[1], oracle.fpfh(dsS)[1]
+        FD = oracle.fd_fpfh(hS[kpS], hT[kpT])
+        assert np.float32(lines["FPFHD"][0]) == FD[0, 0] or (np.isnan(FD[0, 0]) and np.isnan(np.float32(lines["FPFHD"][0])))
+        P = oracle.default_params(oracle.FPFH, oracle.NNR, 6, 0.6, 1.5, oracle.bbx_magnitude(dsS), max_iter=80)
+    else:
+        # BSCEncoder(..., true) draws the pattern from rand() and writes it like the reference (bfe:75-101); the sequence
+        # depends on how often the process called rand() before (the HIP runtime does), so the oracle is fed the written file.
+        pat = np.loadtxt(tmp_path / "sample_pattern.txt", dtype=np.int32)
+        assert pat.shape == (49, 2) and pat.min() >= 0 and pat.max() <= 48 and (pat[:, 0] != pat[:, 1]).all()
+        assert len({tuple(sorted(r)) for r in pat.tolist()}) == 49  # contain2DPair: no repeated pair (bfe:856-871)
+        fT, _, _ = oracle.bsc(dsT, kpT, 1.5, 0, pat)
+        fS, _, _ = oracle.bsc(dsS, kpS, 1.5, 6, pat)
+        FD = oracle.fd_bsc(fS, fT[0])
+        P = oracle.default_params(oracle.BSC, oracle.KM if corr == "K" else oracle.NN, 6, 0.6, 1.5, oracle.bbx_magnitude(dsS), max_iter=80)
+    ro = oracle.register(P, dsS[kpS].astype(np.float64), dsT[kpT].astype(np.float64), FD)
     assert int(lines["KP"][3]) == ro["iters"]
     Rg = np.array([float(v) for v in lines["RT"]]).reshape(4, 4)
     assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
+    # S7 (main:153): the raw source under the final transform, row 11
+    np.testing.assert_allclose(np.array([float(v) for v in lines["REG"]], np.float32), oracle.transform_cloud(p.source[11:12], Rg)[0], rtol=0, atol=0)
     # CRegistration (common_reg.h): transformcloud -> calOverlap -> icp_reg -> invTransform, against the CPU restatement
     Rf = Rg.astype(np.float32)
     S1 = oracle.transform_cloud(dsS, Rf.astype(np.float64))

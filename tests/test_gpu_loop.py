@@ -87,6 +87,35 @@ def test_loop_fpfh_energy(ctx, api, synth, oracle, corr):
     np.testing.assert_allclose(rg["Rt"], ro["Rt"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("feature,corr", [("none", 0), ("bsc", 1), ("bsc", 2)])
+def test_iterate_equals_register(ctx, api, synth, oracle, feature, corr):
+    """ghicp_loop_create + ghicp_iterate (one pass of ghicp_reg.cpp:49-103 per call): the same records, match lists and final 4x4 as
+    ghicp_register, bit for bit, and the oracle's iteration count; iterating a converged loop is an error."""
+    import torch
+
+    p, kpS, kpT, bbx = _cfg1(synth, oracle, n_kp=500)
+    kpS, kpT = kpS[:430], kpT[:500]
+    FDg, FDo = None, None
+    if feature == "bsc":
+        FDo = _fake_bsc_fd(np.random.default_rng(21 + corr), 430, 500)
+        FDg = torch.from_numpy(FDo.astype(np.int16)).to(ctx.dev)
+    ft_g, ft_o = (api.FEATURE_BSC, oracle.BSC) if feature == "bsc" else (api.FEATURE_NONE, oracle.NONE)
+    pg = api.default_params(ft_g, corr, 6, 0.6 if feature == "bsc" else 0.9, 1.5, bbx, max_iter=40)
+    whole = ctx.register(pg, kpS, kpT, FDg, want_matchlist=True)
+    steps = ctx.register_stepwise(pg, kpS, kpT, FDg)
+    assert steps["iters"] == whole["iters"] == len(steps["trace"])
+    np.testing.assert_array_equal(steps["matchlist"], whole["matchlist"])
+    for a, b in zip(steps["trace"], whole["trace"]):
+        for k in a:
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)  # identical bits, NaN == NaN
+    np.testing.assert_array_equal(steps["Rt"], whole["Rt"])
+    ro = oracle.register(oracle.default_params(ft_o, corr, 6, 0.6 if feature == "bsc" else 0.9, 1.5, bbx, max_iter=40), kpS, kpT, FDo)
+    assert steps["iters"] == ro["iters"] and steps["converged"] == int(ro["trace"][-1]["converged"])
+    if steps["converged"]:
+        with pytest.raises(Exception):
+            ctx.register_stepwise(pg, kpS, kpT, FDg, extra_calls=1)
+
+
 def test_km_kat_and_random(ctx, oracle):
     """km.cpp:237-259 known-answer vector + random matrices vs the oracle (and the reference's own km.cpp)."""
     W = np.array([[-5, -2, -100], [-4, -2, -6], [-100, -1, -7]], float)
