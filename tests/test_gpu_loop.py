@@ -116,6 +116,37 @@ def test_iterate_equals_register(ctx, api, synth, oracle, feature, corr):
             ctx.register_stepwise(pg, kpS, kpT, FDg, extra_calls=1)
 
 
+def test_final_transform_of_a_batch(ctx, oracle):
+    """S7 (main:153) for a batch in one launch (ghicp_transform_clouds): bit-identical to ghicp_transform_cloud cloud by cloud and to the
+    restatement, for packed clouds (the float4 path incl. its 1-3 point tail), an empty cloud and a NaN transform."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    sizes = [4096, 1, 0, 4099, 30001, 2]
+    clouds = [torch.from_numpy((rng.standard_normal((n, 3)) * 20).astype(np.float32)).to(ctx.dev) for n in sizes]
+    Rts = []
+    for i in range(len(sizes)):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        Rt = np.eye(4)
+        Rt[:3, :3] = q
+        Rt[:3, 3] = rng.standard_normal(3) * 5
+        if i == 4:
+            Rt[0, 3] = np.nan
+        Rts.append(Rt)
+    outs = [torch.full((n, 3), -7.0, dtype=torch.float32, device=ctx.dev) for n in sizes]
+    ctx.transform_clouds(clouds, Rts, outs)
+    for c, Rt, o in zip(clouds, Rts, outs):
+        single = ctx.transform_cloud(c, Rt).cpu().numpy() if c.shape[0] else np.zeros((0, 3), np.float32)
+        np.testing.assert_array_equal(o.cpu().numpy(), single)
+        np.testing.assert_array_equal(o.cpu().numpy(), oracle.transform_cloud(c.cpu().numpy(), Rt))
+    # a strided view base that is not 16-byte aligned takes the scalar path: same bits
+    big = torch.from_numpy((rng.standard_normal((1001, 3)) * 3).astype(np.float32)).to(ctx.dev)
+    off = big[1:]  # 12 bytes past an aligned base
+    o2 = torch.empty((1000, 3), dtype=torch.float32, device=ctx.dev)
+    ctx.transform_clouds([off], [Rts[0]], [o2])
+    np.testing.assert_array_equal(o2.cpu().numpy(), oracle.transform_cloud(off.cpu().numpy(), Rts[0]))
+
+
 def test_km_kat_and_random(ctx, oracle):
     """km.cpp:237-259 known-answer vector + random matrices vs the oracle (and the reference's own km.cpp)."""
     W = np.array([[-5, -2, -100], [-4, -2, -6], [-100, -1, -7]], float)
