@@ -57,7 +57,7 @@ typedef __attribute__((address_space(1))) const int* k4_gint;
 typedef __attribute__((address_space(1))) const double* k4_gf64;
 typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
 
-enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_NUM = 16 };
+enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_UNCERT, SH_LROW, SH_NUM = 16 };
 
 struct K4 {
   double *lx, *ly, *slack, *red;
@@ -80,7 +80,11 @@ __device__ inline int k4_cnt(int tn) { return tn > K4_CAP ? 0 : tn; }  // listed
 // non-tight entries (R4), ONLY_UNPUSHED skips rows whose minima are already in slack.  16 lanes per row, so a wave instruction works
 // on four rows and every lane has four entries (64 per row) in flight per round: the pass is bound by the latency of the CSR
 // loads (L2), not by their volume, and 16 rows per workgroup in flight is what hides it.
-template <bool REBUILD, bool PUSH, bool ONLY_UNPUSHED>
+// SEED (rule R3', with the rebuild pass of a failed phase): a tight entry into a column the failed phase had visited certifies that
+// column when it is the column's TREE EDGE (sty[col] = the row the flood claimed it from; certificates collect in goody, which is idle
+// between two augmenting phases); a tight entry into any other column is new: the column is claimed for the next phase's flood on the
+// spot (visited bit, tree edge, owner appended to the queue behind the `count` rows this pass reads).
+template <bool REBUILD, bool PUSH, bool ONLY_UNPUSHED, bool SEED = false>
 __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int count, int wave, int lane) {
   const int grp = lane >> 4, lig = lane & 15;
   unsigned long long* sl = reinterpret_cast<unsigned long long*>(s.slack);
@@ -114,6 +118,17 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
         const double d = (lxr + lyv[j]) - val[j];
         const bool td = d < s.eps;
         if (PUSH && in && !td) atomicMin(&sl[col[j]], (unsigned long long)__double_as_longlong(d));
+        if (SEED && in && td) {
+          const unsigned bit = 1u << (col[j] & 31);
+          if (s.prevy[col[j] >> 5] & bit) {
+            if (s.sty[col[j]] == x) atomicOr(&s.goody[col[j] >> 5], bit);
+          } else if (!(atomicOr(&s.visy[col[j] >> 5], bit) & bit)) {
+            s.sty[col[j]] = (unsigned short)x;
+            const int m = s.match[col[j]];
+            if (m == K4_NONE) s.sh[SH_FREE] = 1;
+            else { s.stx[atomicAdd(&s.sh[SH_QT], 1)] = (unsigned short)m; atomicOr(&s.visx[m >> 5], 1u << (m & 31)); }
+          }
+        }
         if (REBUILD) {
           const unsigned gb = (unsigned)(__ballot(in && td) >> (grp * 16)) & 0xffffu;
           if (in && td) {
@@ -259,13 +274,16 @@ __device__ inline double k4_wave_min(double v) {
 // ---- R3: the flood (wave 0), level by level.  Returns true when a free column is reachable; the visited rows are stx[0 .. *qt_out).
 // A column is claimed by the returning ds_or on its visited bit (two rows reaching it in the same instruction are serialised by
 // the LDS); every matched row owns exactly one column, so the claim of a column is also the one enqueue of its owner, and the
-// queue tail lives in a register (ballot ranks, no LDS counter).
-#define K4_CLAIM(WANT, COL, OWNER)                                                          \
+// queue tail lives in a register (ballot ranks, no LDS counter).  The row a column is claimed FROM is its tree edge (sty[col], the
+// DFS's column stack is idle until the augmenting phase): rule R3' certifies the tree after the next relabelling instead of flooding
+// from the root again.  The flood starts at queue position qh0 with qt0 rows queued and lflood0 the smallest label already swept.
+#define K4_CLAIM(WANT, COL, OWNER, PARENT)                                                  \
   do {                                                                                      \
     unsigned old_ = 0u;                                                                     \
     const unsigned bit_ = 1u << ((COL) & 31);                                               \
     if (WANT) old_ = atomicOr(&s.visy[(COL) >> 5], bit_);                                   \
     const bool fresh_ = (WANT) && !(old_ & bit_);                                           \
+    if (fresh_) s.sty[COL] = (unsigned short)(PARENT);                                      \
     free_l |= fresh_ && (OWNER) == K4_NONE;                                                 \
     const bool enq_ = fresh_ && (OWNER) != K4_NONE;                                         \
     const unsigned long long eb_ = __ballot(enq_);                                          \
@@ -277,16 +295,15 @@ __device__ inline double k4_wave_min(double v) {
   } while (0)
 
 template <bool PROF>
-__device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, long long* pc) {
+__device__ inline bool k4_flood(const K4& s, int qh0, int qt0, double lflood0, int lane, int* qt_out, long long* pc) {
   const int n = s.n;
-  if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); }
-  __builtin_amdgcn_wave_barrier();
-  int qh = 0, qt = 1;
+  int qh = qh0, qt = qt0;
   bool free_l = false;
-  double lflood = INFINITY;
+  double lflood = lflood0;
   while (qh < qt) {
     const int qe = qt;
     double lcand = INFINITY;
+    int xcand = 0;
     const long long tl0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
     if (PROF) pc[0]++;
     for (int base = qh; base < qe; base += 64) {
@@ -305,9 +322,9 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
 #pragma unroll
       for (int k = 0; k < K4_CAP; k++) {  // listed entries are tight (R2): unvisited is all that is asked
         const bool want = (int)(k < t) & (int)(((vw[k] >> (lc[k] & 31)) & 1u) == 0u);
-        K4_CLAIM(want, lc[k], mc[k]);
+        K4_CLAIM(want, lc[k], mc[k], xr);
       }
-      if (act && (lxr - s.bg) < s.eps && lxr < lflood) lcand = fmin(lcand, lxr);
+      if (act && (lxr - s.bg) < s.eps && lxr < lflood && lxr < lcand) { lcand = lxr; xcand = xr; }
       unsigned long long ob = __ballot(act && k4_flagged(tn));
       if (PROF) pc[1] += __popcll(ob);
       while (ob) {  // flagged rows: every tight entry of the CSR row
@@ -322,14 +339,16 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
           const double val = s.vals[cc];
           const int m = s.match[col];
           const bool want = (int)(c < ce) & (int)(((lxo + s.ly[col]) - val) < s.eps) & (int)!k4_bit(s.visy, col);
-          K4_CLAIM(want, col, m);
+          K4_CLAIM(want, col, m, xo);
         }
       }
     }
     const long long tl1 = PROF ? (long long)__builtin_readcyclecounter() : 0;
     if (PROF) pc[2] += tl1 - tl0;
     if (__ballot(lcand < lflood)) {  // a label below every one swept so far (rare: a reduction per level was a third of a level's time);
-      lcand = k4_wave_min(lcand);    // T_L of the smallest label contains T_L of every larger one
+      const double lmin = k4_wave_min(lcand);  // T_L of the smallest label contains T_L of every larger one
+      const int xpar = __builtin_amdgcn_readlane(xcand, (int)__ffsll((long long)__ballot(lcand == lmin)) - 1);  // a row that has it
+      lcand = lmin;
       lflood = lcand;
       if (PROF) pc[3]++;
       for (int y0 = 0; y0 < n; y0 += 256) {  // four independent windows per round
@@ -347,7 +366,7 @@ __device__ inline bool k4_flood(const K4& s, int root, int lane, int* qt_out, lo
         for (int k = 0; k < 4; k++) {
           if (y0 + k * 64 >= n) break;
           const int y = min(y0 + k * 64 + lane, n - 1);
-          K4_CLAIM(c[k], y, m[k]);
+          K4_CLAIM(c[k], y, m[k], xpar);
         }
       }
     }
@@ -641,21 +660,22 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
     for (int i = tid; i < n; i += K4_T) s.slack[i] = K4_INF;
     for (int w = tid; w < nw; w += K4_T) s.pushed[w] = 0u;
     bool have_prev = false;
+    // phase 0 floods from the root; a later phase expands the certified sets of the failed phase before it (R3')
+    for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; }
+    __syncthreads();
+    if (wave == sw) {
+      if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); }
+      __builtin_amdgcn_wave_barrier();
+      int fq = 0;
+      const bool fr = k4_flood<PROF>(s, 0, 1, INFINITY, lane, &fq, pcf);
+      if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
+    }
     for (int phase = 0;; ++phase) {
       if (PROF) q_phase++;
-      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; }
-      __syncthreads();
-      const long long t0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
-      if (wave == sw) {
-        int fq = 0;
-        const bool fr = k4_flood<PROF>(s, root, lane, &fq, pcf);
-        if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
-      }
       __syncthreads();
       const bool free_found = s.sh[SH_RES] != 0;
       const int qt = s.sh[SH_QTF];
       const long long t1 = PROF ? (long long)__builtin_readcyclecounter() : 0;
-      if (PROF) c_flood += t1 - t0;
       if (!free_found) {
         // ---- R4: failed phase
         if (PROF) { q_fail++; q_frows += qt; }
@@ -676,7 +696,7 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         dl = k4_wave_min(dl);
         if (lane == 0) s.red[4 + wave] = dl;
         for (int w = tid; w < nw; w += K4_T) {
-          if (have_prev && (s.prevy[w] & ~s.visy[w])) s.sh[SH_HAZ] = 1;  // a visited column dropped out (R4)
+          if (have_prev && (s.prevy[w] & ~s.visy[w])) s.sh[SH_HAZ] = 1;  // a visited column dropped out (R4; only after a flood from the root)
           s.prevy[w] = s.visy[w];
         }
         __syncthreads();
@@ -687,10 +707,58 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
           if (k4_bit(s.visy, i)) s.ly[i] += dl;
           else s.slack[i] -= dl;
         }
-        for (int w = tid; w < nw; w += K4_T) s.pushed[w] = s.visx[w];
+        for (int w = tid; w < nw; w += K4_T) { s.pushed[w] = s.visx[w]; s.goody[w] = 0u; }  // goody: the certificates of this relabelling
+        if (tid == 0) { s.sh[SH_QT] = qt; s.sh[SH_FREE] = 0; s.sh[SH_UNCERT] = 0; s.sh[SH_LROW] = 0; }
         __syncthreads();
-        k4_revalidate(s, tid);                                  // rows that were not visited: entries in visited columns may have left
-        k4_bulk<true, true, false>(s, s.stx, qt, wave, lane);  // visited rows: lists under the new labels + the minima of the next phase
+        k4_revalidate(s, tid);                                        // rows that were not visited: entries in visited columns may have left
+        k4_bulk<true, true, false, true>(s, s.stx, qt, wave, lane);  // visited rows: lists under the new labels, the minima of the next phase,
+                                                                      // certificates of their tree edges, claims of their newly tight columns
+        double lb = INFINITY;  // the smallest label of a visited row that can be background-tight at all
+        for (int i = tid; i < qt; i += K4_T) {
+          const double l = s.lx[s.stx[i]];
+          if ((l - bg) < eps) lb = fmin(lb, l);
+        }
+        lb = k4_wave_min(lb);
+        if (lane == 0) s.red[8 + wave] = lb;
+        __syncthreads();
+        const double lnew = fmin(fmin(s.red[8], s.red[9]), fmin(s.red[10], s.red[11]));
+        for (int i = tid; i < qt; i += K4_T)
+          if (s.lx[s.stx[i]] == lnew) s.sh[SH_LROW] = s.stx[i];  // any row that has it
+        __syncthreads();
+        const int lrow = s.sh[SH_LROW];
+        for (int y = tid; y < n; y += K4_T) {
+          const unsigned bit = 1u << (y & 31);
+          if (s.prevy[y >> 5] & bit) {  // an old column: its tree edge has to be tight under the new labels (explicit: seen by the pass above)
+            if (!(s.goody[y >> 5] & bit) && !(((s.lx[s.sty[y]] + s.ly[y]) - bg) < eps)) s.sh[SH_UNCERT] = 1;
+          } else if (!(s.visy[y >> 5] & bit) && ((lnew + s.ly[y]) - bg) < eps) {  // T_L of the smallest label (INF: never)
+            if (!(atomicOr(&s.visy[y >> 5], bit) & bit)) {
+              s.sty[y] = (unsigned short)lrow;
+              const int m = s.match[y];
+              if (m == K4_NONE) s.sh[SH_FREE] = 1;
+              else { s.stx[atomicAdd(&s.sh[SH_QT], 1)] = (unsigned short)m; atomicOr(&s.visx[m >> 5], 1u << (m & 31)); }
+            }
+          }
+        }
+        __syncthreads();
+        const bool certified = s.sh[SH_UNCERT] == 0;
+        if (!certified) {  // an ulp moved a tree edge across eps: flood from the root, rule R4's check decides
+          __syncthreads();
+          for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; }
+          __syncthreads();
+        }
+        if (wave == sw) {
+          int fq = s.sh[SH_QT];
+          bool fr = s.sh[SH_FREE] != 0;
+          if (!certified) {
+            if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); }
+            __builtin_amdgcn_wave_barrier();
+            fr = k4_flood<PROF>(s, 0, 1, INFINITY, lane, &fq, pcf);
+          } else if (!fr) {
+            fr = k4_flood<PROF>(s, qt, fq, lnew, lane, &fq, pcf);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
+        }
         have_prev = true;
         if (PROF) { q_prows += qt; c_fail += (long long)__builtin_readcyclecounter() - t1; }
         if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
