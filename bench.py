@@ -111,8 +111,10 @@ def algorithmic_bytes(k, m, n2, V, kernel, batch):
         return (24.0 * 2 * k + 2.0 * k * k + 12.0 * k) * batch
     if kernel == "km_weights":  # CSR build: FD read twice (count + fill), <= 12 B per explicit entry written
         return (24.0 * 2 * k + 4.0 * k * k) * batch
-    if kernel == "fd_bsc":
-        return 56.0 * (V + 1) * k + 2.0 * k * k
+    if kernel == "fd_bsc":  # ONE launch for `batch` pairs: strings in, matrix + transposed copy out
+        return (56.0 * (V + 1) * k + 4.0 * k * k) * batch
+    if kernel == "transform":  # S7 (main:153): 12 B read + 12 B written per RAW source point (m stands for the raw count here)
+        return 24.0 * m * batch
     return float("nan")
 
 
@@ -355,6 +357,7 @@ def main():
     job_records = {}
     last_results = [None] * G
     thread_busy = {"front_end": 0.0, "loop": 0.0, "gather_wait": 0.0}
+    host_log = {"fe": [], "loop": [], "t0": 0.0}  # (start, end, clouds) of every front-end call / (start, end, step) of every loop call, timed region only
 
     # ---- S7 (main:153): the RAW source of every registered pair under its final transform, inside the timed region, one launch per RING
     # pairs (ghicp_transform_clouds).  The transformed clouds land in a ring of output buffers per loop context (a consumer would read them
@@ -434,6 +437,7 @@ def main():
                                     buf[i][0].recompute(S)
                                     buf[i][1].recompute(T)
                         dt = time.perf_counter() - t
+                        host_log["fe"].append((t, t + dt, 2 * len(chunk)))
                         with cv:
                             thread_busy["front_end"] += dt
                             for i in chunk:
@@ -462,6 +466,7 @@ def main():
                         final_transform(gp, [mine[i] for i in range(bounds[g], bounds[g + 1])], r)
                         loop_ctxs[gp].sync()
                     dt = time.perf_counter() - t
+                    host_log["loop"].append((t, t + dt, k))
                     with cv:
                         thread_busy["loop"] += dt
                         res[k][g] = r
@@ -596,8 +601,11 @@ def main():
     for c in ctxs:
         c.kernel_timing(True)
     thread_busy["front_end"] = thread_busy["loop"] = thread_busy["gather_wait"] = 0.0
+    host_log["fe"].clear()
+    host_log["loop"].clear()
     barrier()
     t0 = time.perf_counter()
+    host_log["t0"] = t0
     run_steps(args.steps)
     time_own = time.perf_counter() - t0  # before the closing barrier
     barrier()
@@ -840,7 +848,28 @@ def main():
         out["speedup_vs_cpu_1thread"] = round(rate_all / cpu["value"], 2)  # all pairs on both sides (the CPU legs register the same scenes)
         out["speedup_vs_cpu_all_cores"] = round(rate_all / cpu["all_cores"]["value"], 2)
     # ---- everything that does not fit an 8 KB tail goes to a side file: per-scene records (4x4s), per-kernel table, calibration
-    detail = {"scenes": [{"pair_id": int(sid), "k_s": int(st.k_s), "k_t": int(st.k_t), "m_s": int(st.m_s), "m_t": int(st.m_t), "iterations": int(st.iterations),
+    # ---- where a step's time goes (diagnostics): host-side call intervals and the slot timeline of the last batch of every loop context
+    timeline = {"fe_calls_s": [[round(a - host_log["t0"], 3), round(b - host_log["t0"], 3), n] for a, b, n in sorted(host_log["fe"])][:4000],
+                "loop_calls_s": [[round(a - host_log["t0"], 3), round(b - host_log["t0"], 3), k] for a, b, k in sorted(host_log["loop"])], "last_batches": []}
+    for ci, c in enumerate(loop_ctxs):
+        try:
+            tl = c.loop_timeline()
+        except Exception:  # noqa: BLE001
+            tl = np.zeros((0, 3), np.int64)
+        tl = tl[(tl[:, 1] > tl[:, 0]) & (tl[:, 0] > 0)] if len(tl) else tl
+        if len(tl) == 0:
+            continue
+        b0 = tl[:, 0].min()
+        beg, end = (tl[:, 0] - b0) / 1e8, (tl[:, 1] - b0) / 1e8  # seconds since the first slot started
+        span = float(end.max())
+        edges = np.arange(0.0, span + 0.25, 0.25)
+        active = [int(((beg <= e) & (end > e)).sum()) for e in edges]
+        long_ = np.argsort(-(end - beg))[:10]
+        timeline["last_batches"].append({"ctx": ci, "pairs": int(len(tl)), "span_s": round(span, 3), "active_pairs_every_250ms": active,
+                                         "pair_seconds": round(float((end - beg).sum()), 1), "ms_per_iteration_in_slot": round(1e3 * float((end - beg).sum()) / max(1, int(tl[:, 2].sum())), 2),
+                                         "ten_longest": [{"begin_s": round(float(beg[i]), 2), "end_s": round(float(end[i]), 2), "iterations": int(tl[i, 2])} for i in long_],
+                                         "last_begin_s": round(float(beg.max()), 2)})
+    detail = {"timeline": timeline, "scenes": [{"pair_id": int(sid), "k_s": int(st.k_s), "k_t": int(st.k_t), "m_s": int(st.m_s), "m_t": int(st.m_t), "iterations": int(st.iterations),
                           "converged": int(st.converged), "registered_ok": int(st.registered_ok), "rmse_after": float(st.rmse_after),
                           "rot_vs_gt": float(gt[sid][0]) if sid in gt else None, "trans_vs_gt_m": float(gt[sid][1]) if sid in gt else None,
                           "Rt": [float(v) for v in st.Rt[:]]} for sid, st in sorted(by_scene.items())],

@@ -146,6 +146,15 @@ extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* t
     }
   return ctx->fail(GHICP_ERR_ARG, "unknown kernel name '%s'", name);
 }
+extern "C" int ghicp_ctx_loop_timeline(ghicp_ctx* ctx, int64_t* out3, int64_t cap_pairs, int64_t* n_pairs) {
+  GH_ENTER(ctx);
+  GH_ARG(n_pairs != nullptr && cap_pairs >= 0);
+  const int64_t n = (int64_t)(ctx->loop_timeline.size() / 3);
+  *n_pairs = n;
+  if (out3)
+    for (int64_t i = 0; i < std::min(n, cap_pairs) * 3; i++) out3[i] = ctx->loop_timeline[(size_t)i];
+  return GHICP_OK;
+}
 extern "C" const char* ghicp_last_error(const ghicp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 namespace {

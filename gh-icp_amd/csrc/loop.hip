@@ -32,6 +32,7 @@ struct LoopState {
   double RMS, FDM, FDstd, IoU, para1, para2, penalty, CDmean, CDstd, energy;
   double Rt_till[16];
   double rmse_after;
+  unsigned long long t_begin, t_end;  // persistent pair loop: when a slot took the pair and when it let go (s_memrealtime, 100 MHz)
 };
 
 struct LoopConst {
@@ -622,6 +623,7 @@ __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restric
     const int q = *s_idx;
     if (q >= npairs) break;
     const LoopProb& P = probs[order[q]];
+    if (threadIdx.x == 0 && lstat) P.st->t_begin = __builtin_amdgcn_s_memrealtime();
     while (*(volatile int*)&P.st->done == 0) {
       pl_sweep<FT>(P, sB, red);   // calED + calCD_* + sums + penalty (ghicp_reg.cpp:114-139, 216-341)
       pl_graph<FT>(P, ired);      // the sparse graph of findcorrespondenceKM (ghicp_reg.cpp:348-365): count, scan, fill
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restric
       }
       pl_solve<FT>(P, red, ired, sh);  // Km::output, transformestimation, adjustweight (ghicp_reg.cpp:416-460, 605-927)
     }
+    if (threadIdx.x == 0 && lstat) P.st->t_end = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && progress) __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (threadIdx.x == 0 && lstat) {  // launch record: first slot start, last slot end, sum / max of the solve times, solves, sum of slot lifetimes
@@ -941,6 +944,14 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       GH_HIP(hipMemcpyAsync(hst.data(), dstates, (size_t)nb * sizeof(LoopState), hipMemcpyDeviceToHost, s));
       GH_HIP(hipMemcpyAsync(hkmst.data(), dkmst, ((size_t)nb + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
       GH_HIP(hipStreamSynchronize(s));
+      if (ctx->kt_on && persistent) {  // slot timeline of the batch (diagnostics, ghicp_ctx_loop_timeline): per pair begin / end / iterations
+        ctx->loop_timeline.resize((size_t)nb * 3);
+        for (int b = 0; b < nb; b++) {
+          ctx->loop_timeline[(size_t)b * 3] = (long long)hst[b].t_begin;
+          ctx->loop_timeline[(size_t)b * 3 + 1] = (long long)hst[b].t_end;
+          ctx->loop_timeline[(size_t)b * 3 + 2] = hst[b].it;
+        }
+      }
       for (int b = 0; b < nb; b++) {
         const gh_loop_job& J = jobs[b];
         for (int d = 0; d < 16; d++) J.Rt16[d] = hst[b].Rt_till[d];

@@ -91,6 +91,10 @@ int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8);
  * timing is on: out8 = { batches, workgroups that ran, solves, mean solve ms, longest solve ms, mean batch span ms, idle-slot fraction
  * (1 - slot lifetimes / (resident slots x span): the tail of a batch), share of the slot lifetimes spent inside Kuhn-Munkres solves }. */
 int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8);
+/* Diagnostics: the slot timeline of the LAST persistent batch that ran on this context while kernel timing was on -- per pair of the
+ * batch (in the order of the call) three int64: when a solve slot took the pair, when it let go (device real-time clock, 100 MHz ticks),
+ * and the pair's iterations.  out3 may be NULL (only *n_pairs is written); at most cap_pairs triples are copied. */
+int ghicp_ctx_loop_timeline(ghicp_ctx* ctx, int64_t* out3, int64_t cap_pairs, int64_t* n_pairs);
 /* Progress of the batched loop (ghicp_register_pairs / ghicp_register_clouds) currently running on this context: pairs that are still
  * iterating and pairs of the batch.  No device work; may be called from another thread while the loop runs (a scheduler can start the
  * next batch's front ends when only the slowly converging pairs are left). */

@@ -23,12 +23,13 @@ def test_every_timed_kernel_has_a_byte_model():
 
 
 def test_pair_bytes_follows_survey_8d():
-    # SURVEY.md 8(d'): per cloud S0 + S1 + S2 + S3, S4 once, I x (S5 + S6); S7 is not part of a step
+    # SURVEY.md 8(d'): per cloud S0 + S1 + S2 + S3, S4 once, I x (S5 + S6), S7 = 24 B per raw source point (main:153)
     n, m, c, ks, kt, V, it = 1_000_000, 500_000, 50_000, 4000, 4000, 4, 30
     b = bench.pair_bytes(n, m, c, ks, kt, V, it, True, 1500)
     s5 = 24 * 8000 + 2 * 16e6 + 12 * 8000 + 16 * 16e6
     assert abs(b - (2 * ((16 * n + 16 * m) + 36 * m + (20 * m + 4 * 4000) + (16 * m + 56 * 2.5 * 4000 + 48 * 4000)) + (56 * (4 * 4000 + 4000) + 2 * 16e6)
-                    + it * (s5 + 48 * 1500 + 48 * 4000))) < 1.0
+                    + it * (s5 + 48 * 1500 + 48 * 4000) + 24 * n)) < 1.0
+    assert bench.pair_bytes(n, m, c, ks, kt, V, it, True, 1500, n_src=2 * n) == b + 24 * n  # S7 counts the raw SOURCE
     assert bench.pair_bytes(n, m, c, ks, kt, V, it, False, 1500) < b  # NN: no 16 n^2 per iteration
     assert bench.pair_loop_bytes(657, 540_000, 10, 300) * 2 == bench.pair_loop_bytes(657, 540_000, 20, 300)
 
