@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--fe-batch-streams", type=int, default=4, help="worker contexts of the batched front end")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the many-core CPU leg (0 = 64, capped by the host's logical CPUs; the distinct scenes are cycled)")
     ap.add_argument("--scene-cache", default="", help="directory that keeps the generated synthetic scenes between runs (the generation is untimed)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the pair queue: nccl (= RCCL over xGMI, one rank per GPU) or "
+                    "gloo (host-side records; lets several ranks share ONE GPU: the N > 1 queue logic on real HIP contexts, SURVEY.md 8e)")
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"], help="pair queue across ranks: static p mod R, or chunks claimed from a shared counter")
     ap.add_argument("--queue-chunks", type=int, default=8, help="--queue dynamic: claims per rank and step (chunk = job / (ranks x this))")
     ap.add_argument("--detail-dir", default=os.path.join(ROOT, "gpurun_out"), help="where the per-scene / per-kernel side file goes")
@@ -238,12 +240,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the GH-ICP hot path has no CPU fallback")
+    if args.backend == "gloo":  # ranks may share a device (virtual ranks on one GPU)
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    comm_dev = "cuda" if args.backend == "nccl" else "cpu"  # gloo gathers host tensors
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
         manifest = pq.broadcast_manifest(manifest, dist)  # scene ids, not point data
 
     api = importlib.import_module("gh-icp_amd.api")
@@ -353,7 +361,7 @@ def main():
     for g in range(G):
         group_of[bounds[g]:bounds[g + 1]] = g
     nb_max = n_job if dynamic else pq.records_per_rank(n_job, world)  # same record block on every rank (all_gather wants equal shapes)
-    rec_dev = torch.zeros((nb_max, pq.RECORD_WIDTH), dtype=torch.float64, device="cuda")
+    rec_dev = torch.zeros((nb_max, pq.RECORD_WIDTH), dtype=torch.float64, device=comm_dev)
     job_records = {}
     last_results = [None] * G
     thread_busy = {"front_end": 0.0, "loop": 0.0, "gather_wait": 0.0}
@@ -615,11 +623,11 @@ def main():
     busy_mine = max(0.0, time_own - thread_busy["gather_wait"])
     busy_all = [busy_mine]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        bt = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(bt, torch.tensor([busy_mine], dtype=torch.float64, device="cuda"))
+        bt = [torch.zeros(1, dtype=torch.float64, device=comm_dev) for _ in range(world)]
+        dist.all_gather(bt, torch.tensor([busy_mine], dtype=torch.float64, device=comm_dev))
         busy_all = [float(x.item()) for x in bt]
     results = last_results
     if dynamic:  # what this rank claimed in the last step, as one "group"
@@ -827,7 +835,7 @@ def main():
                    "config_id": args.config, "fe_batch": args.fe_batch, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene),
                    "n_s": int(sts[0].n_s), "m_mean": round(m_mean), "k_mean": round(k_mean, 1), "n_km_max": int(max(max(s.k_s, s.k_t) for s in sts)),
                    "iterations_mean": round(it_mean, 1), "iterations_min_max": [int(min(s.iterations for s in sts)), int(max(s.iterations for s in sts))],
-                   "parallelism": "pairs sharded over ranks (%s), no data-path collective" % args.queue},
+                   "parallelism": "pairs sharded over ranks (%s), no data-path collective" % args.queue, "backend": args.backend if world > 1 else None},
         "registered_ok": {"pairs_per_step_rank0": nb_eff, "reference_verdict_ok": int(reg_ok_pairs), "gt_ok": int(gt_ok_pairs),
                           "gt_tolerance": "0.05 rot (||R R_gt^T - I||_F), 0.5 m", "distinct_scenes_gt_failed": gt_fail[:24],
                           "value_gt_ok": round(rate_all * gt_ok_pairs / nb_eff, 4), "value_reference_verdict_ok": round(rate_all * reg_ok_pairs / nb_eff, 4),
@@ -869,7 +877,10 @@ def main():
                                          "pair_seconds": round(float((end - beg).sum()), 1), "ms_per_iteration_in_slot": round(1e3 * float((end - beg).sum()) / max(1, int(tl[:, 2].sum())), 2),
                                          "ten_longest": [{"begin_s": round(float(beg[i]), 2), "end_s": round(float(end[i]), 2), "iterations": int(tl[i, 2])} for i in long_],
                                          "last_begin_s": round(float(beg.max()), 2)})
-    detail = {"timeline": timeline, "scenes": [{"pair_id": int(sid), "k_s": int(st.k_s), "k_t": int(st.k_t), "m_s": int(st.m_s), "m_t": int(st.m_t), "iterations": int(st.iterations),
+    detail = {"timeline": timeline,
+              # every pair of the LAST step's job, from the all-gather of the result records (all ranks): pair id -> [iterations, converged, 4x4]
+              "job_records": {str(k): [v[0], v[1]] + list(v[2]) for k, v in sorted(job_records.items())} if len(job_records) <= 4096 else None,
+              "scenes": [{"pair_id": int(sid), "k_s": int(st.k_s), "k_t": int(st.k_t), "m_s": int(st.m_s), "m_t": int(st.m_t), "iterations": int(st.iterations),
                           "converged": int(st.converged), "registered_ok": int(st.registered_ok), "rmse_after": float(st.rmse_after),
                           "rot_vs_gt": float(gt[sid][0]) if sid in gt else None, "trans_vs_gt_m": float(gt[sid][1]) if sid in gt else None,
                           "Rt": [float(v) for v in st.Rt[:]]} for sid, st in sorted(by_scene.items())],

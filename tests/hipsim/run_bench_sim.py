@@ -41,6 +41,7 @@ def main():
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.zeros = _cpu_device(torch.zeros)
     torch.tensor = _cpu_device(torch.tensor)
+    torch.empty = _cpu_device(torch.empty)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # one process per "GPU": RCCL becomes gloo, everything else of the N > 1 path is bench.py's own
         import torch.distributed as dist
 
