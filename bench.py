@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--scene-cache", default="", help="directory that keeps the generated synthetic scenes between runs (the generation is untimed)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the pair queue: nccl (= RCCL over xGMI, one rank per GPU) or "
                     "gloo (host-side records; lets several ranks share ONE GPU: the N > 1 queue logic on real HIP contexts, SURVEY.md 8e)")
+    ap.add_argument("--queue-hints", type=int, default=1, help="1: the persistent pair loop queues the pairs of a batch costliest first, the cost being what the SAME pair "
+                    "needed in the previous step (iterations x n^2; ghicp_ctx_set_loop_cost_hints): the 112-iteration pairs start first instead of in the middle "
+                    "of a batch.  0: largest graph first (no history).  Results do not depend on the order")
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"], help="pair queue across ranks: static p mod R, or chunks claimed from a shared counter")
     ap.add_argument("--queue-chunks", type=int, default=8, help="--queue dynamic: claims per rank and step (chunk = job / (ranks x this))")
     ap.add_argument("--detail-dir", default=os.path.join(ROOT, "gpurun_out"), help="where the per-scene / per-kernel side file goes")
@@ -365,6 +368,7 @@ def main():
     job_records = {}
     last_results = [None] * G
     thread_busy = {"front_end": 0.0, "loop": 0.0, "gather_wait": 0.0}
+    pair_cost = [None] * G  # per loop group: cost of each of its pairs as measured in the previous step (queue hints)
     host_log = {"fe": [], "loop": [], "t0": 0.0}  # (start, end, clouds) of every front-end call / (start, end, step) of every loop call, timed region only
 
     # ---- S7 (main:153): the RAW source of every registered pair under its final transform, inside the timed region, one launch per RING
@@ -469,7 +473,11 @@ def main():
                     with cv:
                         started[k][g] = True
                     t = time.perf_counter()
+                    if args.queue_hints and pair_cost[g] is not None and len(pair_cost[g]) == n_g and CF["corr"] == "KM":
+                        loop_ctxs[gp].set_loop_cost_hints(pair_cost[g])
                     r = loop_ctxs[gp].register_clouds(cfg, pool_h[k % NBUF][bounds[g]:bounds[g + 1]]) if n_g else []
+                    if n_g:
+                        pair_cost[g] = [float(st.iterations) * float(max(st.k_s, st.k_t)) ** 2 for st in r]
                     if n_g:
                         final_transform(gp, [mine[i] for i in range(bounds[g], bounds[g + 1])], r)
                         loop_ctxs[gp].sync()
@@ -835,6 +843,8 @@ def main():
                    "config_id": args.config, "fe_batch": args.fe_batch, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene),
                    "n_s": int(sts[0].n_s), "m_mean": round(m_mean), "k_mean": round(k_mean, 1), "n_km_max": int(max(max(s.k_s, s.k_t) for s in sts)),
                    "iterations_mean": round(it_mean, 1), "iterations_min_max": [int(min(s.iterations for s in sts)), int(max(s.iterations for s in sts))],
+                   "queue_order": ("costliest first, cost = iterations x n^2 of the same pair in the previous step" if args.queue_hints and CF["corr"] == "KM" and not dynamic
+                                   else "largest graph first"),
                    "parallelism": "pairs sharded over ranks (%s), no data-path collective" % args.queue, "backend": args.backend if world > 1 else None},
         "registered_ok": {"pairs_per_step_rank0": nb_eff, "reference_verdict_ok": int(reg_ok_pairs), "gt_ok": int(gt_ok_pairs),
                           "gt_tolerance": "0.05 rot (||R R_gt^T - I||_F), 0.5 m", "distinct_scenes_gt_failed": gt_fail[:24],

@@ -47,7 +47,7 @@ class PairStats(C.Structure):
 
 EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_set_cu_mask",
-    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_timeline", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
+    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_timeline", "ghicp_ctx_set_loop_cost_hints", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_cloud_bounds", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_loop_create", "ghicp_iterate", "ghicp_loop_result", "ghicp_loop_destroy", "ghicp_transform_cloud", "ghicp_transform_clouds", "ghicp_register_pair",
@@ -211,6 +211,11 @@ class Context:
     def loop_progress_reset(self, total):
         """declare a batch of `total` pairs as about to start (so that other threads never read the previous batch's finished state)"""
         self._check(self.lib.ghicp_ctx_loop_progress_reset(self.h, C.c_int64(int(total))))
+
+    def set_loop_cost_hints(self, cost):
+        """queue order of the next batched Kuhn-Munkres registration with len(cost) pairs: costliest first (results do not depend on it)"""
+        c = np.ascontiguousarray(cost, dtype=np.float32)
+        self._check(self.lib.ghicp_ctx_set_loop_cost_hints(self.h, C.c_int32(c.size), c.ctypes.data_as(C.POINTER(C.c_float))))
 
     def loop_timeline(self):
         """(n, 3) int64: per pair of the last persistent batch (kernel timing on) slot begin / end in 100 MHz ticks, iterations"""

@@ -132,6 +132,7 @@ struct ghicp_ctx {
   static constexpr int KM_LSTAT_W = 8;
   long long km_launches = 0;
   std::vector<int> km_slots;
+  std::vector<float> loop_cost_hints;    // ghicp_ctx_set_loop_cost_hints: queue order of the next persistent batch of exactly this many pairs
   std::vector<long long> loop_timeline;  // last persistent batch with kernel timing on: per pair (begin, end) in 100 MHz ticks and iterations
   // progress of the batched loop that is running on this context (pairs still iterating / pairs of the batch), readable from
   // other threads while ghicp_register_pairs / ghicp_register_clouds is in flight (ghicp_ctx_loop_progress)

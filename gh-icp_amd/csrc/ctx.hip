@@ -146,6 +146,14 @@ extern "C" int ghicp_ctx_kernel_time(ghicp_ctx* ctx, const char* name, double* t
     }
   return ctx->fail(GHICP_ERR_ARG, "unknown kernel name '%s'", name);
 }
+extern "C" int ghicp_ctx_set_loop_cost_hints(ghicp_ctx* ctx, int32_t n_pairs, const float* cost) {
+  GH_ENTER(ctx);
+  GH_ARG(n_pairs >= 0 && (n_pairs == 0 || cost != nullptr));
+  ctx->loop_cost_hints.assign(cost, cost + n_pairs);
+  for (float& c : ctx->loop_cost_hints)
+    if (!(c == c)) c = 0.f;  // NaN would break the strict weak order of the sort
+  return GHICP_OK;
+}
 extern "C" int ghicp_ctx_loop_timeline(ghicp_ctx* ctx, int64_t* out3, int64_t cap_pairs, int64_t* n_pairs) {
   GH_ENTER(ctx);
   GH_ARG(n_pairs != nullptr && cap_pairs >= 0);

@@ -55,7 +55,7 @@ int gh_km4_launch(ghicp_ctx* ctx, const Km2Problem* d_probs, int nprob, int n_ma
   return k4_launch(ctx, d_probs, nprob, gh_km4_lds_bytes(n_max), nullptr);
 }
 
-int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan) {
+int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const float* cost) {
   *plan = Km4Plan();
   std::vector<std::pair<int, int>> key((size_t)nprob);  // (problems per CU, n) per problem
   for (int i = 0; i < nprob; i++) {
@@ -65,8 +65,11 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan) {
   }
   std::vector<int> order((size_t)nprob);
   for (int i = 0; i < nprob; i++) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {  // fewest per CU (largest problems) first; within a class largest first
+  // fewest per CU (largest problems) first; within a class the largest first -- or, with cost hints, the costliest first: the span of a
+  // batch is bounded below by its slowest pair (112 iterations x ~50 ms on the bench scenes), so that pair must not start in the middle
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
     if (key[a].first != key[b].first) return key[a].first < key[b].first;
+    if (cost && cost[a] != cost[b]) return cost[a] > cost[b];
     return key[a].second > key[b].second;
   });
   int nc = 0;

@@ -25,5 +25,6 @@ struct Km4Plan {
   size_t lds[8] = {0};
   int* d_order = nullptr;  // device: problem indices, class after class
 };
-int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan);
+// cost: optional per-problem cost hints (host, nprob floats): within a class the costliest problems are queued first
+int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const float* cost = nullptr);
 int gh_km4_launch_plan(ghicp_ctx* ctx, const Km2Problem* d_probs, const Km4Plan& plan);

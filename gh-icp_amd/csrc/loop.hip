@@ -894,7 +894,14 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         std::vector<int> hn((size_t)nb);
         bool all_sparse = true;
         for (int b = 0; b < nb; b++) { hn[b] = hp[b].C.n; all_sparse &= (hp[b].km_rptr != nullptr) || jobs[b].ks <= 0 || jobs[b].kt <= 0; }
-        if (all_sparse) { GH_TRY(gh_km4_plan(ctx, hn.data(), nb, &km_plan)); use_plan = true; }
+        if (all_sparse) {
+          // cost hints of the caller for exactly this batch (ghicp_ctx_set_loop_cost_hints): consumed once
+          const bool hinted = (int)ctx->loop_cost_hints.size() == nb;
+          const int rc = gh_km4_plan(ctx, hn.data(), nb, &km_plan, hinted ? ctx->loop_cost_hints.data() : nullptr);
+          ctx->loop_cost_hints.clear();
+          GH_TRY(rc);
+          use_plan = true;
+        }
       }
       if (persistent && use_plan) {
         const int rc = run_pair_loop<FT>(ctx, dprobs, nb, km_plan, dqheads);

@@ -58,8 +58,8 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
   }
   for (unsigned q0 = qb; q0 < qe; q0 += 64) {
     const int np = (int)min(64u, qe - q0);
-    int g = 1;
-    while (g * 2 * np <= 64) g *= 2;
+    int g = 1, lg = 0;  // g = 1 << lg
+    while (g * 2 * np <= 64) { g *= 2; lg++; }
     const int qi = lane / g, sl = lane % g;
     const unsigned q = q0 + qi;
     const bool live = qi < np;
@@ -68,9 +68,29 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
     // ---- sweep 1: neighbour count and centroid (pca.h:151, pcl::PCA mean)
     int k = 0;
     double sx = 0, sy = 0, sz = 0;
+    // Resident block: the first sweep remembers WHICH candidates lie within the radius -- one bit per candidate a lane tests, the first
+    // 128 of them in four registers -- and the second sweep walks the set bits instead of testing all candidates again: ~15 % of the
+    // candidates are neighbours, but a wave executes the f64 block of an iteration whenever ANY of its lanes hits, i.e. nearly always.
+    // A lane meets its neighbours in the same ascending order either way, so the sums are the same bits.
+    unsigned hm0 = 0u, hm1 = 0u, hm2 = 0u, hm3 = 0u;
+#define GH_PCA_SWEEP1(HM, W)                                                           \
+    for (int j = 0; j < 32; j++) {                                                     \
+      const int t = sl + ((((W) * 32 + j)) << lg);                                     \
+      if (t >= (int)total) break;                                                      \
+      const float4 Cc = sC[t];                                                         \
+      const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;                   \
+      float d2 = dx * dx;                                                              \
+      d2 += dy * dy;                                                                   \
+      d2 += dz * dz;                                                                   \
+      if (d2 < r2) { k++; sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z; HM |= 1u << j; } \
+    }
     if (resident) {
-      if (live)
-        for (int t = sl; t < (int)total; t += g) {
+      if (live) {
+        GH_PCA_SWEEP1(hm0, 0)
+        GH_PCA_SWEEP1(hm1, 1)
+        GH_PCA_SWEEP1(hm2, 2)
+        GH_PCA_SWEEP1(hm3, 3)
+        for (int t = sl + (128 << lg); t < (int)total; t += g) {
           const float4 Cc = sC[t];
           const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
           float d2 = dx * dx;
@@ -78,6 +98,8 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
           d2 += dz * dz;
           if (d2 < r2) { k++; sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z; }
         }
+      }
+#undef GH_PCA_SWEEP1
     } else
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
       for (unsigned base = rb; base < re; base += CHUNK) {
@@ -101,9 +123,21 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
     const double mx = sx / (double)k, my = sy / (double)k, mz = sz / (double)k;
     // ---- sweep 2: de-meaned scatter
     double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+#define GH_PCA_SWEEP2(HM, W)                                                           \
+    for (unsigned m = HM; m; m &= m - 1u) {                                            \
+      const int t = sl + (((W) * 32 + (__ffs((int)m) - 1)) << lg);                     \
+      const float4 Cc = sC[t];                                                         \
+      const double ex = (double)Cc.x - mx, ey = (double)Cc.y - my, ez = (double)Cc.z - mz; \
+      s00 += ex * ex; s01 += ex * ey; s02 += ex * ez;                                  \
+      s11 += ey * ey; s12 += ey * ez; s22 += ez * ez;                                  \
+    }
     if (resident) {
-      if (live && k >= 3)
-        for (int t = sl; t < (int)total; t += g) {
+      if (live && k >= 3) {
+        GH_PCA_SWEEP2(hm0, 0)
+        GH_PCA_SWEEP2(hm1, 1)
+        GH_PCA_SWEEP2(hm2, 2)
+        GH_PCA_SWEEP2(hm3, 3)
+        for (int t = sl + (128 << lg); t < (int)total; t += g) {
           const float4 Cc = sC[t];
           const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
           float d2 = dx * dx;
@@ -115,6 +149,8 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
             s11 += ey * ey; s12 += ey * ez; s22 += ez * ez;
           }
         }
+      }
+#undef GH_PCA_SWEEP2
     } else
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
       for (unsigned base = rb; base < re; base += CHUNK) {

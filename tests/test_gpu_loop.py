@@ -308,3 +308,24 @@ def test_pair_loop_persistent_batch(ctx, api, synth, oracle):
     for a, b in zip(alone, got):
         assert (a.iterations, a.converged) == (b.iterations, b.converged)
         np.testing.assert_array_equal(np.array(a.Rt[:]), np.array(b.Rt[:]))
+
+
+def test_cost_hints_change_the_queue_order_not_the_results(ctx, api, synth, oracle):
+    """ghicp_ctx_set_loop_cost_hints: the persistent pair loop takes the costliest pairs of a class first; the pairs share nothing, so
+    every pair's iterations and 4x4 are the same bits with, without and with adversarial hints, and a hint for another batch size is ignored."""
+    if not hasattr(ctx, "set_loop_cost_hints"):
+        pytest.skip("context without the hint entry")
+    scenes = [synth.tls_pair(60_000, pair_id=i) for i in range(3)]
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, 6, 0.6, 0.1, 0.5, 1.5, synth.bsc_pattern_glibc(), max_iter=60)
+    hs = []
+    for p in scenes * 2:
+        hs.append((ctx.cloud_create(cfg, p.source), ctx.cloud_create(cfg, p.target)))
+    base = ctx.register_clouds(cfg, hs)
+    for hints in ([float(st.iterations) for st in base], [-float(st.iterations) for st in base], [float("nan")] * len(hs), [1.0] * (len(hs) + 1)):
+        ctx.set_loop_cost_hints(hints)
+        again = ctx.register_clouds(cfg, hs)
+        for a, b in zip(base, again):
+            assert a.iterations == b.iterations and a.converged == b.converged and list(a.Rt) == list(b.Rt)
+    for a, b in hs:
+        a.close()
+        b.close()
