@@ -3,10 +3,12 @@
 #pragma once
 #include "grid.h"
 #include "devmath.h"
+#include "bsc_exp_table.h"
 
 struct BscConst {
   float R, r2s, u, den, r2c, area;
   double radius_w;
+  double dscale, dinv;  // 2^(54 - e), e = binary exponent of R / 2, and its inverse: the fixed-point scale of the exact depth sums (below)
   float centre[7];
   int pattern[98];
   int K, nvar;
@@ -22,6 +24,41 @@ constexpr int BSC_CAP = 2048;
 
 int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_host, BscConst* out, float* r_search);  // bsc.hip
 
+// Numerics contract N4: the Gaussian cell weight expf(-dd / den) of bfe:239 is evaluated as exp(-j / 32) * exp(s), x = -j / 32 + s
+// with j = the nearest grid point (so |s| <= 1 / 64 and the split is EXACT: x is a float, j / 32 has few bits), the first factor from a table
+// of correctly rounded doubles, the second a degree-6 Taylor polynomial in Horner form (truncation 4.5e-17), from * and + only, rounded once
+// to f32.  The CPU restatement the parity tests check against evaluates the same expression, so both sides hold the same bits; against a
+// correctly rounded expf it differs on < 1e-7 of the arguments by one ulp.  x in [-4.5, 0] (dd < (1.5 u)^2, den = u^2 / 2).
+static __device__ const double gh_bsc_exp_tab[145] = {GH_BSC_EXP_TABLE};
+__device__ inline float gh_bsc_expf(float xf, const double* __restrict__ tab) {
+  const double x = (double)xf;
+  int j = (int)(x * -32.0 + 0.5);
+  j = j < 0 ? 0 : (j > 144 ? 144 : j);
+  const double s = x + (double)j * 0.03125;
+  double p = s * (1.0 / 720.0) + (1.0 / 120.0);
+  p = s * p + (1.0 / 24.0);
+  p = s * p + (1.0 / 6.0);
+  p = s * p + 0.5;
+  p = s * p + 1.0;
+  p = s * p + 1.0;
+  return (float)(tab[j] * p);
+}
+
+// The depth sum of a cell, sum(depth * weight) (bfe:247), EXACTLY: depth = fl(loc + R) is a multiple of ulp(R / 2), a weight lies in
+// (2^-7, 1] and is a multiple of 2^-30, so every product is an integer multiple of 1 / dscale below 2^57; it is split into a high part and
+// 27 low bits, both are accumulated as integers (any order, no rounding), and the sum is rounded to f64 ONCE.  The order of the LDS atomics
+// therefore does not reach the result (round 3 summed f64 in arrival order and the GPU test tolerated one bit on 0.5 % of the keypoints).
+__device__ inline void gh_bsc_depth_add(unsigned long long* __restrict__ dhi, unsigned long long* __restrict__ dlo, float depth, float ew, double dscale) {
+  const double p = ((double)depth * (double)ew) * dscale;  // exact integer, |p| < 2^57, <= 48 significant bits
+  const double hi = floor(p * (1.0 / 134217728.0));
+  const double lo = p - hi * 134217728.0;                   // in [0, 2^27)
+  atomicAdd(dhi, (unsigned long long)(long long)hi);
+  atomicAdd(dlo, (unsigned long long)lo);
+}
+__device__ inline double gh_bsc_depth_sum(unsigned long long hi, unsigned long long lo, double dinv) {
+  return ((double)(long long)hi * 134217728.0 + (double)lo) * dinv;
+}
+
 __device__ inline int rearr_src(int type, int k) {  // bfe:700-739
   switch (type) {
     case 1: return 48 - k;
@@ -33,7 +70,8 @@ __device__ inline int rearr_src(int type, int k) {  // bfe:700-739
 __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int kk, int K, uint8_t* __restrict__ feat, float* __restrict__ lcs) {
 
   __shared__ double red[16];
-  __shared__ double s_pnum[147], s_dsum[147];
+  __shared__ double s_pnum[147], s_exp[145];
+  __shared__ unsigned long long s_dhi[147], s_dlo[147];
   __shared__ float s_weight[147], s_depth[147];
   __shared__ float s_axes[9];
   __shared__ double s_stat[3][4];  // per plane: avg_d, sd_d, avg_w, sd_w
@@ -156,7 +194,8 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
     float* o = &lcs[(size_t)kk * 12];
     for (int d = 0; d < 3; d++) { o[d] = X[d]; o[3 + d] = Y[d]; o[6 + d] = Z[d]; }
   }
-  for (int i = tid; i < 147; i += BT) { s_pnum[i] = 0.0; s_dsum[i] = 0.0; }
+  for (int i = tid; i < 147; i += BT) { s_pnum[i] = 0.0; s_dhi[i] = 0ull; s_dlo[i] = 0ull; }
+  for (int i = tid; i < 145; i += BT) s_exp[i] = gh_bsc_exp_tab[i];
   if (tid < 64) s_bits[tid >> 4][tid & 15] = 0u;
   __syncthreads();
   const float X0 = s_axes[0], X1 = s_axes[1], X2 = s_axes[2], Y0 = s_axes[3], Y1 = s_axes[4], Y2 = s_axes[5], Z0 = s_axes[6], Z1 = s_axes[7],
@@ -179,9 +218,9 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
           float dd = dx * dx;
           dd += dy2;
           if (dd < C.r2c) {
-            const float ew = (float)exp((double)(-dd / C.den));  // expf, correctly rounded (bfe:239)
-            atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);
-            atomicAdd(&s_dsum[i + 7 * j + 49 * pl], (double)depth * (double)ew);
+            const float ew = gh_bsc_expf(-dd / C.den, s_exp);  // expf (bfe:239), contract N4
+            atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);  // exact in f64 in any order: multiples of 2^-30 below 2^16
+            gh_bsc_depth_add(&s_dhi[i + 7 * j + 49 * pl], &s_dlo[i + 7 * j + 49 * pl], depth, ew, C.dscale);
           }
         }
       }
@@ -218,9 +257,9 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
           float dd = dx * dx;
           dd += dy2;
           if (dy2 < C.r2c && dd < C.r2c) {
-            const float ew = (float)exp((double)(-dd / C.den));  // expf, correctly rounded (bfe:239)
-            atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);
-            atomicAdd(&s_dsum[i + 7 * j + 49 * pl], (double)depth * (double)ew);
+            const float ew = gh_bsc_expf(-dd / C.den, s_exp);  // expf (bfe:239), contract N4
+            atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);  // exact in f64 in any order: multiples of 2^-30 below 2^16
+            gh_bsc_depth_add(&s_dhi[i + 7 * j + 49 * pl], &s_dlo[i + 7 * j + 49 * pl], depth, ew, C.dscale);
           }
         }
       }
@@ -243,7 +282,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   // ---- cell quantities (bfe:333-372)
   if (tid < 147) {
     const float ndens = (float)mm / C.area;
-    float avg = (float)s_dsum[tid];
+    float avg = (float)gh_bsc_depth_sum(s_dhi[tid], s_dlo[tid], C.dinv);
     avg = (s_pnum[tid] == 0.0) ? 0.0f : (float)((double)avg / s_pnum[tid]);
     const float garea = C.u * C.u;
     const float gdens = (float)(s_pnum[tid] / (double)garea);

@@ -149,8 +149,10 @@ struct ghicp_ctx {
   // persistent pair loop: one launch per LDS-occupancy class, concurrently, on these streams (forked from / joined into `stream`)
   // diagnostics, read from the environment ONCE when the context is created (never on a launch path): GHICP_KM_STATS=1 runs the
   // profiled Kuhn-Munkres kernel and prints its stage counters; GHICP_KM_FORCE_HAZARD=1 is the test hook that sends one phase of
-  // every solve through the literal fallback of rule R4
+  // every solve through the literal fallback of rule R4; GHICP_LOOP_SLOTS=<n> is the test hook that caps the workgroups (solve slots) of
+  // every class launch of the persistent pair loop, so that a few slots take MANY pairs one after the other (state carried over in LDS)
   bool km_stats = false, km_force_hazard = false;
+  int loop_slots_cap = 0;
   std::vector<uint32_t> cu_mask;       // set by ghicp_ctx_set_cu_mask: the auxiliary streams are restricted to the same compute units
   std::vector<hipStream_t> aux_streams;
   std::vector<hipEvent_t> aux_events;  // [0] fork, [1 + c] join of class c

@@ -39,6 +39,7 @@ extern "C" int ghicp_ctx_create(int device, ghicp_ctx** out) {
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->km_stats = getenv("GHICP_KM_STATS") != nullptr;
   c->km_force_hazard = getenv("GHICP_KM_FORCE_HAZARD") != nullptr;
+  if (const char* e = getenv("GHICP_LOOP_SLOTS")) c->loop_slots_cap = atoi(e) > 0 ? atoi(e) : 0;
   if (hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) { delete c; return GHICP_ERR_HIP; }
   c->pinned_cap = 4096;
   *out = c;

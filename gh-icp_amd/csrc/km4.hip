@@ -78,7 +78,8 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const 
     while (j < nprob && key[order[j]].first == key[order[i]].first) j++;
     if (nc == 8) { plan->count[7] += nprob - i; break; }  // cannot happen: at most 8 occupancy classes
     plan->begin[nc] = i; plan->count[nc] = j - i;
-    const int nmax = key[order[i]].second;
+    int nmax = 1;  // (with cost hints the first problem of a class is its costliest, not its largest)
+    for (int t = i; t < j; t++) nmax = std::max(nmax, key[order[t]].second);
     plan->lds[nc] = gh_km4_lds_bytes(nmax);
     nc++;
     i = j;

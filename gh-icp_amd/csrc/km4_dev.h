@@ -628,7 +628,11 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
   s.tlc = s.sty + n + 2;
   s.tlo = s.tlc + (size_t)n * K4_CAP;
   s.tln = (unsigned char*)(s.tlo + (size_t)n * K4_CAP);
-  (void)lds_bytes;
+  if ((long long)(reinterpret_cast<char*>(s.tln + n) - smem) > (long long)lds_bytes) {  // the launch gave this workgroup less LDS than the
+    if (tid == 0 && P.status) *P.status = 6;                                            // problem needs: refuse loudly, touch nothing
+    for (int i = tid; i < n; i += K4_T) P.match_out[i] = -1;
+    return;
+  }
   const double bg = s.bg, eps = s.eps;
   // (the flood and the DFS are one wave's work; letting co-resident workgroups use different waves for it -- block id >> 8 & 3 -- was
   // measured in round 3: 49.04 against 49.08 ms per solve at four problems per CU, no effect, removed)

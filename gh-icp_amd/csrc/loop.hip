@@ -724,7 +724,8 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     GH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K4_T, lds));
     if (per_cu <= 0) return ctx->fail(GHICP_ERR_INTERNAL, "pair loop: a workgroup with %zu bytes of LDS does not fit a CU", lds);
     const int slots = per_cu * ctx->num_cu;
-    const int grid = std::min(plan.count[c], slots);
+    int grid = std::min(plan.count[c], slots);
+    if (ctx->loop_slots_cap > 0) grid = std::min(grid, ctx->loop_slots_cap);  // test hook (GHICP_LOOP_SLOTS)
     batch_slots = std::max(batch_slots, slots);
     batch_grid += grid;
     if (prof)

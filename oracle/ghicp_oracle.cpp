@@ -34,6 +34,27 @@
 
 namespace orc {
 
+// N4 of the numerics contract: expf(x) of the BSC Gaussian cell weight (bfe:239), x in [-4.5, 0]: x = -j / 32 + s with j the nearest grid
+// point (the split is exact), exp(-j / 32) from a table of correctly rounded doubles, exp(s) by its degree-6 Taylor polynomial in Horner
+// form, * and + only, one rounding to f32.  Transcription of gh_bsc_expf (gh-icp_amd/csrc/bsc_dev.h); the table is generated for both
+// sides by scripts/gen_bsc_exp_table.py.
+#include "bsc_exp_table.inc"
+static const double kBscExpTab[145] = {ORC_BSC_EXP_TABLE};
+static float contract_bsc_expf(float xf) {
+  const double x = (double)xf;
+  int j = (int)(x * -32.0 + 0.5);
+  j = j < 0 ? 0 : (j > 144 ? 144 : j);
+  const double s = x + (double)j * 0.03125;
+  double p = s * (1.0 / 720.0) + (1.0 / 120.0);
+  p = s * p + (1.0 / 24.0);
+  p = s * p + (1.0 / 6.0);
+  p = s * p + 0.5;
+  p = s * p + 1.0;
+  p = s * p + 1.0;
+  return (float)(kBscExpTab[j] * p);
+}
+
+
 // ------------------------------------------------------------------ small linear algebra
 // Cyclic Jacobi for a symmetric 3x3 (f64).  Sweep order (0,1),(0,2),(1,2), 8 sweeps, a pivot
 // that is exactly zero is skipped.  V columns are the eigenvectors.  Stands in for
@@ -501,8 +522,15 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
       loc[(size_t)n * 3 + 2] = (Z[0] * d0 + Z[1] * d1) + Z[2] * d2;
     }
     // ---- a7: 3 x (7x7) Gaussian-weighted projection grids (bfe:196-373)
-    double pnum[147], dsum[147];
-    for (int i = 0; i < 147; i++) pnum[i] = dsum[i] = 0;
+    // N4: the Gaussian weight through the contract's own expf (contract_bsc_expf); the depth sums EXACTLY (every product depth * weight
+    // is an integer multiple of 2^(e - 54), e = binary exponent of R / 2: accumulated as integers in two parts, rounded to f64 once), so
+    // that the order in which a parallel implementation adds the points does not reach the result
+    double pnum[147];
+    long long dhi[147], dlo[147];
+    for (int i = 0; i < 147; i++) { pnum[i] = 0; dhi[i] = dlo[i] = 0; }
+    int rex = 0;
+    (void)std::frexp((double)R * 0.5, &rex);
+    const double dscale = std::ldexp(1.0, 54 - rex), dinv = std::ldexp(1.0, rex - 54);
     static const int PA[3] = {0, 0, 1}, PB[3] = {1, 2, 2}, PD[3] = {2, 1, 0};
     for (int pl = 0; pl < 3; pl++)
       for (int n = 0; n < mm; n++) {
@@ -515,13 +543,18 @@ static void bsc_encode(const float* xyz, int m, int stride, const int* kp, int K
             float d2 = dx * dx;
             d2 += dy * dy;
             if (d2 < r2c) {
-              const float e = (float)std::exp((double)(-d2 / den));  // expf, correctly rounded
-              pnum[i + 7 * j + 49 * pl] += (double)e;
-              dsum[i + 7 * j + 49 * pl] += (double)depth * (double)e;
+              const float e = contract_bsc_expf(-d2 / den);
+              pnum[i + 7 * j + 49 * pl] += (double)e;  // exact in any order (multiples of 2^-30 below 2^16)
+              const double p = ((double)depth * (double)e) * dscale;
+              const double hi = std::floor(p * (1.0 / 134217728.0));
+              dhi[i + 7 * j + 49 * pl] += (long long)hi;
+              dlo[i + 7 * j + 49 * pl] += (long long)(p - hi * 134217728.0);
             }
           }
         }
       }
+    double dsum[147];
+    for (int i = 0; i < 147; i++) dsum[i] = ((double)dhi[i] * 134217728.0 + (double)dlo[i]) * dinv;
     const float area = (float)(M_PI * (double)R * (double)R);  // bfe:337
     const float ndens = (float)mm / area;                        // bfe:338
     float weight[294], depth[294];

@@ -41,7 +41,7 @@ def default_params(feature=NONE, corr=NN, dof=6, est_iou=0.6, radius_nonmax=1.5,
 def build(force: bool = False) -> None:
     so = os.path.join(_HERE, "libghicp_oracle.so")
     src = os.path.join(_HERE, "ghicp_oracle.cpp")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ghicp_oracle.cpp", "icp_oracle.inc", "km_model.inc", "km4_model.inc")):
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ghicp_oracle.cpp", "icp_oracle.inc", "km_model.inc", "km4_model.inc", "bsc_exp_table.inc")):
         subprocess.check_call(["make", "-C", _HERE, "libghicp_oracle.so"], stdout=subprocess.DEVNULL)
     ref = os.path.join(_HERE, "_ref", "libkm_ref.so")
     if os.path.exists("/root/reference/src/km.cpp") and (force or not os.path.exists(ref)):
@@ -383,7 +383,7 @@ def build_native() -> str:
     out_dir = os.path.join(_HERE, "_native")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libghicp_oracle_native.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ghicp_oracle.cpp", "icp_oracle.inc", "km_model.inc", "km4_model.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("ghicp_oracle.cpp", "icp_oracle.inc", "km_model.inc", "km4_model.inc", "bsc_exp_table.inc")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-shared",
                                "-o", so, srcs[0]])

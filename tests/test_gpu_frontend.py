@@ -100,10 +100,10 @@ def test_bsc_encode(ctx, oracle, synth, ds_target, dof, pattern):
     fg, lg = ctx.bsc_encode(ds_target, kp, 1.5, dof, pat)
     fg, lg = fg.cpu().numpy(), lg.cpu().numpy()
     np.testing.assert_array_equal(lg, lo)  # LCS axes: f32 bit-exact
-    ham = np.unpackbits(fg ^ fo, axis=-1).sum(-1)  # (4, K)
-    # 441-bit strings: bit-exact (tolerate <= 1 flipped bit on <= 0.5% of keypoints: thresholds on f32 values
-    # whose f64 sums were formed in a different order)
-    assert ham.max() <= 1 and (ham > 0).sum() <= max(1, kp.size // 200), (ham.max(), (ham > 0).sum())
+    # 441-bit strings: bit-exact.  (Round 3 tolerated one bit on 0.5 % of the keypoints: the cells' depth sums were f64 atomics in arrival
+    # order and the Gaussian weight went through two different libm exp.  Now the weight is the contract's own expf on both sides (N4) and the
+    # depth sums are exact integer accumulations, so no order and no library reaches the strings.)
+    np.testing.assert_array_equal(fg, fo)
     nvar = 4 if dof > 4 else (2 if dof > 0 else 1)
     assert not fg[nvar:].any()
     if pattern == "zero":  # Q2: with the shipped (0,0) pattern every compare bit is 0

@@ -329,3 +329,47 @@ def test_cost_hints_change_the_queue_order_not_the_results(ctx, api, synth, orac
     for a, b in hs:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("order", ["ascending", "descending", "shuffled"])
+def test_one_slot_takes_many_pairs_in_any_order(api, synth, oracle, order):
+    """A solve slot of the persistent pair loop keeps its LDS between pairs, and a class launch gets the LDS of the LARGEST graph of its
+    class.  With ONE slot per class (GHICP_LOOP_SLOTS=1, the library's test hook) and the queue order forced by cost hints -- small graphs
+    before large ones, large before small, mixed; all seven graphs in one LDS class, all beyond the stage-scratch floor of the launch --
+    every pair must come out exactly as when it runs alone.  (Round 4: the first version of the hinted order sized a class's LDS by its
+    FIRST problem; the solver now also refuses a problem that does not fit the LDS it was given, status 6.)"""
+    import os
+
+    os.environ["GHICP_LOOP_SLOTS"] = "1"
+    try:
+        c = _fresh_context(api)
+    finally:
+        del os.environ["GHICP_LOOP_SLOTS"]
+    ref = _fresh_context(api)
+    rng = np.random.default_rng(33)
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, dof=6, est_iou=0.6, voxel=0.2, pattern=synth.bsc_pattern_glibc(), max_iter=10)
+    p = synth.gauss_pair(n_kp=600)
+    bbx = float(oracle.bbx_magnitude(p.source))
+    shapes = [(300, 280), (330, 300), (360, 360), (400, 390), (440, 430), (310, 320), (420, 400)]
+    feats = []
+    for ks, kt in shapes:
+        fS = rng.integers(0, 256, size=(4, ks, 56), dtype=np.uint8)
+        fT = rng.integers(0, 256, size=(4, kt, 56), dtype=np.uint8)
+        m = min(ks, kt)
+        fT[0, :m] = fS[0, :m] ^ (rng.random((m, 56)) < 0.03).astype(np.uint8)
+        feats.append((p.source[p.kp_source[:ks]].astype(np.float64), p.target[p.kp_target[:kt]].astype(np.float64), fS, fT))
+    mk = lambda cx: [(cx.cloud_from_features(cfg, kS, fS, bbx), cx.cloud_from_features(cfg, kT, fT, bbx)) for kS, kT, fS, fT in feats]  # noqa: E731
+    hs, hr = mk(c), mk(ref)
+    alone = [ref.register_clouds(cfg, [h])[0] for h in hr]  # every pair alone, on a context without the cap
+    n_of = [max(ks, kt) for ks, kt in shapes]
+    cost = {"ascending": [-float(n) for n in n_of], "descending": [float(n) for n in n_of], "shuffled": list(rng.permutation(len(hs)).astype(float))}[order]
+    for rep in range(2):  # the second batch starts on the LDS the first one left behind
+        c.set_loop_cost_hints(cost)
+        got = c.register_clouds(cfg, hs)
+        for a, b in zip(alone, got):
+            assert a.iterations == b.iterations and a.converged == b.converged and list(a.Rt) == list(b.Rt), (order, rep)
+    for a, b in hs + hr:
+        a.close()
+        b.close()
+    c.close()
+    ref.close()
