@@ -406,10 +406,16 @@ def main():
                 c = fe_ctxs[w]
                 for k in range(K):
                     buf = pool_h[k % NBUF]
-                    mine_w = list(range(w, nb, fe_n))
                     per = max(1, args.fe_batch // 2) if args.fe_batch > 1 else 1   # pairs per front-end launch sequence
-                    for c0 in range(0, len(mine_w), per):
-                        chunk = mine_w[c0:c0 + per]
+                    if args.pipeline == 1:
+                        # group-major: the workers finish group 0's clouds first, then group 1's, ... so that a group's loop starts while the
+                        # front ends of the later groups are still running (with the interleaved order every group is ready at the same moment)
+                        allc = [list(range(c0, min(c0 + per, bounds[gg + 1]))) for gg in range(G) for c0 in range(bounds[gg], bounds[gg + 1], per)]
+                        my_chunks = allc[w::fe_n]
+                    else:
+                        mine_w = list(range(w, nb, fe_n))
+                        my_chunks = [mine_w[c0:c0 + per] for c0 in range(0, len(mine_w), per)]
+                    for chunk in my_chunks:
                         for i in chunk:
                             g = int(group_of[i])
                             if not args.pipeline and k >= 1:  # strict schedule: the front ends of a step start when the previous step is complete
