@@ -249,19 +249,32 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
         const float4 L = s_pts[t];
         const float a = pl == 2 ? L.y : L.x, bb = pl == 0 ? L.y : L.z;
         const float depth = (pl == 0 ? L.z : (pl == 1 ? L.y : L.x)) + C.R;
-        const int i = (int)floorf((a + C.R) * inv_u) + di, j = (int)floorf((bb + C.R) * inv_u) + dj;
-        if (i >= 0 && i < 7 && j >= 0 && j < 7) {
-          const float dy = bb - C.centre[j];
+        const int bi = (int)floorf((a + C.R) * inv_u), bj = (int)floorf((bb + C.R) * inv_u);
+        auto cell = [&](int ci, int cj) {  // the reference's own test for one cell (bfe:229-247)
+          if (ci < 0 || ci >= 7 || cj < 0 || cj >= 7) return;
+          const float dy = bb - C.centre[cj];
           const float dy2 = dy * dy;
-          const float dx = a - C.centre[i];
+          const float dx = a - C.centre[ci];
           float dd = dx * dx;
           dd += dy2;
           if (dy2 < C.r2c && dd < C.r2c) {
             const float ew = gh_bsc_expf(-dd / C.den, s_exp);  // expf (bfe:239), contract N4
-            atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);  // exact in f64 in any order: multiples of 2^-30 below 2^16
-            gh_bsc_depth_add(&s_dhi[i + 7 * j + 49 * pl], &s_dlo[i + 7 * j + 49 * pl], depth, ew, C.dscale);
+            atomicAdd(&s_pnum[ci + 7 * cj + 49 * pl], (double)ew);  // exact in f64 in any order: multiples of 2^-30 below 2^16
+            gh_bsc_depth_add(&s_dhi[ci + 7 * cj + 49 * pl], &s_dlo[ci + 7 * cj + 49 * pl], depth, ew, C.dscale);
           }
-        }
+        };
+        cell(bi + di, bj + dj);
+        // The ring two cells from the base cell.  In exact arithmetic a point reaches three cells per axis; a point within an ulp of a
+        // cell edge can pass the f32 test of a FOURTH (distance 1.5 u, weight e^-4.5), and the reciprocal multiply above can put the base
+        // cell one off -- the reference's 7 x 7 scan finds those cells, so the window is completed here: the lanes with an offset test
+        // the cell beyond theirs (one subtraction and compare each, true a few times per cloud).  (Round-3 advisor finding.)
+        bool fx = false, fy = false;
+        const int i2 = bi + 2 * di, j2 = bj + 2 * dj;
+        if (di != 0 && i2 >= 0 && i2 < 7) { const float dx = a - C.centre[i2]; fx = dx * dx < C.r2c; }
+        if (dj != 0 && j2 >= 0 && j2 < 7) { const float dy = bb - C.centre[j2]; fy = dy * dy < C.r2c; }
+        if (fx) cell(i2, bj + dj);
+        if (fy) cell(bi + di, j2);
+        if (fx && fy) cell(i2, j2);
       }
     }
   } else {
