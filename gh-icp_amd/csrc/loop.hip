@@ -560,7 +560,10 @@ __global__ void k_collect_done(const LoopProb* __restrict__ probs, int n, int* _
 // and no other pair stands between two iterations of a pair, so a slot is never idle while its queue holds work: converged pairs
 // free their slot at once and the next pair is admitted at once (continuous batching at pair granularity; per pair the order of
 // ghicp_reg.cpp:49-103 is kept).  The stages are the SAME device functions the stand-alone kernels run, called for every block
-// coordinate in turn: identical partial sums, identical results.  Stage scratch (13 KB) overlays the solver's LDS.
+// coordinate in turn.  (The sweep's column chunks are sized per path -- one workgroup sweeps a pair here, many workgroups a batch in the
+// per-stage path -- so the f64 sums CDmean / CDstd may differ in the last bits between the two paths: N6 of DESIGN.md §2; everything
+// that is compared bit for bit -- matches, solver, rigid solve -- is the same code on the same values.)  Stage scratch (13 KB) overlays
+// the solver's LDS.
 constexpr int PL_SCRATCH = (CHUNK_MAX * 3 + 16 + 32) * 8 + 20 * 4;
 
 // The stages as out-of-line calls: the persistent kernel's register budget is then the LARGEST stage's, not what the register
@@ -677,6 +680,18 @@ struct Carver {
 // first), all classes concurrently -- class 0 on the context's stream, the others on auxiliary streams forked from and joined into
 // it -- each with its own queue head.  A launch has at most (slots per CU x CUs) workgroups; every workgroup pops pairs until its
 // queue is empty.  Returns when every pair of the batch has converged (or hit max_iter).
+// (Error path, round-3 advisor: class launches that are already running write the batch's states; whoever returns early waits for
+// every stream first -- gh_join_aux -- so that the caller may reuse the context's buffers.  Auxiliary streams inherit the context's CU
+// mask (ghicp_ctx_set_cu_mask); a masked stream handed in through ghicp_ctx_set_stream is not inspected: documented in ghicp_c.h.)
+static void gh_join_aux(ghicp_ctx* ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  for (hipStream_t a : ctx->aux_streams) (void)hipStreamSynchronize(a);
+}
+#define GH_HIP_JOIN(call)                                                                                     \
+  do {                                                                                                        \
+    const hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) { gh_join_aux(ctx); return ctx->fail(GHICP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } \
+  } while (0)
 template <int FT>
 int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan& plan, int* dqheads) {
   hipStream_t s = ctx->stream;
@@ -714,14 +729,15 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     lstat += ctx->km_launches * ghicp_ctx::KM_LSTAT_W;
   }
   hipEvent_t kt = ctx->kt_begin(KT_PAIR_LOOP);
-  GH_HIP(hipEventRecord(ctx->aux_events[0], s));
+  GH_HIP_JOIN(hipEventRecord(ctx->aux_events[0], s));
   for (int c = 0; c < nc; c++) {
     if (plan.count[c] <= 0) continue;
     hipStream_t sc = c == 0 ? s : ctx->aux_streams[(size_t)c - 1];
-    if (c > 0) GH_HIP(hipStreamWaitEvent(sc, ctx->aux_events[0], 0));
+    if (c > 0) GH_HIP_JOIN(hipStreamWaitEvent(sc, ctx->aux_events[0], 0));
     const size_t lds = std::max(plan.lds[c], (size_t)PL_SCRATCH + 64);
     int per_cu = 0;
-    GH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K4_T, lds));
+    GH_HIP_JOIN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K4_T, lds));
+    if (per_cu <= 0) gh_join_aux(ctx);
     if (per_cu <= 0) return ctx->fail(GHICP_ERR_INTERNAL, "pair loop: a workgroup with %zu bytes of LDS does not fit a CU", lds);
     const int slots = per_cu * ctx->num_cu;
     int grid = std::min(plan.count[c], slots);
@@ -734,10 +750,10 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     else
       hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
                          dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
-    GH_HIP(hipGetLastError());
+    GH_HIP_JOIN(hipGetLastError());
     if (c > 0) {
-      GH_HIP(hipEventRecord(ctx->aux_events[(size_t)c + 1], sc));
-      GH_HIP(hipStreamWaitEvent(s, ctx->aux_events[(size_t)c + 1], 0));
+      GH_HIP_JOIN(hipEventRecord(ctx->aux_events[(size_t)c + 1], sc));
+      GH_HIP_JOIN(hipStreamWaitEvent(s, ctx->aux_events[(size_t)c + 1], 0));
     }
   }
   ctx->kt_end(KT_PAIR_LOOP, kt);
@@ -745,9 +761,10 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     ctx->km_slots.push_back(std::min(batch_slots, batch_grid));
     ctx->km_launches++;
   }
-  GH_HIP(hipStreamSynchronize(s));
+  GH_HIP_JOIN(hipStreamSynchronize(s));
   return GHICP_OK;
 }
+#undef GH_HIP_JOIN
 
 template <int FT>
 int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {

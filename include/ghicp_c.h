@@ -70,6 +70,9 @@ typedef struct ghicp_iter {
 /* ------------------------------------------------------------------ context */
 int ghicp_ctx_create(int device, ghicp_ctx** ctx);
 int ghicp_ctx_destroy(ghicp_ctx* ctx);
+/* The stream every call on this context is issued on.  The persistent pair loop of the Kuhn-Munkres batches forks onto auxiliary streams
+ * of its own (one per LDS class of a batch) and joins them back into this stream; those streams follow ghicp_ctx_set_cu_mask, NOT a
+ * compute-unit mask the caller may have put on a stream handed in here (the mask of a foreign stream is not inspected). */
 int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* hip_stream);
 /* Gives the context its own stream restricted to the compute units whose bit is set (32 CUs per word); replaces any stream
  * set before.  Lets a pipeline keep some CUs free of the LDS-filling solve waves for another context's small kernels. */

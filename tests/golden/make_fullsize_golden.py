@@ -20,17 +20,20 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (config table + generators)
 from oracle import oracle as O  # noqa: E402  (the checker)
 
-CASES = [(2, 0), (3, 0), (3, 1), (5, 1)]
+CASES = [(2, 0), (3, 0), (3, 1), (5, 1), (5, 8)]  # cfg5: pair 1 converges to a rejected pose (77 iterations), pair 8 registers (25)
 
 
 def main():
     synth = importlib.import_module("gh-icp_amd.synth")
     O.build()
     out_path = os.path.join(ROOT, "tests", "golden", "fullsize.json")
-    only = {int(a) for a in sys.argv[1:]}
-    rows = [c for c in json.load(open(out_path))["cases"] if c["config"] not in only] if only and os.path.exists(out_path) else []
+    # arguments: config ids (every case of those configs is recomputed) and / or "cfg:pair" (only that case); the other cases are kept
+    only = {int(a) for a in sys.argv[1:] if ":" not in a}
+    only_cases = {tuple(int(v) for v in a.split(":")) for a in sys.argv[1:] if ":" in a}
+    sel = lambda c, pid: (not only and not only_cases) or c in only or (c, pid) in only_cases  # noqa: E731
+    rows = [c for c in json.load(open(out_path))["cases"] if not sel(c["config"], c["pair_id"])] if (only or only_cases) and os.path.exists(out_path) else []
     for cfg_id, pair_id in CASES:
-        if only and cfg_id not in only:
+        if not sel(cfg_id, pair_id):
             continue
         CF = bench.CONFIGS[cfg_id]
         p = bench.make_pair(cfg_id, pair_id, CF["hits"])

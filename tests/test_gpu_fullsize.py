@@ -112,7 +112,7 @@ def test_full_size_4x4_against_the_oracle_fixture(ctx, api, synth, case):
 
 def test_fixture_covers_the_baseline_configs():
     got = {(c["config"], c["pair_id"]) for c in _golden_cases()}
-    assert {(2, 0), (3, 0), (3, 1), (5, 1)} <= got, got
+    assert {(2, 0), (3, 0), (3, 1), (5, 1), (5, 8)} <= got, got
 
 
 def test_cfg4_all_64_pairs_4x4_against_the_live_oracle(ctx, api, synth, oracle):
