@@ -46,8 +46,8 @@ int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_h
   C.radius_w = std::sqrt(2.0) * (double)R;              // bfe:951
   int ex = 0;
   (void)std::frexp((double)R * 0.5, &ex);               // R / 2 = m 2^ex, m in [0.5, 1): ulp_f32(R / 2) = 2^(ex - 24)
-  C.dscale = std::ldexp(1.0, 54 - ex);                  // depth multiples of 2^(ex - 24) x weight multiples of 2^-30 (bsc_dev.h)
-  C.dinv = std::ldexp(1.0, ex - 54);
+  C.dunit = std::ldexp(1.0, 24 - ex);                   // depth is a multiple of 2^(ex - 24) (bsc_dev.h: exact depth sums)
+  C.dinv = std::ldexp(1.0, ex - 54);                    // x weight multiples of 2^-30
   for (int i = 0; i < 7; i++) C.centre[i] = (float)((i + 0.5) * (double)C.u - (double)R);  // bfe:226-227
   for (int i = 0; i < 98; i++) {
     C.pattern[i] = pattern_host[i];

@@ -8,7 +8,7 @@
 struct BscConst {
   float R, r2s, u, den, r2c, area;
   double radius_w;
-  double dscale, dinv;  // 2^(54 - e), e = binary exponent of R / 2, and its inverse: the fixed-point scale of the exact depth sums (below)
+  double dunit, dinv;  // 2^(24 - e) (depth units per metre, e = binary exponent of R / 2) and 2^(e - 54) (metres per unit of depth x weight): the exact depth sums below
   float centre[7];
   int pattern[98];
   int K, nvar;
@@ -44,19 +44,26 @@ __device__ inline float gh_bsc_expf(float xf, const double* __restrict__ tab) {
   return (float)(tab[j] * p);
 }
 
-// The depth sum of a cell, sum(depth * weight) (bfe:247), EXACTLY: depth = fl(loc + R) is a multiple of ulp(R / 2), a weight lies in
-// (2^-7, 1] and is a multiple of 2^-30, so every product is an integer multiple of 1 / dscale below 2^57; it is split into a high part and
-// 27 low bits, both are accumulated as integers (any order, no rounding), and the sum is rounded to f64 ONCE.  The order of the LDS atomics
-// therefore does not reach the result (round 3 summed f64 in arrival order and the GPU test tolerated one bit on 0.5 % of the keypoints).
-__device__ inline void gh_bsc_depth_add(unsigned long long* __restrict__ dhi, unsigned long long* __restrict__ dlo, float depth, float ew, double dscale) {
-  const double p = ((double)depth * (double)ew) * dscale;  // exact integer, |p| < 2^57, <= 48 significant bits
-  const double hi = floor(p * (1.0 / 134217728.0));
-  const double lo = p - hi * 134217728.0;                   // in [0, 2^27)
-  atomicAdd(dhi, (unsigned long long)(long long)hi);
-  atomicAdd(dlo, (unsigned long long)lo);
+// The depth sum of a cell, sum(depth * weight) (bfe:247), EXACTLY: depth = fl(loc + R) is a multiple of ulp(R / 2) = 2^(e - 24) (e = binary
+// exponent of R / 2) below 2^27 of them, a weight lies in (2^-7, 1] and is a multiple of 2^-30, so with the depth shifted by 2^27 units every
+// product is a non-negative INTEGER below 2^58.  The products are added into a 64-bit LDS word that may wrap; the returning atomic tells
+// when it did, and only then (once in a few hundred terms) a carry word is bumped: two LDS atomics per weight as in round 3 (the cell's
+// weight sum and this), no rounding, no order.  The shift is taken out again through the weight sum (exact: multiples of 2^-30), and the
+// integer is rounded to f64 ONCE.  (Round 3 summed f64 in arrival order, and the GPU test tolerated one bit on 0.5 % of the keypoints.)
+__device__ inline void gh_bsc_depth_add(unsigned long long* __restrict__ lo64, unsigned* __restrict__ carry, float depth, float ew, double dunit) {
+  const unsigned d_off = (unsigned)((int)((double)depth * dunit) + (1 << 27));  // exact: depth is a multiple of 1 / dunit
+  const unsigned w_int = (unsigned)((double)ew * 1073741824.0);                 // exact: ew is a multiple of 2^-30, <= 1
+  const unsigned long long term = (unsigned long long)d_off * (unsigned long long)w_int;
+  const unsigned long long old = atomicAdd(lo64, term);
+  if (old + term < old) atomicAdd(carry, 1u);
 }
-__device__ inline double gh_bsc_depth_sum(unsigned long long hi, unsigned long long lo, double dinv) {
-  return ((double)(long long)hi * 134217728.0 + (double)lo) * dinv;
+__device__ inline double gh_bsc_depth_sum(unsigned long long lo64, unsigned carry, double pnum, double dinv) {
+  const unsigned __int128 acc = ((unsigned __int128)carry << 64) | (unsigned __int128)lo64;
+  const unsigned __int128 shift = (unsigned __int128)(unsigned long long)(pnum * 1073741824.0) << 27;  // 2^27 units x the integer weight sum
+  const bool neg = acc < shift;
+  const unsigned __int128 mag = neg ? shift - acc : acc - shift;  // < 2^70
+  const double d = (double)(unsigned long long)(mag >> 32) * 4294967296.0 + (double)(unsigned long long)(mag & 0xFFFFFFFFull);  // both exact: ONE rounding
+  return (neg ? -d : d) * dinv;
 }
 
 __device__ inline int rearr_src(int type, int k) {  // bfe:700-739
@@ -71,7 +78,8 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
 
   __shared__ double red[16];
   __shared__ double s_pnum[147], s_exp[145];
-  __shared__ unsigned long long s_dhi[147], s_dlo[147];
+  __shared__ unsigned long long s_dlo[147];
+  __shared__ unsigned s_dcarry[147];
   __shared__ float s_weight[147], s_depth[147];
   __shared__ float s_axes[9];
   __shared__ double s_stat[3][4];  // per plane: avg_d, sd_d, avg_w, sd_w
@@ -194,7 +202,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
     float* o = &lcs[(size_t)kk * 12];
     for (int d = 0; d < 3; d++) { o[d] = X[d]; o[3 + d] = Y[d]; o[6 + d] = Z[d]; }
   }
-  for (int i = tid; i < 147; i += BT) { s_pnum[i] = 0.0; s_dhi[i] = 0ull; s_dlo[i] = 0ull; }
+  for (int i = tid; i < 147; i += BT) { s_pnum[i] = 0.0; s_dlo[i] = 0ull; s_dcarry[i] = 0u; }
   for (int i = tid; i < 145; i += BT) s_exp[i] = gh_bsc_exp_tab[i];
   if (tid < 64) s_bits[tid >> 4][tid & 15] = 0u;
   __syncthreads();
@@ -220,7 +228,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
           if (dd < C.r2c) {
             const float ew = gh_bsc_expf(-dd / C.den, s_exp);  // expf (bfe:239), contract N4
             atomicAdd(&s_pnum[i + 7 * j + 49 * pl], (double)ew);  // exact in f64 in any order: multiples of 2^-30 below 2^16
-            gh_bsc_depth_add(&s_dhi[i + 7 * j + 49 * pl], &s_dlo[i + 7 * j + 49 * pl], depth, ew, C.dscale);
+            gh_bsc_depth_add(&s_dlo[i + 7 * j + 49 * pl], &s_dcarry[i + 7 * j + 49 * pl], depth, ew, C.dunit);
           }
         }
       }
@@ -249,7 +257,9 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
         const float4 L = s_pts[t];
         const float a = pl == 2 ? L.y : L.x, bb = pl == 0 ? L.y : L.z;
         const float depth = (pl == 0 ? L.z : (pl == 1 ? L.y : L.x)) + C.R;
-        const int bi = (int)floorf((a + C.R) * inv_u), bj = (int)floorf((bb + C.R) * inv_u);
+        const float ta = (a + C.R) * inv_u, tb = (bb + C.R) * inv_u;
+        const float fla = floorf(ta), flb = floorf(tb);
+        const int bi = (int)fla, bj = (int)flb;
         auto cell = [&](int ci, int cj) {  // the reference's own test for one cell (bfe:229-247)
           if (ci < 0 || ci >= 7 || cj < 0 || cj >= 7) return;
           const float dy = bb - C.centre[cj];
@@ -260,21 +270,25 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
           if (dy2 < C.r2c && dd < C.r2c) {
             const float ew = gh_bsc_expf(-dd / C.den, s_exp);  // expf (bfe:239), contract N4
             atomicAdd(&s_pnum[ci + 7 * cj + 49 * pl], (double)ew);  // exact in f64 in any order: multiples of 2^-30 below 2^16
-            gh_bsc_depth_add(&s_dhi[ci + 7 * cj + 49 * pl], &s_dlo[ci + 7 * cj + 49 * pl], depth, ew, C.dscale);
+            gh_bsc_depth_add(&s_dlo[ci + 7 * cj + 49 * pl], &s_dcarry[ci + 7 * cj + 49 * pl], depth, ew, C.dunit);
           }
         };
         cell(bi + di, bj + dj);
         // The ring two cells from the base cell.  In exact arithmetic a point reaches three cells per axis; a point within an ulp of a
         // cell edge can pass the f32 test of a FOURTH (distance 1.5 u, weight e^-4.5), and the reciprocal multiply above can put the base
-        // cell one off -- the reference's 7 x 7 scan finds those cells, so the window is completed here: the lanes with an offset test
-        // the cell beyond theirs (one subtraction and compare each, true a few times per cloud).  (Round-3 advisor finding.)
-        bool fx = false, fy = false;
-        const int i2 = bi + 2 * di, j2 = bj + 2 * dj;
-        if (di != 0 && i2 >= 0 && i2 < 7) { const float dx = a - C.centre[i2]; fx = dx * dx < C.r2c; }
-        if (dj != 0 && j2 >= 0 && j2 < 7) { const float dy = bb - C.centre[j2]; fy = dy * dy < C.r2c; }
-        if (fx) cell(i2, bj + dj);
-        if (fy) cell(bi + di, j2);
-        if (fx && fy) cell(i2, j2);
+        // cell one off -- the reference's 7 x 7 scan finds those cells, so the window is completed here.  Only a point whose fractional
+        // cell position is within 1e-4 of an edge can reach the ring (the error of ta / tb is ~1e-6), so one compare per axis keeps the
+        // ring tests out of all but ~1 % of the waves (measured: the unconditional ring cost 0.47 ms per 32 clouds, profiles/r04_bsc_variants.txt).
+        const float fa = ta - fla, fb = tb - flb;
+        if (fa < 1e-4f || fa > 0.9999f || fb < 1e-4f || fb > 0.9999f) {
+          bool fx = false, fy = false;
+          const int i2 = bi + 2 * di, j2 = bj + 2 * dj;
+          if (di != 0 && i2 >= 0 && i2 < 7) { const float dx = a - C.centre[i2]; fx = dx * dx < C.r2c; }
+          if (dj != 0 && j2 >= 0 && j2 < 7) { const float dy = bb - C.centre[j2]; fy = dy * dy < C.r2c; }
+          if (fx) cell(i2, bj + dj);
+          if (fy) cell(bi + di, j2);
+          if (fx && fy) cell(i2, j2);
+        }
       }
     }
   } else {
@@ -295,7 +309,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   // ---- cell quantities (bfe:333-372)
   if (tid < 147) {
     const float ndens = (float)mm / C.area;
-    float avg = (float)gh_bsc_depth_sum(s_dhi[tid], s_dlo[tid], C.dinv);
+    float avg = (float)gh_bsc_depth_sum(s_dlo[tid], s_dcarry[tid], s_pnum[tid], C.dinv);
     avg = (s_pnum[tid] == 0.0) ? 0.0f : (float)((double)avg / s_pnum[tid]);
     const float garea = C.u * C.u;
     const float gdens = (float)(s_pnum[tid] / (double)garea);
