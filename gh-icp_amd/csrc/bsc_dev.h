@@ -21,6 +21,11 @@ constexpr int BT = 256;
 // point-centric with a 7 x 7 scan per point (rounds 1-2) 7.0 ms, lane-per-cell with register sums 6.4 ms -- both evaluate the exp under
 // ~1-in-6 divergence.  Spheres with more points than BSC_CAP keep the point-centric global sweeps.
 constexpr int BSC_CAP = 2048;
+// The compacted sphere goes through LDS in CHUNKS (round 4): 8 KB instead of 32 KB, 13 KB per workgroup in all, so eight workgroups fit a
+// CU (registers) where four did (LDS): 3.97 -> 3.64 ms per 32 clouds -- and a front-end kernel this small can sit beside the solve slots' LDS
+// (DESIGN.md §8).  A chunk is
+// a multiple of the workgroup size, so thread t meets the points t, t + 256, ... of the list in ascending order exactly as before.
+constexpr int BSC_CHUNK = 512;
 
 int gh_bsc_make_const(ghicp_ctx* ctx, float R, int dof, const int32_t* pattern_host, BscConst* out, float* r_search);  // bsc.hip
 
@@ -84,7 +89,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   __shared__ float s_axes[9];
   __shared__ double s_stat[3][4];  // per plane: avg_d, sd_d, avg_w, sd_w
   __shared__ unsigned s_bits[4][16];
-  __shared__ float4 s_pts[BSC_CAP];
+  __shared__ float4 s_pts[BSC_CHUNK];
   __shared__ int s_scan[17];
   const int tid = threadIdx.x;
   // the keypoint itself: kp holds ORIGINAL indices; find its coordinates through the original cloud copy kept in pts? -> passed via lcs origin
@@ -115,7 +120,9 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   const int my_base = gh_block_excl_scan(cnt, s_scan, &mm);  // thread-major order of the sphere's points: deterministic
   const double mx = sx / (double)mm, my = sy / (double)mm, mz = sz / (double)mm;
   const bool packed = mm <= BSC_CAP;
-  if (packed) {  // second global sweep: the same enumeration, hits written behind the thread's base
+  // chunk [c0, c0 + BSC_CHUNK) of the sphere's point list into LDS: the same enumeration as the counting sweep, a hit lands at its list
+  // position (the thread's base + its running count) when that falls into the chunk
+  auto fill_chunk = [&](int c0) {
     int w = my_base;
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
       for (unsigned q = b + tid; q < e; q += BT) {
@@ -124,21 +131,29 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
         float d2 = dx * dx;
         d2 += dy * dy;
         d2 += dz * dz;
-        if (d2 < C.r2s) s_pts[w++] = make_float4(P.x, P.y, P.z, d2);
+        if (d2 < C.r2s) {
+          if (w >= c0 && w < c0 + BSC_CHUNK) s_pts[w - c0] = make_float4(P.x, P.y, P.z, d2);
+          w++;
+        }
       }
     });
     __syncthreads();
-  }
+  };
 
   // ---- sweep B
   double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
   if (mm >= 3 && packed) {
-    for (int t = tid; t < mm; t += BT) {
-      const float4 P = s_pts[t];
-      const double w = (double)(float)(C.radius_w - (double)sqrtf(P.w));  // float weight (bfe:975-976), negative beyond sqrt2*R
-      const double ex = (double)P.x - mx, ey = (double)P.y - my, ez = (double)P.z - mz;
-      c00 += w * ex * ex; c01 += w * ex * ey; c02 += w * ex * ez;
-      c11 += w * ey * ey; c12 += w * ey * ez; c22 += w * ez * ez;
+    for (int c0 = 0; c0 < mm; c0 += BSC_CHUNK) {
+      fill_chunk(c0);
+      const int cn = min(BSC_CHUNK, mm - c0);
+      for (int t = tid; t < cn; t += BT) {
+        const float4 P = s_pts[t];
+        const double w = (double)(float)(C.radius_w - (double)sqrtf(P.w));  // float weight (bfe:975-976), negative beyond sqrt2*R
+        const double ex = (double)P.x - mx, ey = (double)P.y - my, ez = (double)P.z - mz;
+        c00 += w * ex * ex; c01 += w * ex * ey; c02 += w * ex * ez;
+        c11 += w * ey * ey; c12 += w * ey * ez; c22 += w * ez * ez;
+      }
+      __syncthreads();
     }
   } else if (mm >= 3) {
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
@@ -235,21 +250,23 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
     }
   };
   if (packed) {
-    for (int t = tid; t < mm; t += BT) {  // into the LCS (bfe:178-180), in place
+    const int wave = tid >> 6, lane = tid & 63;
+    const int sub = lane / 9, slot = lane % 9;
+    const int di = slot % 3 - 1, dj = slot / 3 - 1;
+    const float inv_u = 1.0f / C.u;
+    // Work item = (point, plane, one of the 3 x 3 cells around the point's own cell): a point only reaches cells within 1.5 u of it, i.e.
+    // the cell it projects into and that cell's neighbours, so 9 candidates per plane replace the 49-cell scan and ~7 of the 9 lanes
+    // of an item evaluate a Gaussian weight.  7 items per wave (63 lanes).  The cell sums are exact, so the chunking does not reach them.
+    for (int c0 = 0; c0 < mm; c0 += BSC_CHUNK) {
+    fill_chunk(c0);
+    const int cn = min(BSC_CHUNK, mm - c0);
+    for (int t = tid; t < cn; t += BT) {  // into the LCS (bfe:178-180), in place
       const float4 P = s_pts[t];
       const float d0 = P.x - qx, d1 = P.y - qy, d2v = P.z - qz;
       s_pts[t] = make_float4((X0 * d0 + X1 * d1) + X2 * d2v, (Y0 * d0 + Y1 * d1) + Y2 * d2v, (Z0 * d0 + Z1 * d1) + Z2 * d2v, 0.f);
     }
     __syncthreads();
-    // Work item = (point, plane, one of the 3 x 3 cells around the point's own cell): a point only reaches cells within 1.5 u of it, i.e.
-    // the cell it projects into and that cell's neighbours, so 9 candidates per plane replace the 49-cell scan and ~7 of the 9 lanes
-    // of an item evaluate a Gaussian weight -- the f64 exp, which is what this kernel's time goes to, runs on ~3/4 full waves instead of
-    // under the 1-in-6 divergence of a lane-per-cell or lane-per-point layout.  7 items per wave (63 lanes).
-    const int wave = tid >> 6, lane = tid & 63;
-    const int sub = lane / 9, slot = lane % 9;
-    const int di = slot % 3 - 1, dj = slot / 3 - 1;
-    const float inv_u = 1.0f / C.u;
-    const int nitem = mm * 3;
+    const int nitem = cn * 3;
     for (int base = 0; base < nitem; base += 28) {
       const int w = base + wave * 7 + sub;
       if (lane < 63 && w < nitem) {
@@ -290,6 +307,8 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
           if (fx && fy) cell(i2, j2);
         }
       }
+    }
+    __syncthreads();  // the chunk is consumed: the next one overwrites it
     }
   } else {
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
