@@ -426,6 +426,7 @@ extern "C" int ghicp_transform_clouds(ghicp_ctx* ctx, int32_t n_clouds, const fl
   TransformJob* d;
   GH_TRY(ctx->reserve(B_TRANSFORM_JOBS, h.size(), &d));
   GH_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(TransformJob), hipMemcpyHostToDevice, ctx->stream));
+  GH_HIP(hipStreamSynchronize(ctx->stream));  // `h` is a local, and the table slot is reused by the next call: the copy has to be done
   if (nmax > 0) {
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nmax, 256 * 8), 2048));
     hipEvent_t kev = ctx->kt_begin(KT_TRANSFORM);
