@@ -315,12 +315,20 @@ def test_cost_hints_change_the_queue_order_not_the_results(ctx, api, synth, orac
     every pair's iterations and 4x4 are the same bits with, without and with adversarial hints, and a hint for another batch size is ignored."""
     if not hasattr(ctx, "set_loop_cost_hints"):
         pytest.skip("context without the hint entry")
-    scenes = [synth.tls_pair(60_000, pair_id=i) for i in range(3)]
-    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, 6, 0.6, 0.1, 0.5, 1.5, synth.bsc_pattern_glibc(), max_iter=60)
+    rng = np.random.default_rng(17)
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, dof=6, est_iou=0.6, voxel=0.2, pattern=synth.bsc_pattern_glibc(), max_iter=12)
+    p = synth.gauss_pair(n_kp=400)
+    bbx = float(oracle.bbx_magnitude(p.source))
     hs = []
-    for p in scenes * 2:
-        hs.append((ctx.cloud_create(cfg, p.source), ctx.cloud_create(cfg, p.target)))
+    for ks, kt in [(120, 100), (300, 310), (64, 200), (350, 340), (90, 90), (260, 250)]:
+        fS = rng.integers(0, 256, size=(4, ks, 56), dtype=np.uint8)
+        fT = rng.integers(0, 256, size=(4, kt, 56), dtype=np.uint8)
+        m = min(ks, kt)
+        fT[0, :m] = fS[0, :m] ^ (rng.random((m, 56)) < 0.03).astype(np.uint8)
+        hs.append((ctx.cloud_from_features(cfg, p.source[p.kp_source[:ks]].astype(np.float64), fS, bbx),
+                   ctx.cloud_from_features(cfg, p.target[p.kp_target[:kt]].astype(np.float64), fT, bbx)))
     base = ctx.register_clouds(cfg, hs)
+    assert max(st.iterations for st in base) > 1
     for hints in ([float(st.iterations) for st in base], [-float(st.iterations) for st in base], [float("nan")] * len(hs), [1.0] * (len(hs) + 1)):
         ctx.set_loop_cost_hints(hints)
         again = ctx.register_clouds(cfg, hs)
