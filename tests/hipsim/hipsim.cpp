@@ -292,6 +292,8 @@ struct Job {
   dim3 grid, block;
   void (*tramp)(void*);
   void* closure;
+  size_t shmem = 0;
+  char* (*smem_fn[2])() = {nullptr, nullptr};
   std::atomic<unsigned long long> next{0};
   unsigned long long total = 0;
   std::atomic<int> active{0};
@@ -312,7 +314,19 @@ static void work_on(Job* j) {
   for (;;) {
     const unsigned long long b = j->next.fetch_add(1);
     if (b >= j->total) break;
+    // guard behind the dynamic LDS the launch asked for (this thread's instances of the two `smem` candidates)
+    constexpr size_t GUARD = 256;
+    char* sm[2] = {j->smem_fn[0] ? j->smem_fn[0]() : nullptr, j->smem_fn[1] ? j->smem_fn[1]() : nullptr};
+    for (char* p : sm)
+      if (p) memset(p + j->shmem, 0xC7, GUARD);
     run_block(j->grid, j->block, b);
+    for (char* p : sm)
+      if (p)
+        for (size_t k = 0; k < GUARD; k++)
+          if ((unsigned char)p[j->shmem + k] != 0xC7) {
+            fprintf(stderr, "hipsim: a workgroup wrote dynamic LDS byte %zu, the launch asked for %zu bytes (block %llu of the grid)\n", j->shmem + k, j->shmem, b);
+            abort();
+          }
   }
 }
 static void pool_main() {
@@ -373,7 +387,7 @@ static void install_segv_trace() {
   sigaction(SIGBUS, &sa, nullptr);
 }
 
-void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure) {
+void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure, char* (*smem_a)(), char* (*smem_b)()) {
   if (trace_div < 0) {
     trace_div = getenv("HIPSIM_TRACE_DIVERGENCE") ? 1 : 0;
     policy_max = getenv("HIPSIM_POLICY") && !strcmp(getenv("HIPSIM_POLICY"), "max");
@@ -393,6 +407,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* clo
   n_launches++; n_blocks += (long long)total;
   Job j;
   j.grid = grid; j.block = block; j.tramp = tramp; j.closure = closure; j.total = total;
+  j.shmem = shmem; j.smem_fn[0] = smem_a; j.smem_fn[1] = smem_b;
   const int nthreads = pool_threads();
   if (total < 4 || nthreads == 1) {  // small launches stay on the calling thread (host threads may launch concurrently)
     work_on(&j);

@@ -66,7 +66,10 @@ extern thread_local BlockInfo binfo;
 uint64_t wave_collective(int op, int site, uint64_t payload, int src);
 void sync_threads();
 void yield();
-void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure);
+// smem_a / smem_b: return the calling OS thread's instances of the two candidates for `extern __shared__` (see `smem` below); the launch puts a
+// guard pattern behind the `shmem` bytes the launch asked for and checks it after every workgroup: a kernel that uses more dynamic LDS than
+// its launch requested aborts the process with a message (on the GPU that is silent corruption of a neighbour's LDS or a fault)
+void launch(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure, char* (*smem_a)() = nullptr, char* (*smem_b)() = nullptr);
 enum { C_MEMCPY = 0, C_MEMSET, C_SYNC, C_LIBCALL, C_MALLOC, C_NUM };
 void count(int what);  // host API calls, for "operations per cloud" bookkeeping (hipsim_counters)
 }  // namespace hipsim
@@ -78,8 +81,10 @@ void count(int what);  // host API calls, for "operations per cloud" bookkeeping
 static const int warpSize = 64;
 
 // dynamic LDS: `extern __shared__ char smem[]` in a kernel resolves to one of these (global or the TU's unnamed namespace)
-inline thread_local __attribute__((aligned(64))) char smem[160 * 1024];
-namespace { thread_local __attribute__((aligned(64), unused)) char smem[160 * 1024]; }
+inline thread_local __attribute__((aligned(64))) char smem[160 * 1024 + 256];  // (+ 256: room for the guard when a launch asks for all 160 KB)
+namespace { thread_local __attribute__((aligned(64), unused)) char smem[160 * 1024 + 256]; }
+inline char* hipsim_smem_global() { return ::smem; }
+namespace { __attribute__((unused)) char* hipsim_smem_tu() { return smem; } }
 
 // ------------------------------------------------------------------------------------------------ synchronisation, collectives
 static inline void __syncthreads() { hipsim::sync_threads(); }
@@ -313,5 +318,5 @@ template <class F> static void closure_tramp(void* c) { (*static_cast<F*>(c))();
 template <class... KA, class... A>
 static inline void hipLaunchKernelGGL(void (*kernel)(KA...), dim3 grid, dim3 block, size_t shmem, hipStream_t, A&&... args) {
   auto body = [&]() { kernel(static_cast<KA>(args)...); };
-  hipsim::launch(grid, block, shmem, &hipsim::closure_tramp<decltype(body)>, &body);
+  hipsim::launch(grid, block, shmem, &hipsim::closure_tramp<decltype(body)>, &body, &hipsim_smem_global, &hipsim_smem_tu);
 }
