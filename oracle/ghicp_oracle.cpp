@@ -1181,6 +1181,11 @@ void orc_weighted_cov(const float* xyz, int stride, const int* idx, int cnt, int
   for (int i = 0; i < 9; i++) out9[i] = M[i];
 }
 
+// N4 test hook: the contract's expf of the BSC Gaussian weight (tests/test_oracle_cpu.py compares it with the correctly rounded value)
+void orc_bsc_expf(const float* x, int n, float* out) {
+  for (int i = 0; i < n; i++) out[i] = orc::contract_bsc_expf(x[i]);
+}
+
 // N7 test hook: the contract's atan2f (tests/test_oracle_cpu.py compares it with the correctly rounded value)
 void orc_atan2f(const float* y, const float* x, int n, float* out) {
   for (int i = 0; i < n; i++) out[i] = orc::contract_atan2f(y[i], x[i]);

@@ -159,6 +159,14 @@ def fpfh(xyz, k=20):
     return nrm, hist
 
 
+def bsc_expf(x):
+    """N4 of the numerics contract: expf(x), x in [-4.5, 0], of the BSC Gaussian cell weight (orc::contract_bsc_expf)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.float32)
+    lib().orc_bsc_expf(_p(x, C.c_float), int(x.size), _p(out, C.c_float))
+    return out
+
+
 def atan2f(y, x):
     """N7 of the numerics contract: the atan2f of the SPFH angle feature (orc::contract_atan2f)."""
     y = np.ascontiguousarray(y, np.float32)

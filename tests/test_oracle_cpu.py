@@ -470,6 +470,41 @@ def test_gpu_solver_state_machine_model_matches_reference_traversal(oracle):
         assert fp == failed and s2 - mr2 < 0.6 * (s - mr) and dead_rows > 0  # E12 at least halves... the serial DFS iterations
 
 
+def test_bsc_exp_table_is_the_same_on_both_sides_and_correctly_rounded():
+    """N4: the 145 literals of exp(-j / 32) in the library's header and in the oracle's include are the same text, and are what
+    scripts/gen_bsc_exp_table.py produces today (60-digit decimal exp -> nearest double)."""
+    import re
+    import sys
+
+    lit = []
+    for path in (os.path.join(ROOT, "gh-icp_amd", "csrc", "bsc_exp_table.h"), os.path.join(ROOT, "oracle", "bsc_exp_table.inc")):
+        lit.append(re.findall(r"0x[0-9a-f.]+p[+-]\d+", open(path).read()))
+    assert len(lit[0]) == 145 and lit[0] == lit[1]
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_bsc_exp_table as G
+
+    assert [float.fromhex(v) for v in lit[0]] == G.table()
+    assert float.fromhex(lit[0][0]) == 1.0 and float.fromhex(lit[0][32]) == float(np.exp(np.float64(-1.0)))
+
+
+def test_contract_bsc_expf_is_a_faithful_expf(oracle):
+    """N4: the contract's expf (table x degree-6 polynomial, one rounding) against the correctly rounded value over the range the BSC
+    encoder uses (x = -dd / den in [-4.5, 0]): never more than one f32 ulp away, equal on all but ~1e-6 of the inputs, exact at 0 and on
+    the grid points, monotonic, and -- what the exact cell sums rest on -- a multiple of 2^-30 in (2^-7, 1]."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([-rng.uniform(0, 4.5, 1_500_000), -np.arange(145) / 32.0, [-4.5, -4.5000005, -0.0, 0.0]]).astype(np.float32)
+    got = oracle.bsc_expf(x)
+    ref = np.exp(x.astype(np.float64)).astype(np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp != 0).mean() < 1e-5, (ulp.max(), (ulp != 0).mean())
+    assert oracle.bsc_expf(np.array([0.0, -0.0], np.float32)).tolist() == [1.0, 1.0]
+    xs = np.sort(x)
+    assert (np.diff(oracle.bsc_expf(xs)) >= 0).all()
+    assert got.min() > 2.0 ** -7 and got.max() <= 1.0
+    scaled = got.astype(np.float64) * 2.0 ** 30
+    assert (scaled == np.floor(scaled)).all()
+
+
 def test_contract_atan2f_is_a_faithful_atan2f(oracle):
     """N7: the contract's atan2f (f64 series rounded once) against the correctly rounded value: never more than one f32 ulp away, equal
     on all but ~1e-5 of random inputs, exact on the axes / signed zeros / infinities (C99 F.9.1.4), and odd in y."""
