@@ -11,6 +11,22 @@
 namespace ghicp {
 template <typename PointT> class CloudUtility {  // utility.h:132-200 (the members the hot path's callers use)
  public:
+  // utility.h:136-150: centroid as a running sum of coordinate / size in double (host arithmetic: one pass over the caller's vector)
+  void getCloudCenterPoint(const typename pcl::PointCloud<PointT>& cloud, CenterPoint& centerPoint) {
+    double cx = 0, cy = 0, cz = 0;
+    const size_t n = cloud.points.size();
+    for (size_t i = 0; i < n; i++) {
+      cx += cloud.points[i].x / n;
+      cy += cloud.points[i].y / n;
+      cz += cloud.points[i].z / n;
+    }
+    centerPoint.x = cx; centerPoint.y = cy; centerPoint.z = cz;
+  }
+  void getBoundAndCenter(const typename pcl::PointCloud<PointT>& cloud, Bounds& bound, CenterPoint& centerPoint) {  // utility.h:186-190
+    getCloudCenterPoint(cloud, centerPoint);
+    getCloudBound(cloud, bound);
+  }
+
   // utility.h:153-183: the six extremes of the cloud (doubles holding float values).  An empty cloud is undefined behaviour in the
   // reference (it reads cloud[0]); here the bounds stay as they were.
   void getCloudBound(const typename pcl::PointCloud<PointT>& cloud, Bounds& bound) {

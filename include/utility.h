@@ -18,6 +18,10 @@ typedef pcl::PointCloud<pcl::FPFHSignature33> fpfhFeature;
 namespace ghicp {
 enum FeatureType { BSC, RoPS, FPFH, None };      // utility.h:51-57 (== GHICP_FEATURE_*)
 enum CorrespondenceType { NN, NNR, KM };         // utility.h:59-64 (== GHICP_CORR_*)
+struct CenterPoint {                             // utility.h:66-76 (the reference's constructor assigns its PARAMETERS; the members start at 0 here)
+  double x, y, z;
+  CenterPoint(double x_ = 0, double y_ = 0, double z_ = 0) : x(x_), y(y_), z(z_) {}
+};
 struct Bounds {                                  // utility.h:78-90
   double min_x, min_y, min_z, max_x, max_y, max_z;
   Bounds() { min_x = min_y = min_z = max_x = max_y = max_z = 0.0; }
