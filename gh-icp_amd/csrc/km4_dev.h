@@ -136,7 +136,10 @@ __device__ inline void k4_bulk(const K4& s, const unsigned short* list, int coun
             if (rk < K4_CAP) { s.tlc[x * K4_CAP + rk] = (unsigned short)col[j]; s.tlo[x * K4_CAP + rk] = (unsigned short)(c[j] - cb); }
           }
           // entries 4..6 of a row that turns out flagged: their columns over the offsets, which a flagged row never uses.  A separate
-          // store AFTER the one above: entries 1..3 come earlier in the row, so in program order the hints land last
+          // store AFTER the one above: entries 1..3 come earlier in the row, so in program order the hints land last.  The two stores to one
+          // slot come from different lanes; the wave barrier (no instruction: a fence for the scheduler) states the order the lockstep wave
+          // has anyway (found by tests/hipsim with HIPSIM_ORDER=reverse: without it the offset of entry 1 could land on the hint of entry 4)
+          __builtin_amdgcn_wave_barrier();
           if (in && td) {
             const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
             if (rk >= K4_CAP && rk < K4_HINT) s.tlo[x * K4_CAP + rk - K4_CAP] = (unsigned short)col[j];

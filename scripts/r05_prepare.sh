@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round 5, BEFORE the first GPU call (runs in the build container, no GPU): the working tree's library plus one variant library per staged branch,
+# side by side under gh-icp_amd/ (git-ignored, they travel to the GPU box with the snapshot).  ~4 minutes of hipcc.
+#   occ5    next/pair-loop-96vgpr       k_pair_loop at 96 VGPRs (co-residency probe)
+#   beside  next/fe-beside-slots        96-VGPR loop + 2 KB LDS buckets + small-LDS BSC / NMS (front end beside the slots)
+#   packed  next/fe-packed-voxel-sort   keys-only voxel sort of the batched front end
+#   sfused  next/km-s-rounds-fused      S rounds of the Kuhn-Munkres solver with one pass / one barrier per round
+set -e
+root=$(cd "$(dirname "$0")/.." && pwd)
+make -C "$root/gh-icp_amd/csrc" -j8 >/dev/null
+bash "$root/scripts/km_variant_lib.sh" next/pair-loop-96vgpr occ5
+bash "$root/scripts/km_variant_lib.sh" next/km-s-rounds-fused sfused
+bash "$root/scripts/branch_lib.sh" next/fe-beside-slots beside
+bash "$root/scripts/branch_lib.sh" next/fe-packed-voxel-sort packed
+ls -l "$root"/gh-icp_amd/libghicp_*.so
