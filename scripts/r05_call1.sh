@@ -10,7 +10,7 @@ L=$R/gh-icp_amd
 mkdir -p $O
 export TMPDIR=/tmp
 # (0) the wave barrier added to k4_bulk after round 4's last GPU call (a scheduling fence, no instruction): the solver tests first
-timeout 300 python -m pytest tests/test_gpu_km.py tests/test_gpu_loop.py -m gpu -x -q > $O/r05_gputests_km_loop.txt 2>&1
+timeout 300 python -m pytest tests/test_gpu_loop.py -m gpu -x -q > $O/r05_gputests_km_loop.txt 2>&1
 echo "pytest km+loop rc=$?" | tee -a $O/r05_gputests_km_loop.txt; tail -2 $O/r05_gputests_km_loop.txt
 # (1) single solves of the five real matrices: shipped against the fused S rounds
 {

@@ -41,6 +41,21 @@ def test_gpu_tests_on_the_host_simt_interpreter():
     assert m and int(m.group(1)) >= 40 and "failed" not in r.stdout, tail
 
 
+def test_solver_fuzz_in_reverse_lane_order():
+    """The Kuhn-Munkres fuzz with the interpreter running waves and lanes in REVERSE order: a result may not depend on which lane of a lockstep
+    wave gets somewhere first unless a barrier says so.  (End of round 4: two lanes of k4_bulk stored to one list slot and relied on program order;
+    exact on the MI355X, wrong here until a wave barrier stated the order -- the fuzz had never been run with this switch.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hipsim import build
+
+    build.build()
+    env = dict(os.environ, GHICP_SIM="1", HIPSIM_ORDER="reverse", HIPSIM_THREADS="2")
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_loop.py"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           "-k", "solver_paths_fuzz"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_bench_py_on_the_host_simt_interpreter():
     """bench.py itself (calibration of the two front ends, pipeline threads, batched front end, record gather, the JSON line) against the
     simulated library: its host logic is exercised before it ever meets the GPU box.  The numbers mean nothing."""
