@@ -36,6 +36,16 @@ def test_bbx_magnitude(ctx, oracle, tls):
     assert ctx.bbx_magnitude(tls.source) == oracle.bbx_magnitude(tls.source)
 
 
+def test_cloud_bounds(ctx, api, tls):
+    """CloudUtility::getCloudBound (utility.h:153-183): per-axis float minima / maxima returned as doubles; stride 4 (PointXYZI) as well."""
+    for cloud in (tls.source, tls.target[:1], np.concatenate([tls.target[:1000], np.ones((1000, 1), np.float32)], axis=1)):
+        b = np.asarray(ctx.cloud_bounds(cloud), np.float64)
+        np.testing.assert_array_equal(b[:3], cloud[:, :3].min(axis=0).astype(np.float64))
+        np.testing.assert_array_equal(b[3:], cloud[:, :3].max(axis=0).astype(np.float64))
+    with pytest.raises(api.GhicpError):
+        ctx.cloud_bounds(np.zeros((0, 3), np.float32))
+
+
 def test_pca_curvature(ctx, oracle, ds_target):
     lo, co, no = oracle.pca(ds_target, 0.5)
     lg, cg, ng = ctx.pca_curvature(ds_target, 0.5)
