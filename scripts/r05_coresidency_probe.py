@@ -25,7 +25,17 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    import argparse
+
     import torch
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hits", type=int, default=0, help="points per cloud (default: the bench configuration's); small values are for the dry run on the interpreter")
+    ap.add_argument("--n-range", type=int, nargs=2, default=(740, 930), help="graph sizes of the four-per-CU LDS class")
+    ap.add_argument("--pairs", type=int, default=2600, help="pairs in the batch (~2.5 per slot of the chip)")
+    ap.add_argument("--probe-points", type=int, default=1_000_000)
+    ap.add_argument("--full-above", type=int, default=1100, help="the slots count as full while more pairs than this are unfinished")
+    args = ap.parse_args()
 
     import bench
 
@@ -39,10 +49,10 @@ def main():
     picked = []
     # (scene ids with 740 < max(K_S, K_T) <= 930 and ordinary iteration counts, from profiles/r04_bench_default_detail.json: no search on the GPU box)
     for sid in (0, 5, 10, 14, 16, 18, 19, 21, 24, 26, 27, 28):
-        p = bench.make_pair(2, sid, CF["hits"])
+        p = bench.make_pair(2, sid, args.hits or CF["hits"])
         S, T = A.cloud_create(cfg, torch.from_numpy(p.source).cuda()), A.cloud_create(cfg, torch.from_numpy(p.target).cuda())
         n = max(S.info().k, T.info().k)
-        if 740 < n <= 930:
+        if args.n_range[0] < n <= args.n_range[1]:
             picked.append((S, T, n))
         else:
             S.close()
@@ -51,8 +61,8 @@ def main():
             break
     if not picked:
         raise SystemExit("no scene in the four-per-CU class among the first 64")
-    pairs = [(S, T) for S, T, _ in picked] * (2600 // len(picked))  # ~2.5 pairs per slot: several seconds of full slots
-    cloud = torch.from_numpy(np.random.default_rng(1).standard_normal((1_000_000, 3)).astype(np.float32)).cuda()
+    pairs = [(S, T) for S, T, _ in picked] * max(1, args.pairs // len(picked))  # ~2.5 pairs per slot: several seconds of full slots
+    cloud = torch.from_numpy(np.random.default_rng(1).standard_normal((args.probe_points, 3)).astype(np.float32)).cuda()
     hS = torch.from_numpy(np.random.default_rng(2).random((4096, 33)).astype(np.float32)).cuda()
     Rt = np.eye(4)
 
@@ -86,7 +96,10 @@ def main():
     beside = {"transform_ms": [], "fd_fpfh_ms": [], "active_pairs": []}
     while not done.is_set():
         a, tot = A.loop_progress()
-        if tot > 0 and a <= 1100:  # the queue is about to drain: no longer "every slot busy"
+        if tot == 0:  # feature distances / hand-over still running: the loop has not started
+            time.sleep(0.05)
+            continue
+        if a <= args.full_above:  # the queue is about to drain: no longer "every slot busy"
             break
         part = probe(0.25, done)
         for k in ("transform_ms", "fd_fpfh_ms"):

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def patch_torch():
+    """The interpreter's library behind api.Context and CPU stand-ins for the torch.cuda entry points the repository's scripts touch (this process only)."""
     import torch
 
     from hipsim import simctx
@@ -42,6 +43,15 @@ def main():
     torch.zeros = _cpu_device(torch.zeros)
     torch.tensor = _cpu_device(torch.tensor)
     torch.empty = _cpu_device(torch.empty)
+
+
+def main():
+    patch_torch()
+    if len(sys.argv) > 2 and sys.argv[1] == "--script":  # any other script of the repository, unchanged:  --script scripts/x.py [its arguments]
+        script = os.path.join(ROOT, sys.argv[2])
+        sys.argv = [script] + sys.argv[3:]
+        runpy.run_path(script, run_name="__main__")
+        return
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # one process per "GPU": RCCL becomes gloo, everything else of the N > 1 path is bench.py's own
         import torch.distributed as dist
 
