@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5, first GPU call (after scripts/r05_prepare.sh; ~14 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
+# Round 5, first GPU call (after scripts/r05_prepare.sh; ~17 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
 # (box-to-box noise of bench.py is +-3 %, so only numbers of the same call are compared).
-#   gpurun --timeout 1100 -- 'bash scripts/r05_call1.sh'
+#   gpurun --timeout 1500 -- 'bash scripts/r05_call1.sh'
 # Writes gpurun_out/r05_*: copy what is to be judged into profiles/.
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
@@ -33,6 +33,19 @@ for v in main beside packed sfused; do
   GHICP_LIB=$lib timeout 400 python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64 > $O/r05_bench_var_$v.json 2> $O/r05_bench_var_$v.err
   echo "--- bench $v rc=$?"
   python - $O/r05_bench_var_$v.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print({k:d.get(k) for k in ("value","value_all_pairs","ms_per_step")}, d.get("pair_loop_stats"))
+except Exception as e: print("parse failed",e)
+PY
+done
+# (3b) the same branch with its primitives in small-LDS configurations (switch off = the kernels of `beside`, timed above)
+for sw in 1; do
+  env=""; [ $sw = 1 ] && env="GHICP_FE_SMALL_LDS=1"
+  env $env GHICP_LIB=$L/libghicp_var_besides.so timeout 400 python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64 > $O/r05_bench_var_besides_small$sw.json 2> $O/r05_bench_var_besides_small$sw.err
+  echo "--- bench besides small=$sw rc=$?"
+  python - $O/r05_bench_var_besides_small$sw.json <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -3,6 +3,7 @@
 # side by side under gh-icp_amd/ (git-ignored, they travel to the GPU box with the snapshot).  ~4 minutes of hipcc.
 #   occ5    next/pair-loop-96vgpr       k_pair_loop at 96 VGPRs (co-residency probe)
 #   beside  next/fe-beside-slots        96-VGPR loop + 2 KB LDS buckets + small-LDS BSC / NMS (front end beside the slots)
+#   besides next/fe-small-lds-primitives   the same + sort / select / unique in <= 6.2 KB of LDS when GHICP_FE_SMALL_LDS=1
 #   packed  next/fe-packed-voxel-sort   keys-only voxel sort of the batched front end
 #   sfused  next/km-s-rounds-fused      S rounds of the Kuhn-Munkres solver with one pass / one barrier per round
 set -e
@@ -11,5 +12,6 @@ make -C "$root/gh-icp_amd/csrc" -j8 >/dev/null
 bash "$root/scripts/km_variant_lib.sh" next/pair-loop-96vgpr occ5
 bash "$root/scripts/km_variant_lib.sh" next/km-s-rounds-fused sfused
 bash "$root/scripts/branch_lib.sh" next/fe-beside-slots beside
+bash "$root/scripts/branch_lib.sh" next/fe-small-lds-primitives besides
 bash "$root/scripts/branch_lib.sh" next/fe-packed-voxel-sort packed
 ls -l "$root"/gh-icp_amd/libghicp_*.so
