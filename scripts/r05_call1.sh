@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5, first GPU call (after scripts/r05_prepare.sh; ~17 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
+# Round 5, first GPU call (after scripts/r05_prepare.sh; ~20 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
 # (box-to-box noise of bench.py is +-3 %, so only numbers of the same call are compared).
-#   gpurun --timeout 1500 -- 'bash scripts/r05_call1.sh'
+#   gpurun --timeout 1600 -- 'bash scripts/r05_call1.sh'
 # Writes gpurun_out/r05_*: copy what is to be judged into profiles/.
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
@@ -40,12 +40,13 @@ try:
 except Exception as e: print("parse failed",e)
 PY
 done
-# (3b) the same branch with its primitives in small-LDS configurations (switch off = the kernels of `beside`, timed above)
-for sw in 1; do
-  env=""; [ $sw = 1 ] && env="GHICP_FE_SMALL_LDS=1"
-  env $env GHICP_LIB=$L/libghicp_var_besides.so timeout 400 python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64 > $O/r05_bench_var_besides_small$sw.json 2> $O/r05_bench_var_besides_small$sw.err
-  echo "--- bench besides small=$sw rc=$?"
-  python - $O/r05_bench_var_besides_small$sw.json <<'PY'
+# (3b) the same branch with its primitives in small-LDS configurations, from its own tree (variants/besides: scripts/r05_prepare.sh): always, and
+#      only while the loops are dense (switch off = the kernels of `beside`, timed above)
+for m in 1 auto; do
+  ( cd $R/variants/besides && timeout 400 python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64 --fe-small-lds $m \
+      > $O/r05_bench_var_besides_small_$m.json 2> $O/r05_bench_var_besides_small_$m.err )
+  echo "--- bench besides small=$m rc=$?"
+  python - $O/r05_bench_var_besides_small_$m.json <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -14,4 +14,8 @@ bash "$root/scripts/km_variant_lib.sh" next/km-s-rounds-fused sfused
 bash "$root/scripts/branch_lib.sh" next/fe-beside-slots beside
 bash "$root/scripts/branch_lib.sh" next/fe-small-lds-primitives besides
 bash "$root/scripts/branch_lib.sh" next/fe-packed-voxel-sort packed
-ls -l "$root"/gh-icp_amd/libghicp_*.so
+# the whole tree of the small-primitives branch with its library in place: its bench.py has --fe-small-lds {0,1,auto} (variants/ is git-ignored, it travels)
+rm -rf "$root/variants/besides"; mkdir -p "$root/variants/besides"
+git -C "$root" archive next/fe-small-lds-primitives | tar -x -C "$root/variants/besides"
+cp "$root/gh-icp_amd/libghicp_var_besides.so" "$root/variants/besides/gh-icp_amd/libghicp_hip.so"
+ls -l "$root"/gh-icp_amd/libghicp_*.so "$root"/variants/besides/gh-icp_amd/libghicp_hip.so
