@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5, first GPU call (after scripts/r05_prepare.sh; ~20 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
+# Round 5, first GPU call (after scripts/r05_prepare.sh; ~25 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
 # (box-to-box noise of bench.py is +-3 %, so only numbers of the same call are compared).
-#   gpurun --timeout 1600 -- 'bash scripts/r05_call1.sh'
+#   gpurun --timeout 1800 -- 'bash scripts/r05_call1.sh'
 # Writes gpurun_out/r05_*: copy what is to be judged into profiles/.
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
@@ -27,32 +27,33 @@ for v in main occ5; do
   GHICP_LIB=$lib timeout 240 python scripts/r05_coresidency_probe.py > $O/r05_probe_$v.json 2> $O/r05_probe_$v.err
   echo "--- probe $v rc=$?"; tail -1 $O/r05_probe_$v.json | cut -c1-600
 done
-# (3) the bench line per library (3 steps; scenes cached between the runs)
+# (3) the bench line per library, default schedule (front ends of step k+1 start in the TAIL of step k): what each change costs or gives by itself
+show() {
+  python - $1 <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print({k:d.get(k) for k in ("value","value_all_pairs","ms_per_step")}, d.get("pair_loop_stats"), (d.get("batch_ms") or {}).get("front_end_ms_per_cloud_on_its_stream"))
+except Exception as e: print("parse failed",e)
+PY
+}
+B="--steps 2 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64"
 for v in main beside packed sfused; do
   lib=$L/libghicp_var_$v.so; [ $v = main ] && lib=$L/libghicp_hip.so
-  GHICP_LIB=$lib timeout 400 python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64 > $O/r05_bench_var_$v.json 2> $O/r05_bench_var_$v.err
-  echo "--- bench $v rc=$?"
-  python - $O/r05_bench_var_$v.json <<'PY'
-import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print({k:d.get(k) for k in ("value","value_all_pairs","ms_per_step")}, d.get("pair_loop_stats"))
-except Exception as e: print("parse failed",e)
-PY
+  GHICP_LIB=$lib timeout 300 python bench.py $B > $O/r05_bench_var_$v.json 2> $O/r05_bench_var_$v.err
+  echo "--- bench $v rc=$?"; show $O/r05_bench_var_$v.json
 done
-# (3b) the same branch with its primitives in small-LDS configurations, from its own tree (variants/besides: scripts/r05_prepare.sh): always, and
-#      only while the loops are dense (switch off = the kernels of `beside`, timed above)
+# (3b) THE experiment of lever 1: front ends of step k+1 issued while step k is dense (--tail-fraction 1.0: they start with the loop).  With the shipped
+#      library they wait for the tail anyway (same-box baseline; round 4 measured this schedule as slightly worse); with `beside` they can back-fill;
+#      `besides` (its own tree under variants/: scripts/r05_prepare.sh) adds the small-LDS primitives, always (1) or only while the loops are dense (auto)
+for v in main beside; do
+  lib=$L/libghicp_var_$v.so; [ $v = main ] && lib=$L/libghicp_hip.so
+  GHICP_LIB=$lib timeout 300 python bench.py $B --tail-fraction 1.0 > $O/r05_bench_early_$v.json 2> $O/r05_bench_early_$v.err
+  echo "--- bench early front ends, $v rc=$?"; show $O/r05_bench_early_$v.json
+done
 for m in 1 auto; do
-  ( cd $R/variants/besides && timeout 400 python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64 --fe-small-lds $m \
-      > $O/r05_bench_var_besides_small_$m.json 2> $O/r05_bench_var_besides_small_$m.err )
-  echo "--- bench besides small=$m rc=$?"
-  python - $O/r05_bench_var_besides_small_$m.json <<'PY'
-import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print({k:d.get(k) for k in ("value","value_all_pairs","ms_per_step")}, d.get("pair_loop_stats"))
-except Exception as e: print("parse failed",e)
-PY
+  ( cd $R/variants/besides && timeout 300 python bench.py $B --tail-fraction 1.0 --fe-small-lds $m > $O/r05_bench_early_besides_small_$m.json 2> $O/r05_bench_early_besides_small_$m.err )
+  echo "--- bench early front ends, besides small=$m rc=$?"; show $O/r05_bench_early_besides_small_$m.json
 done
 # (4) front end alone on one stream: shipped against the packed voxel sort (the Onesweep rows of the two summaries)
 for v in main packed; do
