@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5, first GPU call (after scripts/r05_prepare.sh; ~25 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
+# Round 5, first GPU call (after scripts/r05_prepare.sh; ~27 GPU-minutes): every staged candidate of round 4 timed against the shipped library ON ONE BOX
 # (box-to-box noise of bench.py is +-3 %, so only numbers of the same call are compared).
-#   gpurun --timeout 1800 -- 'bash scripts/r05_call1.sh'
+#   gpurun --timeout 1900 -- 'bash scripts/r05_call1.sh'
 # Writes gpurun_out/r05_*: copy what is to be judged into profiles/.
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
@@ -55,6 +55,8 @@ for m in 1 auto; do
   ( cd $R/variants/besides && timeout 300 python bench.py $B --tail-fraction 1.0 --fe-small-lds $m > $O/r05_bench_early_besides_small_$m.json 2> $O/r05_bench_early_besides_small_$m.err )
   echo "--- bench early front ends, besides small=$m rc=$?"; show $O/r05_bench_early_besides_small_$m.json
 done
+( cd $R/variants/besides && GHICP_LOOP_HI_PRIO=1 timeout 300 python bench.py $B --tail-fraction 1.0 --fe-small-lds auto > $O/r05_bench_early_besides_auto_hiprio.json 2> $O/r05_bench_early_besides_auto_hiprio.err )
+echo "--- bench early front ends, besides small=auto, loop streams at the highest priority rc=$?"; show $O/r05_bench_early_besides_auto_hiprio.json
 # (4) front end alone on one stream: shipped against the packed voxel sort (the Onesweep rows of the two summaries)
 for v in main packed; do
   lib=$L/libghicp_var_$v.so; [ $v = main ] && lib=$L/libghicp_hip.so
