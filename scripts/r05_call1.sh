@@ -38,7 +38,7 @@ except Exception as e: print("parse failed",e)
 PY
 }
 B="--steps 2 --warmup 1 --cpu-baseline 0 --scene-cache /tmp/scenes64"
-for v in main beside packed sfused; do
+for v in main beside; do
   lib=$L/libghicp_var_$v.so; [ $v = main ] && lib=$L/libghicp_hip.so
   GHICP_LIB=$lib timeout 300 python bench.py $B > $O/r05_bench_var_$v.json 2> $O/r05_bench_var_$v.err
   echo "--- bench $v rc=$?"; show $O/r05_bench_var_$v.json
@@ -64,3 +64,5 @@ for v in main packed; do
   cp $O/r04_fe_check.txt $O/r05_fe_one_stream_$v.txt 2>/dev/null
   grep -h "radix\|onesweep\|Onesweep" $O/r05_fe_one_stream_$v.txt | cut -c1-150 | head -6
 done
+# (5) Infinity-Cache knee of the solve slots (scripts/r05_slots_knee.sh), last: it is the cheapest to lose
+bash $R/scripts/r05_slots_knee.sh
