@@ -769,6 +769,10 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
 template <int FT>
 int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
   hipStream_t s = ctx->stream;
+  // ghicp_ctx_set_loop_cost_hints: "consumed by the next registration call of this context, ignored otherwise" -- taken here, whatever
+  // path the batch takes (round-4 advisor: cleared only in the Kuhn-Munkres branch, hints survived a batch of another kind)
+  std::vector<float> cost_hints;
+  cost_hints.swap(ctx->loop_cost_hints);
   const ghicp_params* p0 = jobs[0].p;
   const int corr = p0->corr;
   int max_iter = 1;
@@ -914,10 +918,8 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
         for (int b = 0; b < nb; b++) { hn[b] = hp[b].C.n; all_sparse &= (hp[b].km_rptr != nullptr) || jobs[b].ks <= 0 || jobs[b].kt <= 0; }
         if (all_sparse) {
           // cost hints of the caller for exactly this batch (ghicp_ctx_set_loop_cost_hints): consumed once
-          const bool hinted = (int)ctx->loop_cost_hints.size() == nb;
-          const int rc = gh_km4_plan(ctx, hn.data(), nb, &km_plan, hinted ? ctx->loop_cost_hints.data() : nullptr);
-          ctx->loop_cost_hints.clear();
-          GH_TRY(rc);
+          const bool hinted = (int)cost_hints.size() == nb;
+          GH_TRY(gh_km4_plan(ctx, hn.data(), nb, &km_plan, hinted ? cost_hints.data() : nullptr));
           use_plan = true;
         }
       }

@@ -125,7 +125,7 @@ def pack_records(mine: Sequence[int], results, rows: int):
 def gather_records(block, dist=None):
     """All ranks' record blocks (torch tensors of equal shape) -> dict pair id -> (iterations, converged, Rt16 list)."""
     blocks = [block]
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():  # also for a one-rank group: the same collective runs whatever the world size
         import torch
 
         blocks = [torch.zeros_like(block) for _ in range(dist.get_world_size())]
@@ -151,7 +151,7 @@ class SharedCounter:
         self._local = 0
         self._store = None
         self._key = name
-        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist is not None and dist.is_initialized():
             from torch.distributed import distributed_c10d as c10d
 
             self._store = c10d._get_default_store()

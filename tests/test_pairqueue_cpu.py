@@ -248,3 +248,31 @@ def test_dynamic_pair_queue_two_ranks_skewed():
     assert {r["rank"] for r in got[0][3]} == {0, 1}  # both ranks took part
     imb = {k: max(g[1][k] for g in got) / (sum(g[1][k] for g in got) / 2) for k in ("static", "dynamic")}
     assert imb["static"] > 1.3 and imb["dynamic"] < 1.15 and imb["dynamic"] < imb["static"], imb
+
+
+def _one_rank_worker(port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    m = pq.broadcast_manifest([5, 3, 9], dist)
+    blk = torch.from_numpy(pq.pack_records([2, 0], [(7, 1, list(range(16))), (9, 0, [0.5] * 16)], 3))
+    out = pq.gather_records(blk, dist)  # a one-rank group still goes through all_gather (the RCCL self-test of tests/test_gpu_multirank.py)
+    c = pq.SharedCounter(dist, "selftest")
+    ids = c.claim(4, 6) + c.claim(4, 6) + c.claim(4, 6)
+    q.put((m, sorted(out), out[2][0], out[0][2][0], ids, c._store is not None))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_runs_the_same_collectives():
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(30)
+    assert got == ([5, 3, 9], [0, 2], 7, 0.5, [0, 1, 2, 3, 4, 5], True)
