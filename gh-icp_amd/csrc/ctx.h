@@ -159,6 +159,15 @@ struct ghicp_ctx {
   int* progress_host = nullptr;        // mapped pinned counter: pairs completed by the running persistent loop
   std::atomic<bool> progress_live{false};
   bool host_ptrs = false;
+  // host-pointer mode: staged copies of LARGE input arrays, kept between ABI calls so that the reference's call sequence -- voxelfilter ->
+  // keypointDetection -> extractBinaryFeatures on the SAME cloud (test/ghicp_main.cpp:86-116) -- uploads a cloud once.  Keyed on host address +
+  // size + a 64-bit fingerprint of the CONTENT (a caller may change a cloud in place between calls), least recently used out first.
+  struct Staged { const void* host; size_t bytes; uint64_t fp; void* dev; uint64_t tick; };
+  std::vector<Staged> staged;
+  size_t staged_bytes = 0;
+  uint64_t stage_tick = 0;
+  long long staged_hits = 0, staged_misses = 0;
+  static constexpr size_t STAGED_MIN = 256 * 1024, STAGED_CAP = (size_t)1 << 30;
   std::string err;
   DevBuf buf[B_NUM];
   std::vector<DevBuf> pairbuf;  // per-pair outputs of the front end (batched API): 3 per pair slot
@@ -191,10 +200,55 @@ struct Stager {
   struct Out { void* host; void* dev; size_t bytes; };
   std::vector<Out> outs;
   std::vector<void*> temps;
-  explicit Stager(ghicp_ctx* c) : ctx(c) {}
+  explicit Stager(ghicp_ctx* c) : ctx(c) { ctx->stage_tick++; }
   ~Stager() { for (void* p : temps) (void)hipFree(p); }
+  // content fingerprint of a host array: four independent multiply-xor lanes over 8-byte words (memory bound, ~10 GB/s per core)
+  static uint64_t fingerprint(const void* p, size_t bytes) {
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(p);
+    const size_t nw = bytes / 8;
+    uint64_t h0 = 0x9E3779B97F4A7C15ull, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull, h3 = 0x27D4EB2F165667C5ull;
+    size_t i = 0;
+    for (; i + 4 <= nw; i += 4) {
+      h0 = (h0 ^ w[i]) * 0x100000001B3ull; h1 = (h1 ^ w[i + 1]) * 0x100000001B3ull;
+      h2 = (h2 ^ w[i + 2]) * 0x100000001B3ull; h3 = (h3 ^ w[i + 3]) * 0x100000001B3ull;
+      h0 ^= h0 >> 29; h1 ^= h1 >> 31; h2 ^= h2 >> 27; h3 ^= h3 >> 33;
+    }
+    for (; i < nw; i++) h0 = (h0 ^ w[i]) * 0x100000001B3ull;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
+    for (size_t k = nw * 8; k < bytes; k++) h1 = (h1 ^ b[k]) * 0x100000001B3ull;
+    return (h0 ^ (h1 << 1) ^ (h2 << 2) ^ (h3 << 3)) + bytes;
+  }
   template <typename T> int in(const T* p, size_t count, const T** out) {
     if (!ctx->host_ptrs || p == nullptr) { *out = p; return GHICP_OK; }
+    const size_t bytes = count * sizeof(T);
+    if (bytes >= ghicp_ctx::STAGED_MIN && bytes <= ghicp_ctx::STAGED_CAP / 4) {  // large input: look for the copy an earlier call staged
+      const uint64_t fp = fingerprint(p, bytes);
+      for (auto& e : ctx->staged)
+        if (e.host == p && e.bytes == bytes && e.fp == fp) {
+          e.tick = ctx->stage_tick;
+          ctx->staged_hits++;
+          *out = reinterpret_cast<const T*>(e.dev);
+          return GHICP_OK;
+        }
+      while (!ctx->staged.empty() && (ctx->staged_bytes + bytes > ghicp_ctx::STAGED_CAP || ctx->staged.size() >= 16)) {  // LRU out; never an entry this call uses
+        size_t lru = ctx->staged.size();
+        for (size_t i = 0; i < ctx->staged.size(); i++)
+          if (ctx->staged[i].tick != ctx->stage_tick && (lru == ctx->staged.size() || ctx->staged[i].tick < ctx->staged[lru].tick)) lru = i;
+        if (lru == ctx->staged.size()) break;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->staged[lru].dev);
+        ctx->staged_bytes -= ctx->staged[lru].bytes;
+        ctx->staged.erase(ctx->staged.begin() + (long)lru);
+      }
+      void* d = nullptr;
+      if (hipMalloc(&d, bytes + 16) != hipSuccess) return ctx->fail(GHICP_ERR_HIP, "stage-in hipMalloc failed");
+      if (hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { (void)hipFree(d); return ctx->fail(GHICP_ERR_HIP, "stage-in copy failed"); }
+      ctx->staged.push_back({p, bytes, fp, d, ctx->stage_tick});
+      ctx->staged_bytes += bytes;
+      ctx->staged_misses++;
+      *out = reinterpret_cast<const T*>(d);
+      return GHICP_OK;
+    }
     void* d = nullptr;
     if (hipMalloc(&d, count * sizeof(T) + 16) != hipSuccess) return ctx->fail(GHICP_ERR_HIP, "stage-in hipMalloc failed");
     temps.push_back(d);

@@ -56,6 +56,7 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   ctx->pair_clouds.clear();
   for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
   for (auto& b : ctx->pairbuf) b.release();
+  for (auto& e : ctx->staged) (void)hipFree(e.dev);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->fb_pinned) (void)hipHostFree(ctx->fb_pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -63,6 +64,14 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
   if (ctx->progress_host) (void)hipHostFree(ctx->progress_host);
   delete ctx;
+  return GHICP_OK;
+}
+
+extern "C" int ghicp_ctx_stage_stats(const ghicp_ctx* ctx, int64_t* hits, int64_t* misses, int64_t* bytes_kept) {
+  if (!ctx) return GHICP_ERR_ARG;
+  if (hits) *hits = ctx->staged_hits;
+  if (misses) *misses = ctx->staged_misses;
+  if (bytes_kept) *bytes_kept = (int64_t)ctx->staged_bytes;
   return GHICP_OK;
 }
 

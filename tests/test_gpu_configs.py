@@ -22,15 +22,20 @@ def _oracle_pair(oracle, synth, S, T, voxel, r_pca, R, dof, corr, est_iou, pat, 
 
 
 def test_cfg4_indoor_fragment_batch(ctx, api, oracle, synth):
-    """configs[3]: a batch of 3DMatch-like fragment pairs (voxel 0.025, r 0.10, R 0.30, BSC + NN) through the batched API."""
+    """configs[3]: a batch of 3DMatch-like fragment pairs (centimetres: voxel 1.25, r 5, R 15, BSC + NN) through the batched API."""
     import torch
 
+    import bench
+
+    CF = bench.CONFIGS[4]
+    vx, rp, Rn = CF["voxel"], CF["r"], CF["R"]
     pat = synth.bsc_pattern_glibc()
     pairs = [synth.indoor_pair(i, 60_000) for i in range(3)]
-    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_NN, 6, 0.6, 0.025, 0.10, 0.30, pat, max_iter=80)
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_NN, 6, 0.6, vx, rp, Rn, pat, max_iter=80)
     stats = ctx.register_pairs(cfg, [(torch.from_numpy(p.source).to(ctx.dev), torch.from_numpy(p.target).to(ctx.dev)) for p in pairs])
     for p, st in zip(pairs, stats):
-        ro, kp = _oracle_pair(oracle, synth, p.source, p.target, 0.025, 0.10, 0.30, 6, oracle.NN, 0.6, pat)
+        ro, kp = _oracle_pair(oracle, synth, p.source, p.target, vx, rp, Rn, 6, oracle.NN, 0.6, pat)
+        assert ro["iters"] >= 5 and kp["S"].size >= 60  # the configuration iterates (rounds 1-4: 1-3 iterations on 19-53 keypoints)
         assert (st.k_s, st.k_t, st.iterations) == (kp["S"].size, kp["T"].size, ro["iters"])
         Rg = np.array(st.Rt[:]).reshape(4, 4)
         if np.isfinite(ro["Rt"]).all():
@@ -94,4 +99,57 @@ def test_edge_cases(ctx, api, oracle):
     m = np.zeros(3, np.int32)
     assert lib.ghicp_km_solve(h, W.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(3), ctypes.c_double(0.01), m.ctypes.data_as(ctypes.c_void_p)) == 0
     assert m.tolist() == [0, 2, 1]
+    lib.ghicp_ctx_destroy(h)
+
+
+def test_host_pointer_mode_uploads_a_cloud_once_and_sees_in_place_changes(ctx, api, oracle, synth):
+    """The C++ drop-in classes run the context in host-pointer mode; the reference's call sequence on one cloud (main:86-116: bounds,
+    keypoints, BSC) must upload it once -- the staged copy is found again by address + size + content fingerprint -- and a cloud that was
+    CHANGED in place between two calls must be uploaded again (ghicp_ctx_stage_stats)."""
+    if getattr(ctx, "simulated", False):
+        pytest.skip("the interpreter's contexts stage nothing")
+    lib = ctx.lib
+    h = ctypes.c_void_p()
+    assert lib.ghicp_ctx_create(0, ctypes.byref(h)) == 0
+    lib.ghicp_ctx_set_host_pointers(h, 1)
+
+    def stats():
+        a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        assert lib.ghicp_ctx_stage_stats(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
+        return a.value, b.value, c.value
+
+    p = synth.tls_pair(120_000, pair_id=9)
+    raw = np.ascontiguousarray(p.target[:, :3], np.float32)  # 1.4 MB: above the 256 KB threshold
+    vp = ctypes.c_void_p
+
+    def voxel(x):
+        keep = np.zeros(x.shape[0] + 1, np.int32)
+        m = ctypes.c_int64(0)
+        assert lib.ghicp_voxel_filter(h, x.ctypes.data_as(vp), ctypes.c_int64(x.shape[0]), 3, ctypes.c_float(0.1), keep.ctypes.data_as(vp), ctypes.byref(m)) == 0
+        return keep[:m.value].copy()
+
+    def bounds(x):
+        out = (ctypes.c_double * 6)()
+        assert lib.ghicp_cloud_bounds(h, x.ctypes.data_as(vp), ctypes.c_int64(x.shape[0]), 3, out) == 0
+        return np.array(out[:])
+
+    k1 = voxel(raw)
+    assert stats()[:2] == (0, 1)
+    b1 = bounds(raw)
+    k2 = voxel(raw)
+    assert stats()[:2] == (2, 1) and stats()[2] >= raw.nbytes  # two more calls on the same cloud: no upload
+    np.testing.assert_array_equal(k1, k2)
+    np.testing.assert_array_equal(k1, oracle.voxel_filter(raw, 0.1))
+    raw[7] += 1000.0  # same address, same size, other content: must not be served from the kept copy
+    b2 = bounds(raw)
+    assert stats()[:2] == (2, 2)
+    assert b2[3] > b1[3] + 500.0 or b2[4] > b1[4] + 500.0
+    np.testing.assert_array_equal(voxel(raw), oracle.voxel_filter(raw, 0.1))
+    assert stats()[:2] == (3, 2)
+    # many distinct clouds: the cache stays bounded (16 arrays)
+    others = [np.ascontiguousarray(raw + float(i), np.float32) for i in range(20)]
+    for o in others:
+        bounds(o)
+    hits, misses, kept = stats()
+    assert (hits, misses) == (3, 22) and kept <= 16 * raw.nbytes
     lib.ghicp_ctx_destroy(h)
