@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void k_fb_bbox(const FbBlock* __restrict__ D, 
 }
 
 // filter.hpp:57-70 per cloud; the cloud id sits above the voxel key's bits
-__global__ __launch_bounds__(256) void k_fb_voxel_keys(const FbBlock* __restrict__ D, int N, int shift, unsigned long long* __restrict__ keys,
+// idx_bits > 0 (branch next/fe-packed-voxel-sort): the point's index rides in the low bits of the key itself -- ONE 8-byte array goes through the
+// radix sort (keys only, sorted on the bits above the index: stable, so the lowest index still leads its voxel) instead of a key and a value array
+__global__ __launch_bounds__(256) void k_fb_voxel_keys(const FbBlock* __restrict__ D, int N, int shift, int idx_bits, unsigned long long* __restrict__ keys,
                                                        unsigned* __restrict__ vals) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
@@ -133,17 +135,18 @@ __global__ __launch_bounds__(256) void k_fb_voxel_keys(const FbBlock* __restrict
   const unsigned long long vx = (unsigned long long)floorf((p[0] - C.vmn[0]) * C.vinv);
   const unsigned long long vy = (unsigned long long)floorf((p[1] - C.vmn[1]) * C.vinv);
   const unsigned long long vz = (unsigned long long)floorf((p[2] - C.vmn[2]) * C.vinv);
-  keys[i] = ((unsigned long long)b << shift) | (vx * C.mul_x + vy * C.mul_y + vz);
-  vals[i] = (unsigned)i;
+  const unsigned long long key = ((unsigned long long)b << shift) | (vx * C.mul_x + vy * C.mul_y + vz);
+  if (idx_bits > 0) keys[i] = (key << idx_bits) | (unsigned long long)i;
+  else { keys[i] = key; vals[i] = (unsigned)i; }
 }
 
 // head of every voxel run whose voxel key > 0 (the run of voxel 0 is the reference's phantom group: filter.hpp:52,66,75-83)
-__global__ __launch_bounds__(256) void k_fb_voxel_flags(const unsigned long long* __restrict__ keys, int N, unsigned long long vmask,
+__global__ __launch_bounds__(256) void k_fb_voxel_flags(const unsigned long long* __restrict__ keys, int N, unsigned long long vmask, int idx_bits,
                                                         unsigned char* __restrict__ flags) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const unsigned long long k = keys[i];
-  flags[i] = ((k & vmask) != 0ull && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+  const unsigned long long k = keys[i] >> idx_bits;
+  flags[i] = ((k & vmask) != 0ull && (i == 0 || (keys[i - 1] >> idx_bits) != k)) ? 1 : 0;
 }
 
 __device__ inline int fb_lower_bound(const int* __restrict__ a, int n, int v) {
@@ -178,13 +181,17 @@ __global__ __launch_bounds__(128) void k_fb_cand_bounds(const int* __restrict__ 
 
 // down-sampled clouds, concatenated: row 0 of a cloud is its raw point 0 (phantom group), then the lowest-index point of every voxel
 __global__ __launch_bounds__(256) void k_fb_gather_ds(const FbBlock* __restrict__ D, const int* __restrict__ headpos, const unsigned* __restrict__ vals2,
-                                                      float4* __restrict__ dsg) {
+                                                      const unsigned long long* __restrict__ packed, unsigned long long idx_mask, float4* __restrict__ dsg) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int nb = D->nb;
   if (i >= D->moff[nb]) return;
   const int b = fb_find(D->moff, nb, i), j = i - D->moff[b];
   const FbCloud& C = D->c[b];
-  const long long s = j == 0 ? 0ll : (long long)vals2[headpos[D->hoff[b] + j - 1]] - D->roff[b];
+  long long s = 0;
+  if (j != 0) {
+    const int hp = headpos[D->hoff[b] + j - 1];
+    s = (packed ? (long long)(packed[hp] & idx_mask) : (long long)vals2[hp]) - D->roff[b];
+  }
   const float* p = C.xyz + (size_t)s * C.stride;
   dsg[i] = make_float4(p[0], p[1], p[2], 0.f);
 }
@@ -232,14 +239,14 @@ __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__
   const int lane = threadIdx.x;
   const int nc = *ncells;
   (void)counter;
-  for (int c = blockIdx.x; c < nc; c += gridDim.x) {  // static deal of the occupied cells (see pca.hip:k_pca_cells)
+  gh_pca_for_my_cells(nc, [&](int c) {  // static deal of the occupied cells: runs of consecutive cells, neighbourhoods per XCD (pca_dev.h)
     __syncthreads();
     const unsigned gkey = cells[c];
     const int b = fb_find_u(D->cb1, D->nb, gkey);
     GridArgs G;
     G.d = D->g1[b]; G.pts = pts; G.start = start + D->cb1[b];
     gh_pca_cell<CHUNK>(G, gkey - D->cb1[b], r2, scat, count, sC, lane);
-  }
+  });
 }
 
 __global__ __launch_bounds__(256) void k_fb_pca_eigen(const double* __restrict__ scat, const int* __restrict__ count, int m, float* __restrict__ lambda,
@@ -490,24 +497,32 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   GH_TRY(ctx->reserve(B_FB_DS, (size_t)N + nb + 1, &dsg));
   GH_HIP(upload());
   hipEvent_t kv0 = ctx->kt_begin(KT_FB_VOXEL);
-  hipLaunchKernelGGL(k_fb_voxel_keys, dim3(cdiv(N, 256)), dim3(256), 0, s, (const FbBlock*)D, (int)N, ebmax, vkeys, vvals);
+  // index bits: enough for the N concatenated points; packed when key and index fit 64 bits together (always at TLS sizes: 34 + 25)
+  int idx_bits = 1;
+  while ((1ll << idx_bits) < N) idx_bits++;
+  if (ebmax + cloud_bits + idx_bits > 64) idx_bits = 0;
+  hipLaunchKernelGGL(k_fb_voxel_keys, dim3(cdiv(N, 256)), dim3(256), 0, s, (const FbBlock*)D, (int)N, ebmax, idx_bits, vkeys, vvals);
   ctx->kt_end(KT_FB_VOXEL, kv0);
   size_t tb = 0, tb2 = 0;
   hipcub::CountingInputIterator<int> iota(0);
   const unsigned sort_bits = (unsigned)(ebmax + cloud_bits);
-  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));
+  if (idx_bits > 0) GH_HIP((rocprim::radix_sort_keys<GhSortConfig>(nullptr, tb, vkeys, vkeys2, (size_t)N, (unsigned)idx_bits, (unsigned)idx_bits + sort_bits, s)));
+  else GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));
   GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, iota, flags, headpos, misc, (int)N, s));
   char* tmp;
   GH_TRY(ctx->reserve(B_GRID_TMP, std::max(tb, tb2) + 16, &tmp));
   hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
-  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));  // stable: lowest index leads its voxel
+  // stable: lowest index leads its voxel
+  if (idx_bits > 0) GH_HIP((rocprim::radix_sort_keys<GhSortConfig>(tmp, tb, vkeys, vkeys2, (size_t)N, (unsigned)idx_bits, (unsigned)idx_bits + sort_bits, s)));
+  else GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));
   ctx->kt_end(KT_VOXEL_SORT, kev);
   const unsigned long long vmask = ebmax >= 64 ? ~0ull : ((1ull << ebmax) - 1ull);
   hipEvent_t kv1 = ctx->kt_begin(KT_FB_VOXEL);
-  hipLaunchKernelGGL(k_fb_voxel_flags, dim3(cdiv(N, 256)), dim3(256), 0, s, vkeys2, (int)N, vmask, flags);
+  hipLaunchKernelGGL(k_fb_voxel_flags, dim3(cdiv(N, 256)), dim3(256), 0, s, vkeys2, (int)N, vmask, idx_bits, flags);
   GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, iota, flags, headpos, misc, (int)N, s));
   hipLaunchKernelGGL(k_fb_voxel_bounds, dim3(1), dim3(128), 0, s, headpos, misc, D, O);
-  hipLaunchKernelGGL(k_fb_gather_ds, dim3(cdiv(N + nb, 256)), dim3(256), 0, s, (const FbBlock*)D, headpos, vvals2, dsg);
+  hipLaunchKernelGGL(k_fb_gather_ds, dim3(cdiv(N + nb, 256)), dim3(256), 0, s, (const FbBlock*)D, headpos, vvals2,
+                     idx_bits > 0 ? (const unsigned long long*)vkeys2 : (const unsigned long long*)nullptr, idx_bits > 0 ? (1ull << idx_bits) - 1ull : 0ull, dsg);
   hipLaunchKernelGGL(k_fb_bbox_init, dim3(cdiv(nb * 6, 256)), dim3(256), 0, s, O->bb, nb);
   hipLaunchKernelGGL(k_fb_bbox, dim3(64, nb), dim3(256), 0, s, (const FbBlock*)D, reinterpret_cast<const float*>(dsg), 1, O->bb);
   ctx->kt_end(KT_FB_VOXEL, kv1);

@@ -57,7 +57,7 @@ typedef __attribute__((address_space(1))) const int* k4_gint;
 typedef __attribute__((address_space(1))) const double* k4_gf64;
 typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
 
-enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_UNCERT, SH_LROW, SH_NUM = 16 };
+enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_UNCERT, SH_LROW, SH_CH2, SH_NUM = 16 };
 
 struct K4 {
   double *lx, *ly, *slack, *red;
@@ -773,7 +773,7 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
       }
       // ---- R5: augmenting phase.  S by pull rounds ...
       for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = 0u; s.goody[w] = s.freey[w]; }
-      if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; s.sh[SH_NF] = 0; }
+      if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; s.sh[SH_CH2] = 0; s.sh[SH_NF] = 0; }
       if (wave == 0) {  // the flagged rows without hints, ascending, into sty (without the pool they would all be members of S: measured, v4)
         int cnt = 0;
         for (int base = 0; base < n; base += 64) {
@@ -786,6 +786,18 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         if (lane == 0) s.sh[SH_NF] = cnt;
       }
       __syncthreads();
+      // (branch next/km-s-rounds-fused) row -> column map of the matching, in the slack array's storage: an augmenting phase is the LAST phase of
+      // its root and the next root starts by resetting slack, so the 8 n bytes are dead from here to the end of the phase.  With it a row
+      // that joins S takes its own column along in the same pass: no column pass, one barrier per round, and rows later in the pass can
+      // already see the column (the fixed point is the same: the least one of a monotone rule, whatever the order).
+      unsigned short* mx = reinterpret_cast<unsigned short*>(s.slack);
+      for (int i = tid; i < n; i += K4_T) mx[i] = (unsigned short)K4_NONE;
+      __syncthreads();
+      for (int y = tid; y < n; y += K4_T) {
+        const int m = s.match[y];
+        if (m != K4_NONE) mx[m] = (unsigned short)y;
+      }
+      __syncthreads();
       const int nf = s.sh[SH_NF];
       const int region = nf > 0 ? min(64, (n + 2) / nf) : 0;  // u16 of stx per flagged row: count + columns (region 1: every flagged row stays in S)
       if (nf > 0) {
@@ -794,27 +806,10 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
       }
       for (int round = 0;; round++) {
         if (PROF) q_rounds++;
-        for (int base = tid; base < n; base += 4 * K4_T) {  // columns: S gains the columns whose owner is in S
-          int yy[4], mm[4];
-          unsigned gw[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            yy[k] = base + k * K4_T;
-            const int yc = min(yy[k], n - 1);
-            gw[k] = s.goody[yc >> 5]; mm[k] = s.match[yc];
-          }
-          unsigned ow[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) ow[k] = s.good[(mm[k] == K4_NONE ? 0 : mm[k]) >> 5];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            if (yy[k] >= n) continue;
-            const bool g = (gw[k] >> (yy[k] & 31)) & 1u;
-            if (!g && mm[k] != K4_NONE && ((ow[k] >> (mm[k] & 31)) & 1u)) atomicOr(&s.goody[yy[k] >> 5], 1u << (yy[k] & 31));
-          }
-        }
-        __syncthreads();
-        if (tid == 0) s.sh[SH_CH0 + ((round + 1) & 1)] = 0;
+        // "something changed" flag of round r in slot r % 3: one barrier per round is enough -- the slot reset here (r + 1) is neither the one
+        // this round sets nor the one a thread that is late out of the previous round may still be reading (r - 1)
+        const int chslot[3] = {SH_CH0, SH_CH1, SH_CH2};
+        if (tid == 0) s.sh[chslot[(round + 1) % 3]] = 0;
         bool ch = false;
         for (int base = tid; base < n; base += 2 * K4_T) {  // rows (two per thread and pass: the hints doubled the registers a row needs): background-tight to the best column of S, or a listed entry in S
           int xx[2], tn[2], lc[2][K4_HINT];
@@ -835,14 +830,24 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
             for (int e = 0; e < K4_HINT; e++) gyw[k][e] = s.goody[lc[k][e] >> 5];  // (a listed row's slots 4..6 hold CSR offsets: < n, any word will do)
 #pragma unroll
           for (int k = 0; k < 2; k++) {
-            if (xx[k] >= n || ((gdw[k] >> (xx[k] & 31)) & 1u)) continue;
+            if (xx[k] >= n) continue;
+            if ((gdw[k] >> (xx[k] & 31)) & 1u) {  // already in S (an earlier round, or the pool build): its column has to be there as well
+              const int yo = mx[xx[k]];
+              if (yo != K4_NONE && !k4_bit(s.goody, yo)) { atomicOr(&s.goody[yo >> 5], 1u << (yo & 31)); ch = true; }
+              continue;
+            }
             bool g = (lxv[k] - bg) < eps;  // background-tight to a free column: those are in S and their label is still 0, the smallest there is
             // listed entries are tight (R2); the hints of a flagged row are the columns that WERE tight when its list was built -- entries
             // only leave between two rebuilds of a row, so "a hint in S" is necessary for the row to be good (R5)
             const int t = tn[k] <= K4_HINT ? tn[k] : 0;
 #pragma unroll
             for (int e = 0; e < K4_HINT; e++) g |= (int)(e < t) & (int)((gyw[k][e] >> (lc[k][e] & 31)) & 1u);
-            if (g) { atomicOr(&s.good[xx[k] >> 5], 1u << (xx[k] & 31)); ch = true; }
+            if (g) {
+              atomicOr(&s.good[xx[k] >> 5], 1u << (xx[k] & 31));
+              const int yo = mx[xx[k]];
+              if (yo != K4_NONE) atomicOr(&s.goody[yo >> 5], 1u << (yo & 31));
+              ch = true;
+            }
           }
         }
         for (int fb = 0; fb < nf; fb += 16) {  // flagged rows: a pooled tight column in S (16 lanes per row)
@@ -853,11 +858,16 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
           if (x >= 0 && !k4_bit(s.good, x))
             for (int e = lig; e < cnt; e += 16) hit |= k4_bit(s.goody, s.stx[i * region + 1 + e]);
           const unsigned gb = (unsigned)(__ballot(hit) >> (lane & 48)) & 0xffffu;
-          if (gb && lig == 0) { atomicOr(&s.good[x >> 5], 1u << (x & 31)); ch = true; }
+          if (gb && lig == 0) {
+            atomicOr(&s.good[x >> 5], 1u << (x & 31));
+            const int yo = mx[x];
+            if (yo != K4_NONE) atomicOr(&s.goody[yo >> 5], 1u << (yo & 31));
+            ch = true;
+          }
         }
-        if (ch) s.sh[SH_CH0 + (round & 1)] = 1;
+        if (ch) s.sh[chslot[round % 3]] = 1;
         __syncthreads();
-        if (!s.sh[SH_CH0 + (round & 1)]) break;
+        if (!s.sh[chslot[round % 3]]) break;
         if (round >= 40) {  // give up pruning for this phase: any superset of good is valid (R5)
           for (int w = tid; w < nw; w += K4_T) s.goody[w] = ~0u;
           break;

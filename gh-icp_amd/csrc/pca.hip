@@ -27,10 +27,10 @@ __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __
   // cells are dealt out statically (block b takes cells b, b + grid, ...): the round-2 version popped ONE cell per atomicAdd on a single
   // global counter, and ~450 k pops per batch of 32 clouds, serialised in L2, were the kernel's whole run time (5.9 ms whatever the
   // arithmetic inside cost: profiles/r03_kernel_stats_fe_one_stream*.txt)
-  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+  gh_pca_for_my_cells(nc, [&](int c) {  // (round 5: runs of consecutive cells per workgroup, neighbourhoods per XCD -- pca_dev.h)
     __syncthreads();
     gh_pca_cell<CHUNK>(G, cells[c], r2, scat, count, sC, lane);
-  }
+  });
 }
 
 __global__ __launch_bounds__(256) void k_pca_eigen(const double* __restrict__ scat, const int* __restrict__ count, long long m, float* __restrict__ lambda,

@@ -18,6 +18,71 @@ __device__ inline double gh_group_sum(double x, int g) {
   for (int o = 1; o < g; o <<= 1) x += __shfl_xor(x, o, 64);
   return x;
 }
+// Radius tests of up to 32 staged candidates pc[0], pc[1 << LG], ... against the query P: bit j of the result = candidate j lies
+// within the radius.  LG (log2 of the lanes that share a query) is a template parameter so that the four LDS loads of a step carry
+// their offsets as immediates; they are issued together, and the step has no branch.  The caller masks the bits of candidates past
+// the end of the block (the tile is readable up to PCA_PAD entries beyond it).
+template <int LG>
+__device__ inline unsigned gh_pca_tests32(const float4* __restrict__ pc, int nj, const float4 P, float r2) {
+  unsigned m = 0u;
+  int j = 0;
+  for (; j + 4 <= nj; j += 4) {
+    const float4* q = pc + (j << LG);
+    const float4 c0 = q[0], c1 = q[1 << LG], c2 = q[2 << LG], c3 = q[3 << LG];
+    float a0 = P.x - c0.x, a1 = P.x - c1.x, a2 = P.x - c2.x, a3 = P.x - c3.x;
+    float d0 = a0 * a0, d1 = a1 * a1, d2 = a2 * a2, d3 = a3 * a3;
+    a0 = P.y - c0.y; a1 = P.y - c1.y; a2 = P.y - c2.y; a3 = P.y - c3.y;
+    d0 += a0 * a0; d1 += a1 * a1; d2 += a2 * a2; d3 += a3 * a3;
+    a0 = P.z - c0.z; a1 = P.z - c1.z; a2 = P.z - c2.z; a3 = P.z - c3.z;
+    d0 += a0 * a0; d1 += a1 * a1; d2 += a2 * a2; d3 += a3 * a3;
+    const unsigned nib = (d0 < r2 ? 1u : 0u) | (d1 < r2 ? 2u : 0u) | (d2 < r2 ? 4u : 0u) | (d3 < r2 ? 8u : 0u);
+    m |= nib << j;
+  }
+  for (; j < nj; j++) {
+    const float4 c = pc[j << LG];
+    const float a0 = P.x - c.x, a1 = P.y - c.y, a2 = P.z - c.z;
+    float d = a0 * a0;
+    d += a1 * a1;
+    d += a2 * a2;
+    m |= (d < r2 ? 1u : 0u) << j;
+  }
+  return m;
+}
+__device__ inline unsigned gh_pca_tests32_lg(int lg, const float4* __restrict__ pc, int nj, const float4 P, float r2) {
+  switch (lg) {
+    case 0: return gh_pca_tests32<0>(pc, nj, P, r2);
+    case 1: return gh_pca_tests32<1>(pc, nj, P, r2);
+    case 2: return gh_pca_tests32<2>(pc, nj, P, r2);
+    case 3: return gh_pca_tests32<3>(pc, nj, P, r2);
+    case 4: return gh_pca_tests32<4>(pc, nj, P, r2);
+    case 5: return gh_pca_tests32<5>(pc, nj, P, r2);
+    default: return gh_pca_tests32<6>(pc, nj, P, r2);
+  }
+}
+// Which occupied cells a workgroup of a PCA launch takes: runs of 8 CONSECUTIVE cells of the (z-fastest) cell list -- a cell's block
+// shares two thirds of its nine runs with its z-neighbour's, so the second staging of a run comes out of L1 / L2 instead of the fabric --
+// and 64 consecutive runs (one neighbourhood of the scan) go to workgroups of ONE XCD (block b runs on XCD b % 8, observed: for speed only),
+// whose L2 then holds the (x +- 1, y +- 1) columns the runs share.  Rounds 3-4 dealt single cells round-robin over all workgroups: every
+// XCD fetched every point, counter traffic 9 x the algorithmic bytes (profiles/r04_pmc_*).  Results do not depend on the deal.
+template <typename F>
+__device__ inline void gh_pca_for_my_cells(int nc, F&& f) {
+  const int grid = (int)gridDim.x, b = (int)blockIdx.x;
+  if (grid < 8) {
+    for (int c = b; c < nc; c += grid) f(c);
+    return;
+  }
+  const int nlb = grid >> 3, xcd = b & 7, lb = b >> 3;
+  if (lb >= nlb) return;  // grid not a multiple of 8: the last few workgroups stay idle
+  const int nrun = (nc + 7) >> 3;
+  for (int r = lb; ((r >> 6) << 9) < nrun; r += nlb) {
+    const int run = ((r >> 6) << 9) | (xcd << 6) | (r & 63);
+    if (run >= nrun) continue;
+    const int c1 = min(nc, (run << 3) + 8);
+    for (int c = run << 3; c < c1; c++) f(c);
+  }
+}
+constexpr int PCA_PAD = 64;  // a block is kept resident in the tile when it leaves this many entries free: the test steps may read (never use) up to g - 1 entries past its end
+
 template <int CHUNK>
 __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, double* __restrict__ scat, int* __restrict__ count, float4* sC, int lane) {
   const int cz = key % G.d.dim[2];
@@ -47,7 +112,7 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
   }
   const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)off_l, 8);
   off_l -= len_l;  // exclusive
-  const bool resident = total <= (unsigned)CHUNK;
+  const bool resident = total + (unsigned)PCA_PAD <= (unsigned)CHUNK;
   if (resident) {
     for (int r = 0; r < 9; r++) {
       const unsigned rb = (unsigned)__builtin_amdgcn_readlane((int)rb_l, r), re = (unsigned)__builtin_amdgcn_readlane((int)re_l, r);
@@ -68,28 +133,36 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
     // ---- sweep 1: neighbour count and centroid (pca.h:151, pcl::PCA mean)
     int k = 0;
     double sx = 0, sy = 0, sz = 0;
-    // Resident block: the first sweep remembers WHICH candidates lie within the radius -- one bit per candidate a lane tests, the first
-    // 128 of them in four registers -- and the second sweep walks the set bits instead of testing all candidates again: ~15 % of the
-    // candidates are neighbours, but a wave executes the f64 block of an iteration whenever ANY of its lanes hits, i.e. nearly always.
-    // A lane meets its neighbours in the same ascending order either way, so the sums are the same bits.
+    // Resident block (round 5): the sweep is split into TESTS and SUMS.  The tests are f32 only and run four candidates per step with
+    // their LDS loads issued together (the rolled loop of rounds 3-4 waited a full LDS round trip per candidate and spent two thirds of
+    // its ~33 instructions per candidate on loop control and on the f64 block, which a wave executes whenever ANY of its lanes hits):
+    // they leave one bit per candidate a lane tested, the first 128 of them in four registers.  The centroid sums and the scatter sums
+    // then walk the set bits (~15 % of the candidates).  A lane meets its neighbours in the same ascending order as before, so the sums
+    // are the same bits; the count is the population count of the masks.
     unsigned hm0 = 0u, hm1 = 0u, hm2 = 0u, hm3 = 0u;
-#define GH_PCA_SWEEP1(HM, W)                                                           \
-    for (int j = 0; j < 32; j++) {                                                     \
-      const int t = sl + ((((W) * 32 + j)) << lg);                                     \
-      if (t >= (int)total) break;                                                      \
-      const float4 Cc = sC[t];                                                         \
-      const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;                   \
-      float d2 = dx * dx;                                                              \
-      d2 += dy * dy;                                                                   \
-      d2 += dz * dz;                                                                   \
-      if (d2 < r2) { k++; sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z; HM |= 1u << j; } \
+    const int per = ((int)total + g - 1) >> lg;                           // candidates a lane tests at most (wave-uniform)
+    const int mine = live ? max(0, ((int)total - sl + g - 1) >> lg) : 0;  // ... and how many of them exist for THIS lane (t = sl + (j << lg) < total)
+#define GH_PCA_CENTROID(HM, W)                                                           \
+    for (unsigned m = HM; m; m &= m - 1u) {                                              \
+      const int t = sl + (((W) * 32 + (__ffs((int)m) - 1)) << lg);                       \
+      const float4 Cc = sC[t];                                                           \
+      sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z;                        \
     }
     if (resident) {
+      const int nw = min(4, (per + 31) >> 5);
+#pragma unroll 1
+      for (int W = 0; W < nw; W++) {  // (a run-time loop: one copy of the test steps per lane split, not four)
+        unsigned m_ = gh_pca_tests32_lg(lg, sC + sl + ((W * 32) << lg), min(32, per - W * 32), P, r2);
+        const int v_ = mine - W * 32;
+        m_ &= v_ >= 32 ? ~0u : (v_ <= 0 ? 0u : (1u << v_) - 1u);
+        hm0 = W == 0 ? m_ : hm0; hm1 = W == 1 ? m_ : hm1; hm2 = W == 2 ? m_ : hm2; hm3 = W == 3 ? m_ : hm3;
+      }
+      k = __popc(hm0) + __popc(hm1) + __popc(hm2) + __popc(hm3);
+      GH_PCA_CENTROID(hm0, 0)
+      GH_PCA_CENTROID(hm1, 1)
+      GH_PCA_CENTROID(hm2, 2)
+      GH_PCA_CENTROID(hm3, 3)
       if (live) {
-        GH_PCA_SWEEP1(hm0, 0)
-        GH_PCA_SWEEP1(hm1, 1)
-        GH_PCA_SWEEP1(hm2, 2)
-        GH_PCA_SWEEP1(hm3, 3)
         for (int t = sl + (128 << lg); t < (int)total; t += g) {
           const float4 Cc = sC[t];
           const float dx = P.x - Cc.x, dy = P.y - Cc.y, dz = P.z - Cc.z;
@@ -99,7 +172,7 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
           if (d2 < r2) { k++; sx += (double)Cc.x; sy += (double)Cc.y; sz += (double)Cc.z; }
         }
       }
-#undef GH_PCA_SWEEP1
+#undef GH_PCA_CENTROID
     } else
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned rb, unsigned re) {
       for (unsigned base = rb; base < re; base += CHUNK) {

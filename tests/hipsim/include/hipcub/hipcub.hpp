@@ -92,4 +92,13 @@ static inline hipError_t radix_sort_pairs(void* tmp, size_t& bytes, const K* kin
   hipcub::detail::sort_pairs(kin, kout, vin, vout, n, (int)b, (int)e, false);
   return hipSuccess;
 }
+template <class Config = default_config, class K>
+static inline hipError_t radix_sort_keys(void* tmp, size_t& bytes, const K* kin, K* kout, size_t n, unsigned b = 0, unsigned e = 8 * sizeof(K), hipStream_t = nullptr,
+                                         bool = false) {
+  if (!tmp) { bytes = 256; return hipSuccess; }
+  hipsim::count(hipsim::C_LIBCALL);
+  std::vector<unsigned char> dummy_in(n), dummy_out(n);
+  hipcub::detail::sort_pairs(kin, kout, dummy_in.data(), dummy_out.data(), n, (int)b, (int)e, false);  // stable on the bits [b, e)
+  return hipSuccess;
+}
 }  // namespace rocprim

@@ -33,15 +33,17 @@ def test_cfg4_indoor_fragment_batch(ctx, api, oracle, synth):
     pairs = [synth.indoor_pair(i, 60_000) for i in range(3)]
     cfg = api.pair_config(api.FEATURE_BSC, api.CORR_NN, 6, 0.6, vx, rp, Rn, pat, max_iter=80)
     stats = ctx.register_pairs(cfg, [(torch.from_numpy(p.source).to(ctx.dev), torch.from_numpy(p.target).to(ctx.dev)) for p in pairs])
+    iterating = 0
     for p, st in zip(pairs, stats):
         ro, kp = _oracle_pair(oracle, synth, p.source, p.target, vx, rp, Rn, 6, oracle.NN, 0.6, pat)
-        assert ro["iters"] >= 5 and kp["S"].size >= 60  # the configuration iterates (rounds 1-4: 1-3 iterations on 19-53 keypoints)
+        iterating += int(ro["iters"] >= 5 and kp["S"].size >= 100)
         assert (st.k_s, st.k_t, st.iterations) == (kp["S"].size, kp["T"].size, ro["iters"])
         Rg = np.array(st.Rt[:]).reshape(4, 4)
         if np.isfinite(ro["Rt"]).all():
             assert rot_err(Rg, ro["Rt"]) < 1e-4 and trans_err(Rg, ro["Rt"]) < 1e-3
         else:
             assert not np.isfinite(Rg).all()
+    assert iterating >= 2  # the configuration iterates on 150-250 keypoints (rounds 1-4: 1-3 iterations on 19-53 keypoints)
 
 
 def test_cfg5_four_dof_km(ctx, api, oracle, synth):
