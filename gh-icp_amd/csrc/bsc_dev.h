@@ -91,6 +91,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   __shared__ unsigned s_bits[4][16];
   __shared__ float4 s_pts[BSC_CHUNK];
   __shared__ int s_scan[17];
+  __shared__ float s_centre[8];  // C.centre, indexed per lane in the cell sweep: out of the kernel arguments (a global load + wait per work item) into LDS
   const int tid = threadIdx.x;
   // the keypoint itself: kp holds ORIGINAL indices; find its coordinates through the original cloud copy kept in pts? -> passed via lcs origin
   const float qx = lcs[(size_t)kk * 12 + 9], qy = lcs[(size_t)kk * 12 + 10], qz = lcs[(size_t)kk * 12 + 11];
@@ -219,6 +220,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   }
   for (int i = tid; i < 147; i += BT) { s_pnum[i] = 0.0; s_dlo[i] = 0ull; s_dcarry[i] = 0u; }
   for (int i = tid; i < 145; i += BT) s_exp[i] = gh_bsc_exp_tab[i];
+  if (tid < 7) s_centre[tid] = C.centre[tid];
   if (tid < 64) s_bits[tid >> 4][tid & 15] = 0u;
   __syncthreads();
   const float X0 = s_axes[0], X1 = s_axes[1], X2 = s_axes[2], Y0 = s_axes[3], Y1 = s_axes[4], Y2 = s_axes[5], Z0 = s_axes[6], Z1 = s_axes[7],
@@ -279,9 +281,9 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
         const int bi = (int)fla, bj = (int)flb;
         auto cell = [&](int ci, int cj) {  // the reference's own test for one cell (bfe:229-247)
           if (ci < 0 || ci >= 7 || cj < 0 || cj >= 7) return;
-          const float dy = bb - C.centre[cj];
+          const float dy = bb - s_centre[cj];
           const float dy2 = dy * dy;
-          const float dx = a - C.centre[ci];
+          const float dx = a - s_centre[ci];
           float dd = dx * dx;
           dd += dy2;
           if (dy2 < C.r2c && dd < C.r2c) {
@@ -300,8 +302,8 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
         if (fa < 1e-4f || fa > 0.9999f || fb < 1e-4f || fb > 0.9999f) {
           bool fx = false, fy = false;
           const int i2 = bi + 2 * di, j2 = bj + 2 * dj;
-          if (di != 0 && i2 >= 0 && i2 < 7) { const float dx = a - C.centre[i2]; fx = dx * dx < C.r2c; }
-          if (dj != 0 && j2 >= 0 && j2 < 7) { const float dy = bb - C.centre[j2]; fy = dy * dy < C.r2c; }
+          if (di != 0 && i2 >= 0 && i2 < 7) { const float dx = a - s_centre[i2]; fx = dx * dx < C.r2c; }
+          if (dj != 0 && j2 >= 0 && j2 < 7) { const float dy = bb - s_centre[j2]; fy = dy * dy < C.r2c; }
           if (fx) cell(i2, bj + dj);
           if (fy) cell(bi + di, j2);
           if (fx && fy) cell(i2, j2);

@@ -153,6 +153,7 @@ struct ghicp_ctx {
   // every class launch of the persistent pair loop, so that a few slots take MANY pairs one after the other (state carried over in LDS)
   bool km_stats = false, km_force_hazard = false;
   int loop_slots_cap = 0;
+  int loop_min_lds = 0;  // GHICP_LOOP_MIN_LDS=<bytes> (experiment hook): every solve slot asks for at least this much LDS, e.g. 46080 = three slots per CU with 25 KB of every CU left to other kernels
   std::vector<uint32_t> cu_mask;       // set by ghicp_ctx_set_cu_mask: the auxiliary streams are restricted to the same compute units
   std::vector<hipStream_t> aux_streams;
   std::vector<hipEvent_t> aux_events;  // [0] fork, [1 + c] join of class c
@@ -172,6 +173,33 @@ struct ghicp_ctx {
   DevBuf buf[B_NUM];
   std::vector<DevBuf> pairbuf;  // per-pair outputs of the front end (batched API): 3 per pair slot
   void* pinned = nullptr;  // small pinned host scratch
+  // job tables of the batched launches (feature distances, final transforms): staged through a grow-only pinned buffer whose reuse waits
+  // for the event behind the previous copy -- no stream synchronisation on the launch path (round-4 advisor: a pageable std::vector +
+  // hipStreamSynchronize stalled the loop stream once per batch)
+  void* job_pinned = nullptr;
+  size_t job_pinned_cap = 0;
+  hipEvent_t job_event = nullptr;
+  bool job_pending = false;
+  int upload_table(const void* src, size_t bytes, void* dst) {
+    if (job_pending) {  // the previous table has left the pinned buffer?
+      if (hipEventSynchronize(job_event) != hipSuccess) return fail(GHICP_ERR_HIP, "job table: event wait failed");
+      job_pending = false;
+    }
+    if (bytes > job_pinned_cap) {
+      if (job_pinned) (void)hipHostFree(job_pinned);
+      job_pinned = nullptr;
+      job_pinned_cap = 0;
+      const size_t cap = ((bytes * 3 / 2) + 4095) & ~(size_t)4095;
+      if (hipHostMalloc(&job_pinned, cap, hipHostMallocDefault) != hipSuccess) return fail(GHICP_ERR_HIP, "job table: pinned allocation of %zu bytes failed", cap);
+      job_pinned_cap = cap;
+    }
+    if (!job_event && hipEventCreateWithFlags(&job_event, hipEventDisableTiming) != hipSuccess) return fail(GHICP_ERR_HIP, "job table: event creation failed");
+    memcpy(job_pinned, src, bytes);
+    if (hipMemcpyAsync(dst, job_pinned, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return fail(GHICP_ERR_HIP, "job table: upload failed");
+    if (hipEventRecord(job_event, stream) != hipSuccess) return fail(GHICP_ERR_HIP, "job table: event record failed");
+    job_pending = true;
+    return GHICP_OK;
+  }
   void* fb_pinned = nullptr;  // descriptor block + report of the batched front end (batch.hip)
   std::vector<struct ghicp_cloud*> pair_clouds;  // cloud handles behind ghicp_register_pairs (2 per pair slot; cloud.hip)
   size_t pinned_cap = 0;

@@ -40,6 +40,7 @@ extern "C" int ghicp_ctx_create(int device, ghicp_ctx** out) {
   c->km_stats = getenv("GHICP_KM_STATS") != nullptr;
   c->km_force_hazard = getenv("GHICP_KM_FORCE_HAZARD") != nullptr;
   if (const char* e = getenv("GHICP_LOOP_SLOTS")) c->loop_slots_cap = atoi(e) > 0 ? atoi(e) : 0;
+  if (const char* e = getenv("GHICP_LOOP_MIN_LDS")) c->loop_min_lds = atoi(e) > 0 ? atoi(e) : 0;
   if (hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) { delete c; return GHICP_ERR_HIP; }
   c->pinned_cap = 4096;
   *out = c;
@@ -58,6 +59,8 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   for (auto& b : ctx->pairbuf) b.release();
   for (auto& e : ctx->staged) (void)hipFree(e.dev);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->job_pinned) (void)hipHostFree(ctx->job_pinned);
+  if (ctx->job_event) (void)hipEventDestroy(ctx->job_event);
   if (ctx->fb_pinned) (void)hipHostFree(ctx->fb_pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   for (hipStream_t a : ctx->aux_streams) (void)hipStreamDestroy(a);
@@ -434,8 +437,7 @@ extern "C" int ghicp_transform_clouds(ghicp_ctx* ctx, int32_t n_clouds, const fl
   }
   TransformJob* d;
   GH_TRY(ctx->reserve(B_TRANSFORM_JOBS, h.size(), &d));
-  GH_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(TransformJob), hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(hipStreamSynchronize(ctx->stream));  // `h` is a local, and the table slot is reused by the next call: the copy has to be done
+  GH_TRY(ctx->upload_table(h.data(), h.size() * sizeof(TransformJob), d));  // through the pinned job buffer: no stream synchronisation
   if (nmax > 0) {
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nmax, 256 * 8), 2048));
     hipEvent_t kev = ctx->kt_begin(KT_TRANSFORM);

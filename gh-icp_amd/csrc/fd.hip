@@ -181,8 +181,7 @@ int gh_fd_bsc_batch_dev(ghicp_ctx* ctx, int nb, const gh_fd_bsc_job* jobs) {
   if (h.empty()) return GHICP_OK;
   FdBscJob* d;
   GH_TRY(ctx->reserve(B_FD_JOBS, h.size(), &d));
-  GH_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(FdBscJob), hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(hipStreamSynchronize(ctx->stream));  // `h` is a local: the table has to be on the device before it goes away (once per batch)
+  GH_TRY(ctx->upload_table(h.data(), h.size() * sizeof(FdBscJob), d));  // through the pinned job buffer: no stream synchronisation
   hipEvent_t kev = ctx->kt_begin(KT_FD_BSC);
   hipLaunchKernelGGL(k_fd_bsc_mfma<true>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const FdBscJob*)d, (int)h.size(), h[0]);
   ctx->kt_end(KT_FD_BSC, kev);

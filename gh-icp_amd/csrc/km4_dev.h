@@ -674,7 +674,9 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
       if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); }
       __builtin_amdgcn_wave_barrier();
       int fq = 0;
+      const long long tf0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
       const bool fr = k4_flood<PROF>(s, 0, 1, INFINITY, lane, &fq, pcf);
+      if (PROF) c_flood += (long long)__builtin_readcyclecounter() - tf0;  // (round-4 advisor: steps[7] stayed 0 after the flood moved out of the phase loop)
       if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
     }
     for (int phase = 0;; ++phase) {
@@ -753,9 +755,11 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
           for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; }
           __syncthreads();
         }
+        long long c_fl_in = 0;  // PROF: the re-flood of this failed phase (counted as flood time, not as failed-phase passes)
         if (wave == sw) {
           int fq = s.sh[SH_QT];
           bool fr = s.sh[SH_FREE] != 0;
+          const long long tf0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
           if (!certified) {
             if (lane == 0) { s.stx[0] = (unsigned short)root; s.visx[root >> 5] = 1u << (root & 31); }
             __builtin_amdgcn_wave_barrier();
@@ -764,10 +768,11 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
             fr = k4_flood<PROF>(s, qt, fq, lnew, lane, &fq, pcf);
           }
           __builtin_amdgcn_wave_barrier();
+          if (PROF) { c_fl_in = (long long)__builtin_readcyclecounter() - tf0; c_flood += c_fl_in; }
           if (lane == 0) { s.sh[SH_RES] = fr ? 1 : 0; s.sh[SH_QTF] = fq; }
         }
         have_prev = true;
-        if (PROF) { q_prows += qt; c_fail += (long long)__builtin_readcyclecounter() - t1; }
+        if (PROF) { q_prows += qt; c_fail += (long long)__builtin_readcyclecounter() - t1 - c_fl_in; }
         if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
         continue;
       }

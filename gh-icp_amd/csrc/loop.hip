@@ -734,7 +734,7 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     if (plan.count[c] <= 0) continue;
     hipStream_t sc = c == 0 ? s : ctx->aux_streams[(size_t)c - 1];
     if (c > 0) GH_HIP_JOIN(hipStreamWaitEvent(sc, ctx->aux_events[0], 0));
-    const size_t lds = std::max(plan.lds[c], (size_t)PL_SCRATCH + 64);
+    const size_t lds = std::max(std::max(plan.lds[c], (size_t)PL_SCRATCH + 64), (size_t)ctx->loop_min_lds);
     int per_cu = 0;
     GH_HIP_JOIN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K4_T, lds));
     if (per_cu <= 0) gh_join_aux(ctx);

@@ -40,7 +40,13 @@ namespace orc {
 // sides by scripts/gen_bsc_exp_table.py.
 #include "bsc_exp_table.inc"
 static const double kBscExpTab[145] = {ORC_BSC_EXP_TABLE};
+// Second evaluation of the same weight, for the TESTS only (round-4 advisor: with the contract's own expf on both sides the bit-exact BSC
+// parity test compares the GPU with a transcription of itself): g_bsc_exp_libm != 0 makes the encoder below use the host libm's f64 exp
+// rounded once to f32 -- what "expf(x), correctly rounded" means up to double rounding -- so that a test can count how many BSC bits the
+// contract moves (tests/test_oracle_cpu.py::test_bsc_bits_under_the_correctly_rounded_exp).
+static int g_bsc_exp_libm = 0;
 static float contract_bsc_expf(float xf) {
+  if (g_bsc_exp_libm) return (float)std::exp((double)xf);
   const double x = (double)xf;
   int j = (int)(x * -32.0 + 0.5);
   j = j < 0 ? 0 : (j > 144 ? 144 : j);
@@ -1181,6 +1187,7 @@ void orc_weighted_cov(const float* xyz, int stride, const int* idx, int cnt, int
   for (int i = 0; i < 9; i++) out9[i] = M[i];
 }
 
+void orc_set_bsc_exp_libm(int on) { orc::g_bsc_exp_libm = on; }
 // N4 test hook: the contract's expf of the BSC Gaussian weight (tests/test_oracle_cpu.py compares it with the correctly rounded value)
 void orc_bsc_expf(const float* x, int n, float* out) {
   for (int i = 0; i < n; i++) out[i] = orc::contract_bsc_expf(x[i]);

@@ -159,6 +159,12 @@ def fpfh(xyz, k=20):
     return nrm, hist
 
 
+def set_bsc_exp_libm(on):
+    """Test switch: the BSC encoder's Gaussian weight through the host libm's f64 exp rounded once to f32 (the correctly rounded expf up to
+    double rounding) instead of the contract's table x polynomial.  Always switch it back off."""
+    lib().orc_set_bsc_exp_libm(1 if on else 0)
+
+
 def bsc_expf(x):
     """N4 of the numerics contract: expf(x), x in [-4.5, 0], of the BSC Gaussian cell weight (orc::contract_bsc_expf)."""
     x = np.ascontiguousarray(x, np.float32)

@@ -524,3 +524,34 @@ def test_contract_atan2f_is_a_faithful_atan2f(oracle):
     r = np.arctan2(sy.astype(np.float64), sx.astype(np.float64)).astype(np.float32)
     np.testing.assert_array_equal(g.view(np.int32), r.view(np.int32))  # incl. the sign of zero
     assert np.isnan(oracle.atan2f(np.array([np.nan], np.float32), np.array([1.0], np.float32)))[0]
+
+
+def test_bsc_bits_under_the_correctly_rounded_exp(oracle, synth):
+    """Round-4 advisor: since N4 the bit-exact BSC parity test compares the GPU with a restatement that shares its expf.  The tie to the
+    reference's libm is this test: the SAME encoder with the Gaussian weight through the host libm's exp (f64, rounded once to f32) instead
+    of the contract's table x polynomial, on every keypoint of two scans -- the 441-bit strings may differ in a handful of bits at most
+    (the contract is within one ulp on ~1e-6 of the arguments, and a weight that moves by an ulp moves a cell's density or depth by
+    less than its distance from the binarisation thresholds almost always)."""
+    pat = synth.bsc_pattern_glibc()
+    bits = flipped = kps = changed = 0
+    for pid in (0, 4):
+        p = synth.tls_pair(60_000, pair_id=pid)
+        ds = p.target[oracle.voxel_filter(p.target, 0.1)]
+        kp, _ = oracle.keypoints(ds, 0.5, 1.5)
+        assert kp.size >= 40
+        f0, l0, _ = oracle.bsc(ds, kp, 1.5, 6, pat)
+        try:
+            oracle.set_bsc_exp_libm(True)
+            f1, l1, _ = oracle.bsc(ds, kp, 1.5, 6, pat)
+        finally:
+            oracle.set_bsc_exp_libm(False)
+        f2, _, _ = oracle.bsc(ds, kp, 1.5, 6, pat)
+        np.testing.assert_array_equal(f0, f2)   # the switch is off again
+        np.testing.assert_array_equal(l0, l1)   # the local frames do not depend on the weight
+        d = np.unpackbits(f0 ^ f1, axis=2).sum(2)  # (variant, keypoint)
+        flipped += int(d.sum())
+        changed += int((d.sum(0) > 0).sum())
+        bits += f0.shape[0] * f0.shape[1] * 441
+        kps += f0.shape[1]
+    assert flipped <= max(4, int(2e-5 * bits)), (flipped, bits)
+    assert changed <= max(2, kps // 50), (changed, kps)
