@@ -218,18 +218,6 @@ __global__ __launch_bounds__(256) void k_fb_gather_sorted(const float4* __restri
   pts[i] = make_float4(P.x, P.y, P.z, __uint_as_float(s));  // w = index into the concatenated cloud
 }
 
-__global__ __launch_bounds__(256) void k_fb_cell_start(const unsigned* __restrict__ keys, unsigned n, unsigned ncell, unsigned* __restrict__ start) {
-  const unsigned c = blockIdx.x * 256u + threadIdx.x;
-  if (c > ncell) return;
-  unsigned lo = 0, hi = n;  // lower_bound(keys, c)
-  while (lo < hi) {
-    const unsigned mid = (lo + hi) >> 1;
-    if (keys[mid] < c) lo = mid + 1;
-    else hi = mid;
-  }
-  start[c] = lo;
-}
-
 // pca.hip:k_pca_cells over the occupied cells of all clouds of the batch
 template <int CHUNK>
 __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__ D, const float4* __restrict__ pts, const unsigned* __restrict__ start,
@@ -239,13 +227,46 @@ __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__
   const int lane = threadIdx.x;
   const int nc = *ncells;
   (void)counter;
-  gh_pca_for_my_cells(nc, [&](int c) {  // static deal of the occupied cells: runs of consecutive cells, neighbourhoods per XCD (pca_dev.h)
-    __syncthreads();
-    const unsigned gkey = cells[c];
-    const int b = fb_find_u(D->cb1, D->nb, gkey);
+  // cell bases of the clouds into LDS: the cloud of a cell is found there (rounds 3-4: a binary search through global memory per cell)
+  __shared__ unsigned s_cb[FB_MAX + 1];
+  const int nbc = D->nb;
+  for (int i = lane; i <= nbc; i += 64) s_cb[i] = D->cb1[i];
+  __syncthreads();
+  auto cloud_of = [&](unsigned gkey) {
+    int lo = 0, hi = nbc - 1;  // last b with s_cb[b] <= gkey
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_cb[mid] <= gkey) lo = mid;
+      else hi = mid - 1;
+    }
+    return lo;
+  };
+  // static deal of the occupied cells: runs of 8 consecutive cells, neighbourhoods per XCD (pca_dev.h).  Within a run the cloud and its
+  // grid are looked up once (they change at most once per cloud), and every cell's table lookups are issued one cell ahead.
+  gh_pca_for_my_runs(nc, [&](int c0, int cnt) {
+    const unsigned key_l = lane < cnt ? cells[c0 + lane] : 0u;
+    unsigned gkey = (unsigned)__builtin_amdgcn_readlane((int)key_l, 0);
+    int b = cloud_of(gkey);
     GridArgs G;
-    G.d = D->g1[b]; G.pts = pts; G.start = start + D->cb1[b];
-    gh_pca_cell<CHUNK>(G, gkey - D->cb1[b], r2, scat, count, sC, lane);
+    G.d = D->g1[b]; G.pts = pts; G.start = start + s_cb[b];
+    unsigned cb_lo = s_cb[b], cb_hi = s_cb[b + 1];
+    PcaMeta mn = gh_pca_meta(G, gkey - cb_lo, lane);
+    for (int j = 0; j < cnt; j++) {
+      const PcaMeta m = mn;
+      const GridArgs Gc = G;
+      const unsigned keyc = gkey - cb_lo;
+      if (j + 1 < cnt) {
+        gkey = (unsigned)__builtin_amdgcn_readlane((int)key_l, j + 1);
+        if (gkey >= cb_hi) {  // the run crosses into the next cloud
+          b = cloud_of(gkey);
+          G.d = D->g1[b]; G.start = start + s_cb[b];
+          cb_lo = s_cb[b]; cb_hi = s_cb[b + 1];
+        }
+        mn = gh_pca_meta(G, gkey - cb_lo, lane);
+      }
+      __syncthreads();
+      gh_pca_cell_body<CHUNK>(Gc, keyc, m, r2, scat, count, sC, lane);
+    }
   });
 }
 
@@ -387,7 +408,7 @@ int build_grid(ghicp_ctx* ctx, const FbBlock* D, int which, const float4* dsg, i
   GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)M, 0u, (unsigned)eb, s)));
   hipLaunchKernelGGL(k_fb_gather_sorted, dim3(cdiv(M, 256)), dim3(256), 0, s, dsg, vals2, M, pts);
-  hipLaunchKernelGGL(k_fb_cell_start, dim3(cdiv((long long)total_cells + 1, 256)), dim3(256), 0, s, keys2, (unsigned)M, total_cells, start);
+  gh_cell_start_launch(s, keys2, (unsigned)M, total_cells, start);  // (round 5: the table is filled from the sorted keys, grid.hip)
   ctx->kt_end(KT_FB_GRID, kg);
   GH_HIP(hipGetLastError());
   *pts_out = pts; *start_out = start; *keys_out = keys2;

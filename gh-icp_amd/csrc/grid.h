@@ -64,6 +64,8 @@ struct GridSlots {
 // Builds a grid with `cell` >= search radius over xyz (device, n x stride floats). Synchronises once
 // (bounding box -> host) to size the cell table.
 int gh_grid_build(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float cell, const GridSlots& slots, DeviceGrid* out);
+// start[c] = lower_bound(keys, c) for c = 0 .. ncell from the n sorted cell keys (start: ncell + 1 entries); grid.hip
+void gh_cell_start_launch(hipStream_t s, const unsigned* keys, unsigned n, unsigned ncell, unsigned* start);
 int gh_bbox_dev(ghicp_ctx* ctx, const float* xyz, long long n, int stride, float* mm_host6);
 
 __device__ inline int gh_cell_coord(float v, float mn, float inv, int dim) {

@@ -27,9 +27,16 @@ __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __
   // cells are dealt out statically (block b takes cells b, b + grid, ...): the round-2 version popped ONE cell per atomicAdd on a single
   // global counter, and ~450 k pops per batch of 32 clouds, serialised in L2, were the kernel's whole run time (5.9 ms whatever the
   // arithmetic inside cost: profiles/r03_kernel_stats_fe_one_stream*.txt)
-  gh_pca_for_my_cells(nc, [&](int c) {  // (round 5: runs of consecutive cells per workgroup, neighbourhoods per XCD -- pca_dev.h)
-    __syncthreads();
-    gh_pca_cell<CHUNK>(G, cells[c], r2, scat, count, sC, lane);
+  gh_pca_for_my_runs(nc, [&](int c0, int cnt) {  // (round 5: runs of consecutive cells per workgroup, neighbourhoods per XCD -- pca_dev.h)
+    const unsigned key_l = lane < cnt ? cells[c0 + lane] : 0u;
+    PcaMeta mn = gh_pca_meta(G, (unsigned)__builtin_amdgcn_readlane((int)key_l, 0), lane);
+    for (int j = 0; j < cnt; j++) {
+      const PcaMeta m = mn;
+      const unsigned key = (unsigned)__builtin_amdgcn_readlane((int)key_l, j);
+      if (j + 1 < cnt) mn = gh_pca_meta(G, (unsigned)__builtin_amdgcn_readlane((int)key_l, j + 1), lane);  // the next cell's lookups fly during this cell's pass
+      __syncthreads();
+      gh_pca_cell_body<CHUNK>(G, key, m, r2, scat, count, sC, lane);
+    }
   });
 }
 

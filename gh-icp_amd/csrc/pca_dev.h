@@ -64,46 +64,63 @@ __device__ inline unsigned gh_pca_tests32_lg(int lg, const float4* __restrict__ 
 // and 64 consecutive runs (one neighbourhood of the scan) go to workgroups of ONE XCD (block b runs on XCD b % 8, observed: for speed only),
 // whose L2 then holds the (x +- 1, y +- 1) columns the runs share.  Rounds 3-4 dealt single cells round-robin over all workgroups: every
 // XCD fetched every point, counter traffic 9 x the algorithmic bytes (profiles/r04_pmc_*).  Results do not depend on the deal.
+// f(c0, cnt): the cells c0 .. c0 + cnt - 1 (cnt <= 8)
 template <typename F>
-__device__ inline void gh_pca_for_my_cells(int nc, F&& f) {
+__device__ inline void gh_pca_for_my_runs(int nc, F&& f) {
   const int grid = (int)gridDim.x, b = (int)blockIdx.x;
+  const int nrun = (nc + 7) >> 3;
   if (grid < 8) {
-    for (int c = b; c < nc; c += grid) f(c);
+    for (int run = b; run < nrun; run += grid) f(run << 3, min(8, nc - (run << 3)));
     return;
   }
   const int nlb = grid >> 3, xcd = b & 7, lb = b >> 3;
   if (lb >= nlb) return;  // grid not a multiple of 8: the last few workgroups stay idle
-  const int nrun = (nc + 7) >> 3;
   for (int r = lb; ((r >> 6) << 9) < nrun; r += nlb) {
     const int run = ((r >> 6) << 9) | (xcd << 6) | (r & 63);
     if (run >= nrun) continue;
-    const int c1 = min(nc, (run << 3) + 8);
-    for (int c = run << 3; c < c1; c++) f(c);
+    f(run << 3, min(8, nc - (run << 3)));
   }
 }
 constexpr int PCA_PAD = 64;  // a block is kept resident in the tile when it leaves this many entries free: the test steps may read (never use) up to g - 1 entries past its end
 
-template <int CHUNK>
-__device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, double* __restrict__ scat, int* __restrict__ count, float4* sC, int lane) {
+// What a cell's pass needs from the cell table: the cell's own points [qb, qe) and, in lanes 0..8, the 9 runs of its 27-cell block.
+// gh_pca_meta only ISSUES the loads (one table lookup per lane, all independent); a caller that walks consecutive cells asks for the
+// next cell's record before it computes the current one, so that the lookups -- each a trip to L2 or HBM: the table has tens of
+// millions of entries per batch -- are in flight during the arithmetic instead of in front of it.
+struct PcaMeta {
+  unsigned rb_l, re_l, qb, qe;
+};
+__device__ inline PcaMeta gh_pca_meta(const GridArgs& G, unsigned key, int lane) {
   const int cz = key % G.d.dim[2];
   const int cy = (key / G.d.dim[2]) % G.d.dim[1];
   const int cx = key / (G.d.dim[2] * G.d.dim[1]);
-  const unsigned qb = G.start[key], qe = G.start[key + 1];
-  // The candidates of a cell are the points of its 27-cell block: 9 runs, ~430 points at TLS density.  When they fit the tile they are
-  // staged ONCE, run after run, and both sweeps of every pass over the cell read them from LDS (one load phase per cell instead of 18
-  // load-barrier-compute phases); larger blocks go through the tile chunk by chunk.  Either way a lane meets the candidates in the same order.
-  // the 9 runs of the block, looked up by 9 LANES at once: the cell table is far larger than L2 (tens of millions of cells per batch), so
-  // each lookup is a trip to HBM, and walking the runs one after the other (twice: sizes, then staging) was most of the kernel's time
-  unsigned rb_l = 0, re_l = 0;
+  PcaMeta m;
+  m.qb = G.start[key];
+  m.qe = G.start[key + 1];
+  m.rb_l = 0u; m.re_l = 0u;
   if (lane < 9) {
     const int x = cx - 1 + lane / 3, y = cy - 1 + lane % 3;
     if (x >= 0 && x < G.d.dim[0] && y >= 0 && y < G.d.dim[1]) {
       const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.d.dim[2] - 1);
       const unsigned base = ((unsigned)x * G.d.dim[1] + y) * G.d.dim[2];
-      rb_l = G.start[base + z0];
-      re_l = G.start[base + z1 + 1];
+      m.rb_l = G.start[base + z0];
+      m.re_l = G.start[base + z1 + 1];
     }
   }
+  return m;
+}
+
+template <int CHUNK>
+__device__ inline void gh_pca_cell_body(const GridArgs& G, unsigned key, const PcaMeta M, float r2, double* __restrict__ scat, int* __restrict__ count, float4* sC,
+                                        int lane) {
+  const int cz = key % G.d.dim[2];
+  const int cy = (key / G.d.dim[2]) % G.d.dim[1];
+  const int cx = key / (G.d.dim[2] * G.d.dim[1]);
+  const unsigned qb = M.qb, qe = M.qe;
+  // The candidates of a cell are the points of its 27-cell block: 9 runs, ~130 points at TLS density (up to ~500).  When they fit the tile
+  // they are staged ONCE, run after run, and every sweep of every pass over the cell reads them from LDS; larger blocks go through the
+  // tile chunk by chunk.  Either way a lane meets the candidates in the same order.
+  const unsigned rb_l = M.rb_l, re_l = M.re_l;
   const unsigned len_l = re_l - rb_l;
   unsigned off_l = len_l;  // inclusive prefix over the lanes (lanes >= 9 add nothing)
   for (int o = 1; o < 16; o <<= 1) {
@@ -113,11 +130,38 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
   const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)off_l, 8);
   off_l -= len_l;  // exclusive
   const bool resident = total + (unsigned)PCA_PAD <= (unsigned)CHUNK;
+  // the first 64 query points' coordinates: asked for before the staging loads are waited for (one memory round trip, not two)
+  float4 P0 = make_float4(0, 0, 0, 0);
+  {
+    const int np0 = (int)min(64u, qe - qb);
+    int g0 = 1;
+    while (g0 * 2 * np0 <= 64) g0 *= 2;
+    if (lane / g0 < np0) P0 = G.pts[qb + lane / g0];
+  }
   if (resident) {
+    // staging: tile entry idx comes from run r(idx) = the last run whose offset is <= idx; the source address is idx + (rb_r - off_r).
+    // Four loads per lane are in flight at a time (rounds 3-4 walked the runs one after the other: nine dependent load -> store rounds)
+    int dsel[9], osel[9];
+#pragma unroll
     for (int r = 0; r < 9; r++) {
-      const unsigned rb = (unsigned)__builtin_amdgcn_readlane((int)rb_l, r), re = (unsigned)__builtin_amdgcn_readlane((int)re_l, r);
-      const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)off_l, r);
-      for (unsigned t = rb + lane; t < re; t += 64) sC[w + (t - rb)] = G.pts[t];
+      osel[r] = __builtin_amdgcn_readlane((int)off_l, r);
+      dsel[r] = __builtin_amdgcn_readlane((int)rb_l, r) - osel[r];
+    }
+    for (int base = 0; base < (int)total; base += 256) {
+      float4 v[4];
+      int ix[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        ix[u] = base + u * 64 + lane;
+        int d = dsel[0];
+#pragma unroll
+        for (int r = 1; r < 9; r++) d = ix[u] >= osel[r] ? dsel[r] : d;  // (offsets never decrease, so the LAST run with offset <= idx < total is never an empty one)
+        v[u] = make_float4(0, 0, 0, 0);
+        if (ix[u] < (int)total) v[u] = G.pts[ix[u] + d];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (ix[u] < (int)total) sC[ix[u]] = v[u];
     }
     __syncthreads();
   }
@@ -128,8 +172,11 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
     const int qi = lane / g, sl = lane % g;
     const unsigned q = q0 + qi;
     const bool live = qi < np;
-    float4 P = make_float4(0, 0, 0, 0);
-    if (live) P = G.pts[q];
+    float4 P = P0;
+    if (q0 != qb) {
+      P = make_float4(0, 0, 0, 0);
+      if (live) P = G.pts[q];
+    }
     // ---- sweep 1: neighbour count and centroid (pca.h:151, pcl::PCA mean)
     int k = 0;
     double sx = 0, sy = 0, sz = 0;
@@ -255,6 +302,13 @@ __device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, do
       count[orig] = k;
     }
   }
+}
+
+// One cell, lookups and pass in a row (the single-cloud kernel's and any other caller's entry point)
+template <int CHUNK>
+__device__ inline void gh_pca_cell(const GridArgs& G, unsigned key, float r2, double* __restrict__ scat, int* __restrict__ count, float4* sC, int lane) {
+  const PcaMeta M = gh_pca_meta(G, key, lane);
+  gh_pca_cell_body<CHUNK>(G, key, M, r2, scat, count, sC, lane);
 }
 
 // pcl::PCA's eigenvalues of one point from its neighbourhood's scatter sums (pca.h:218-223) and the curvature of pca.h:232-239: one

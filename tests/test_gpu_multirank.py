@@ -93,4 +93,5 @@ def test_one_rank_rccl_group_runs_the_pair_queue_collectives_on_device_tensors(c
         port = so.getsockname()[1]
     r = subprocess.run([sys.executable, "-c", code, str(port)], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    assert r.stdout.strip().splitlines()[-1] == "[5, 3, 9] [0, 2] 7 0.5 [1.0, 1.0, 1.0, 1.0] [0, 1, 2, 3, 4, 5] nccl"
+    # (RCCL prints its library path on stdout when the group goes away: the line is looked for, not expected last)
+    assert "[5, 3, 9] [0, 2] 7 0.5 [1.0, 1.0, 1.0, 1.0] [0, 1, 2, 3, 4, 5] nccl" in [l.strip() for l in r.stdout.splitlines()], r.stdout[-2000:]
