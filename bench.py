@@ -54,7 +54,7 @@ CONFIGS = {
             distinct=64, scaling="strong", unit_m=0.01),
     # (scene 0 of cfg5 never converges -- GPU and oracle both stop at the 200-iteration guard the reference does not have --, so the benchmark
     # pair is scene 1: 77 iterations on both sides, tests/golden/fullsize.json)
-    5: dict(name="cfg5: low-overlap levelled TLS pair, 10 M pts/scan", hits=10_000_000, voxel=0.1, r=0.5, R=1.5, feature="BSC", corr="KM", dof=4, iou=0.3, B=8, distinct=1, scaling="weak", first=8),  # pair 8: the one of seeds 0..15 the reference's verdict accepts (profiles/r04_cfg5_pair_search.json)
+    5: dict(name="cfg5: low-overlap levelled TLS pair, 10 M pts/scan", hits=10_000_000, voxel=0.1, r=0.5, R=1.5, feature="BSC", corr="KM", dof=4, iou=0.3, B=8, distinct=8, scaling="weak", first=8),  # seeds 8..15 (round 5: the acceptance rate is MEASURED over eight scenes -- round 4 quoted pair 8 alone, the one of seeds 0..15 the reference's verdict accepts: profiles/r04_cfg5_pair_search.json)
 }
 
 
@@ -97,10 +97,12 @@ def _oracle_worker(a):
     t0 = time.time()
     r = O.register_pair(*a, max_iter=200)  # timed: the -O3 -march=native build
     t1 = time.time()
+    sec_native = r["seconds"]
     if native and check:  # parity: the contract build (-O2, the one the tests pin; -O3 vectorisation changes the f32 rigid solve by an ulp)
         O.use_library(os.path.join(ROOT, "oracle", "libghicp_oracle.so"))
         r = O.register_pair(*a, max_iter=200)
-    r["t0"], r["t1"], r["pair_id"] = t0, t1, pair_id
+        r["seconds"] = sec_native  # the timed run's stage times
+    r["t0"], r["t1"], r["pair_id"], r["checked"] = t0, t1, pair_id, bool(native and check)
     return r
 
 
@@ -834,14 +836,13 @@ def main():
         O.use_library(native)
         Oc = {"BSC": O.BSC, "FPFH": O.FPFH}[CF["feature"]], {"KM": O.KM, "NN": O.NN, "NNR": O.NNR}[CF["corr"]]
         big = hits > 2_000_000
-        # (i) one thread, median of 3 (one run for the 5 M / 10 M configs: flagged)
+        # (i) one thread, median of 3.  The 5 M / 10 M configurations (65-250 s per pair) take the figure from leg (ii) instead: the median
+        # over its concurrently running processes (flagged in `sample`; the box's host cores are far from saturated by 8-64 processes)
         s0, t0c, _ = scene[sid0]
         one = []
-        for _ in range(1 if big else 3):
+        for _ in range(0 if big else 3):
             r1 = O.register_pair(s0, t0c, CF["voxel"], CF["r"], CF["R"], CF["dof"], Oc[0], Oc[1], CF["iou"], synth.bsc_pattern_glibc(), max_iter=200)
             one.append(r1["seconds"])
-        t_pair = float(np.median([o["total"] for o in one]))
-        stage_med = {k: round(float(np.median([o[k] for o in one])), 3) for k in one[0]}
         # (ii) many host cores: the distinct scenes cycled over --cpu-procs processes, started together.  Default 64 of the host's logical
         # CPUs: the leg is memory bound -- 256 processes on the 256 logical CPUs of the GPU box registered FEWER pairs per second than 64
         # (1.07 against 1.27, profiles/r03_bench_default.json) and took 4 minutes -- and the default run has to stay bounded
@@ -851,16 +852,23 @@ def main():
         jobs_cpu = [ids[i % len(ids)] for i in range(max(procs, len(ids)))]
         start_at = time.time() + (25.0 if big else 12.0) + 0.1 * len(jobs_cpu)
         with mp.get_context("spawn").Pool(procs) as pool:
-            ora_all = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at, j < len(ids)) for j, sid in enumerate(jobs_cpu)], chunksize=1)
+            # (the 5 M / 10 M configurations check ONE scene against the contract build here -- a second 1-4 minute run per scene otherwise --;
+            # their parity at full size is tests/test_gpu_fullsize.py's, against committed oracle fixtures)
+            ora_all = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at, j < (1 if big else len(ids))) for j, sid in enumerate(jobs_cpu)], chunksize=1)
         wall = max(r["t1"] for r in ora_all) - min(r["t0"] for r in ora_all)
-        ora = ora_all[:len(ids)]  # one checked result per distinct scene (the repeats only load the other cores)
+        if big:
+            one = [r["seconds"] for r in ora_all]
+        t_pair = float(np.median([o["total"] for o in one]))
+        stage_med = {k: round(float(np.median([o[k] for o in one])), 3) for k in one[0]}
+        ora = [r for r in ora_all[:len(ids)] if r.get("checked")]  # one checked result per distinct scene (the repeats only load the other cores)
         cpu_model = ""
         try:
             cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except (OSError, IndexError):
             pass
         cpu = {"value": round(1.0 / t_pair, 5), "unit": "pairs/s", "cores": 1, "kind": "port",
-               "sample": "pair %d complete (front end + loop), %s, g++ -O3 -march=native" % (sid0, "1 run" if big else "median of 3"),
+               "sample": ("median over the %d concurrent processes of the all-cores leg (front end + loop of one pair each), g++ -O3 -march=native" % len(jobs_cpu)) if big
+               else "pair %d complete (front end + loop), median of 3, g++ -O3 -march=native" % sid0,
                "stages_s": stage_med, "host": "%d logical CPUs, %s" % (ncpu, cpu_model),
                "all_cores": {"value": round(len(jobs_cpu) / wall, 4), "cores": procs, "of_logical_cpus": ncpu, "pairs": len(jobs_cpu), "wall_s": round(wall, 1)}}
         workload_stats = {"k_bar": round(float(np.mean([r["k_bar"] for r in ora])), 1), "m_bar": round(float(np.mean([r["m_bar"] for r in ora])), 1)}

@@ -226,7 +226,6 @@ __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__
   __shared__ float4 sC[CHUNK];
   const int lane = threadIdx.x;
   const int nc = *ncells;
-  (void)counter;
   // cell bases of the clouds into LDS: the cloud of a cell is found there (rounds 3-4: a binary search through global memory per cell)
   __shared__ unsigned s_cb[FB_MAX + 1];
   const int nbc = D->nb;
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(64) void k_fb_pca_cells(const FbBlock* __restrict__
   };
   // static deal of the occupied cells: runs of 8 consecutive cells, neighbourhoods per XCD (pca_dev.h).  Within a run the cloud and its
   // grid are looked up once (they change at most once per cloud), and every cell's table lookups are issued one cell ahead.
-  gh_pca_for_my_runs(nc, [&](int c0, int cnt) {
+  gh_pca_for_my_runs(nc, counter, [&](int c0, int cnt) {
     const unsigned key_l = lane < cnt ? cells[c0 + lane] : 0u;
     unsigned gkey = (unsigned)__builtin_amdgcn_readlane((int)key_l, 0);
     int b = cloud_of(gkey);
@@ -605,14 +604,17 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   hipEvent_t ku = ctx->kt_begin(KT_FB_GRID);
   GH_HIP(hipcub::DeviceSelect::Unique(tmp, tb, keys1, cells, misc, M, s));
-  GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
+  GH_HIP(hipMemsetAsync(misc + 4, 0, 8 * sizeof(int), s));
   ctx->kt_end(KT_FB_GRID, ku);
   const float r2_pca = (float)((double)r_pca * (double)r_pca);  // pcl radiusSearch: static_cast<float>(radius*radius)
   hipEvent_t kt = ctx->kt_begin(KT_PCA);
   double* scat;
   GH_TRY(ctx->reserve(B_FE_SCATTER, (size_t)M * 6 + 6, &scat));
-  hipLaunchKernelGGL(k_fb_pca_cells<PCA_CHUNK>, dim3(ctx->num_cu * 20), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells,
-                     (const int*)misc, misc + 1, r2_pca, scat, count);
+  int pca_per_cu = 0;  // every workgroup of the launch resident at once: the runs are handed out dynamically, a second round of workgroups would only find the counters dry
+  GH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pca_per_cu, reinterpret_cast<const void*>(&k_fb_pca_cells<PCA_CHUNK>), 64, 0));
+  const int pca_blocks = std::max(8, (std::max(1, std::min(pca_per_cu, 20)) * ctx->num_cu) & ~7);
+  hipLaunchKernelGGL(k_fb_pca_cells<PCA_CHUNK>, dim3(pca_blocks), dim3(64), 0, s, (const FbBlock*)D, pts1, start1, (const unsigned*)cells,
+                     (const int*)misc, misc + 4, r2_pca, scat, count);
   hipLaunchKernelGGL(k_fb_pca_eigen, dim3(cdiv(M, 256)), dim3(256), 0, s, (const double*)scat, (const int*)count, M, lambda, curv);
   ctx->kt_end(KT_PCA, kt);
   hipEvent_t kp = ctx->kt_begin(KT_FB_PRUNE);

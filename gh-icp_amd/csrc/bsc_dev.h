@@ -91,8 +91,10 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   __shared__ unsigned s_bits[4][16];
   __shared__ float4 s_pts[BSC_CHUNK];
   __shared__ int s_scan[17];
-  __shared__ float s_centre[8];
-  __shared__ unsigned s_rb[9], s_re[9];  // the 9 runs of the keypoint's 27-cell block, looked up ONCE (rounds 1-4: by every sweep, one run after the other)  // C.centre, indexed per lane in the cell sweep: out of the kernel arguments (a global load + wait per work item) into LDS
+  // (round 5, measured and dropped: the three sweeps over the block's points through an iterator that issues four loads of the thread's own
+  // sequence at a time -- same order, same bits -- 3.61 -> 3.70 ms per 32 clouds: eight workgroups per CU hide the load latency already,
+  // and the kernel is bound by its instruction count, profiles/r05_fe_pmc_call3.txt)
+  __shared__ float s_centre[8];  // C.centre, indexed per lane in the cell sweep: out of the kernel arguments (a global load + wait per work item) into LDS
   const int tid = threadIdx.x;
   // the keypoint itself: kp holds ORIGINAL indices; find its coordinates through the original cloud copy kept in pts? -> passed via lcs origin
   const float qx = lcs[(size_t)kk * 12 + 9], qy = lcs[(size_t)kk * 12 + 10], qz = lcs[(size_t)kk * 12 + 11];
@@ -100,62 +102,21 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   const int cy = gh_cell_coord(qy, G.d.mn[1], G.d.inv, G.d.dim[1]);
   const int cz = gh_cell_coord(qz, G.d.mn[2], G.d.inv, G.d.dim[2]);
 
-  if (tid < 9) {  // nine lanes, nine independent table lookups
-    unsigned rb = 0u, re = 0u;
-    const int x = cx - 1 + tid / 3, y = cy - 1 + tid % 3;
-    if (x >= 0 && x < G.d.dim[0] && y >= 0 && y < G.d.dim[1]) {
-      const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.d.dim[2] - 1);
-      const unsigned base = ((unsigned)x * G.d.dim[1] + y) * G.d.dim[2];
-      rb = G.start[base + z0];
-      re = G.start[base + z1 + 1];
-    }
-    s_rb[tid] = rb; s_re[tid] = re;
-  }
-  __syncthreads();
-  // A sweep over the block's points: thread t meets the points rb[r] + t, rb[r] + t + 256, ... of run r = 0 .. 8 -- the SAME points in
-  // the SAME order as the run-by-run loops of rounds 1-4 (every per-thread sum and the thread-major list order keep their bits) -- but
-  // four at a time: the addresses of four consecutive points of the thread's own sequence are found first (no memory involved), their
-  // loads are issued together, then they are handed to f in order.  (A run holds ~1.5 points per thread, so the old loops were nine
-  // lookups and ~13 loads in a row, each waited for before the next was issued.)
-  auto sweep = [&](auto&& f) {
-    int r = 0;
-    unsigned q = s_rb[0] + (unsigned)tid, e = s_re[0];
-    for (;;) {
-      unsigned qq[4];
-      int nv = 0;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        while (r < 9 && q >= e) {
-          r++;
-          if (r < 9) { q = s_rb[r] + (unsigned)tid; e = s_re[r]; }
-        }
-        qq[u] = q;
-        if (r < 9) { nv = u + 1; q += BT; }
-      }
-      if (nv == 0) break;
-      float4 P[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (u < nv) P[u] = G.pts[qq[u]];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (u < nv) f(P[u]);
-      if (nv < 4) break;
-    }
-  };
-
   // ---- sweep A
   double sx = 0, sy = 0, sz = 0, sw = 0;
   int cnt = 0;
-  sweep([&](const float4 P) {
-    const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
-    float d2 = dx * dx;
-    d2 += dy * dy;
-    d2 += dz * dz;
-    if (d2 < C.r2s) {
-      cnt++;
-      sx += (double)P.x; sy += (double)P.y; sz += (double)P.z;
-      sw += C.radius_w - (double)sqrtf(d2);
+  gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+    for (unsigned q = b + tid; q < e; q += BT) {
+      const float4 P = G.pts[q];
+      const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+      float d2 = dx * dx;
+      d2 += dy * dy;
+      d2 += dz * dz;
+      if (d2 < C.r2s) {
+        cnt++;
+        sx += (double)P.x; sy += (double)P.y; sz += (double)P.z;
+        sw += C.radius_w - (double)sqrtf(d2);
+      }
     }
   });
   sx = gh_block_sum(sx, red); sy = gh_block_sum(sy, red); sz = gh_block_sum(sz, red); sw = gh_block_sum(sw, red);
@@ -167,14 +128,17 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
   // position (the thread's base + its running count) when that falls into the chunk
   auto fill_chunk = [&](int c0) {
     int w = my_base;
-    sweep([&](const float4 P) {
-      const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
-      float d2 = dx * dx;
-      d2 += dy * dy;
-      d2 += dz * dz;
-      if (d2 < C.r2s) {
-        if (w >= c0 && w < c0 + BSC_CHUNK) s_pts[w - c0] = make_float4(P.x, P.y, P.z, d2);
-        w++;
+    gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
+      for (unsigned q = b + tid; q < e; q += BT) {
+        const float4 P = G.pts[q];
+        const float dx = qx - P.x, dy = qy - P.y, dz = qz - P.z;
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        if (d2 < C.r2s) {
+          if (w >= c0 && w < c0 + BSC_CHUNK) s_pts[w - c0] = make_float4(P.x, P.y, P.z, d2);
+          w++;
+        }
       }
     });
     __syncthreads();
@@ -195,7 +159,7 @@ __device__ inline void gh_bsc_keypoint(const GridArgs& G, const BscConst& C, int
       }
       __syncthreads();
     }
-  } else if (mm >= 3) {  // (spheres beyond BSC_CAP points: rare, the plain run-by-run loops)
+  } else if (mm >= 3) {
     gh_for_runs(G.d, G.start, cx, cy, cz, [&](unsigned b, unsigned e) {
       for (unsigned q = b + tid; q < e; q += BT) {
         const float4 P = G.pts[q];

@@ -23,11 +23,10 @@ __global__ __launch_bounds__(64) void k_pca_cells(GridArgs G, const unsigned* __
   __shared__ float4 sC[CHUNK];
   const int lane = threadIdx.x;
   const int nc = *ncells;
-  (void)counter;
   // cells are dealt out statically (block b takes cells b, b + grid, ...): the round-2 version popped ONE cell per atomicAdd on a single
   // global counter, and ~450 k pops per batch of 32 clouds, serialised in L2, were the kernel's whole run time (5.9 ms whatever the
   // arithmetic inside cost: profiles/r03_kernel_stats_fe_one_stream*.txt)
-  gh_pca_for_my_runs(nc, [&](int c0, int cnt) {  // (round 5: runs of consecutive cells per workgroup, neighbourhoods per XCD -- pca_dev.h)
+  gh_pca_for_my_runs(nc, counter, [&](int c0, int cnt) {  // (round 5: runs of consecutive cells per workgroup, neighbourhoods per XCD -- pca_dev.h)
     const unsigned key_l = lane < cnt ? cells[c0 + lane] : 0u;
     PcaMeta mn = gh_pca_meta(G, (unsigned)__builtin_amdgcn_readlane((int)key_l, 0), lane);
     for (int j = 0; j < cnt; j++) {
@@ -74,14 +73,14 @@ int gh_pca_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float 
   char* tmp;
   GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   GH_HIP(hipcub::DeviceSelect::Unique(tmp, tb, G.keys, cells, misc, (int)m, s));
-  GH_HIP(hipMemsetAsync(misc + 1, 0, sizeof(int), s));
+  GH_HIP(hipMemsetAsync(misc + 4, 0, 8 * sizeof(int), s));
   GridArgs A = {G.d, G.pts, G.start};
   const float r2 = (float)((double)radius * (double)radius);  // pcl radiusSearch: static_cast<float>(radius*radius)
   const int blocks = ctx->num_cu * 20;
   hipEvent_t kt = ctx->kt_begin(KT_PCA);
   double* scat;
   GH_TRY(ctx->reserve(B_FE_SCATTER, (size_t)m * 6 + 6, &scat));
-  hipLaunchKernelGGL(k_pca_cells<PCA_CHUNK>, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 1, r2, scat, count);
+  hipLaunchKernelGGL(k_pca_cells<PCA_CHUNK>, dim3(blocks), dim3(64), 0, s, A, cells, misc, misc + 4, r2, scat, count);
   hipLaunchKernelGGL(k_pca_eigen, dim3(cdiv(m, 256)), dim3(256), 0, s, (const double*)scat, (const int*)count, m, lambda, curvature);
   ctx->kt_end(KT_PCA, kt);
   GH_HIP(hipGetLastError());

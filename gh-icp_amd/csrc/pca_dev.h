@@ -64,9 +64,14 @@ __device__ inline unsigned gh_pca_tests32_lg(int lg, const float4* __restrict__ 
 // and 64 consecutive runs (one neighbourhood of the scan) go to workgroups of ONE XCD (block b runs on XCD b % 8, observed: for speed only),
 // whose L2 then holds the (x +- 1, y +- 1) columns the runs share.  Rounds 3-4 dealt single cells round-robin over all workgroups: every
 // XCD fetched every point, counter traffic 9 x the algorithmic bytes (profiles/r04_pmc_*).  Results do not depend on the deal.
-// f(c0, cnt): the cells c0 .. c0 + cnt - 1 (cnt <= 8)
+// f(c0, cnt): the cells c0 .. c0 + cnt - 1 (cnt <= 8).  `ctr`: eight zeroed counters (one per XCD) -- the runs of an XCD's share are
+// handed out one at a time to whichever of its workgroups asks next.  A cell's cost is points x candidates and has a long tail (dense
+// patches near the scanner, 50 x 450 against a mean of 14 x 130), and dense cells are neighbours: with a static deal the workgroup that
+// drew them finished at 2.3 x the mean workgroup's time, and that was the kernel's time -- the counters of round 5 (SQ_WAVE_CYCLES: 44 %
+// of the launched waves resident on average, VALU issue 56 % of peak all the same; profiles/r05_fe_pmc_call3.txt).  One returning atomic
+// per 8 cells (round 2 popped single cells from ONE counter: 450 k serialised pops were the kernel's run time).
 template <typename F>
-__device__ inline void gh_pca_for_my_runs(int nc, F&& f) {
+__device__ inline void gh_pca_for_my_runs(int nc, int* __restrict__ ctr, F&& f) {
   const int grid = (int)gridDim.x, b = (int)blockIdx.x;
   const int nrun = (nc + 7) >> 3;
   if (grid < 8) {
@@ -75,7 +80,13 @@ __device__ inline void gh_pca_for_my_runs(int nc, F&& f) {
   }
   const int nlb = grid >> 3, xcd = b & 7, lb = b >> 3;
   if (lb >= nlb) return;  // grid not a multiple of 8: the last few workgroups stay idle
-  for (int r = lb; ((r >> 6) << 9) < nrun; r += nlb) {
+  for (int r = lb;; r += nlb) {
+    if (ctr) {
+      int t = 0;
+      if (threadIdx.x == 0) t = atomicAdd(&ctr[xcd], 1);
+      r = __builtin_amdgcn_readfirstlane(t);
+    }
+    if (((r >> 6) << 9) >= nrun) break;
     const int run = ((r >> 6) << 9) | (xcd << 6) | (r & 63);
     if (run >= nrun) continue;
     f(run << 3, min(8, nc - (run << 3)));
