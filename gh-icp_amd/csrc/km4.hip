@@ -61,7 +61,13 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const 
   for (int i = 0; i < nprob; i++) {
     const int n = std::max(1, h_n[i]);
     if (!gh_km4_fits(n)) return ctx->fail(GHICP_ERR_INTERNAL, "gh_km4_plan: n = %d does not fit", n);
-    key[i] = {(int)std::min<size_t>(8, (160 * 1024) / gh_km4_lds_bytes(n)), n};
+    // problems per CU by LDS, capped at FOUR: a solve slot is a 256-thread workgroup at 128 VGPRs, so a CU never holds more than four
+    // whatever their LDS.  Rounds 2-4 capped at eight: the graphs below n = 745 then formed four more classes, each with its own launch
+    // and queue, the classes took the chip in launch order (a persistent workgroup leaves only when ITS queue is dry), and the longest
+    // pairs of the later classes -- the cost order is per class -- started 5-6 s into an 11 s batch: 798 pairs running with every queue
+    // dry, a quarter of the slot-time idle (profiles/r04_slot_timeline_call4_hints.json).  One class for every graph that fits four
+    // per CU = one queue in cost order = longest-processing-time-first over (almost) the whole batch.
+    key[i] = {(int)std::min<size_t>(4, (160 * 1024) / gh_km4_lds_bytes(n)), n};
   }
   std::vector<int> order((size_t)nprob);
   for (int i = 0; i < nprob; i++) order[i] = i;
