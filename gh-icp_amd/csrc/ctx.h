@@ -153,6 +153,13 @@ struct ghicp_ctx {
   // every class launch of the persistent pair loop, so that a few slots take MANY pairs one after the other (state carried over in LDS)
   bool km_stats = false, km_force_hazard = false;
   int loop_slots_cap = 0;
+  // The class of graphs that fit only three per CU is CONFINED to a few CUs (a stream with a CU mask, made when first needed): a 50 KB
+  // slot between 40 KB slots leaves LDS holes no 40 KB slot fits, and a persistent slot never leaves -- a CU that has held one big slot
+  // stays at three slots for the rest of the batch (round 5, call 5: 811 of 1024 slots busy from second 3.5 to the end of an 11 s batch).
+  // GHICP_LOOP_CONFINE=0 switches it off (A/B measurements).
+  bool loop_confine = true;
+  hipStream_t confine_stream = nullptr, rest_stream = nullptr;  // masks: the confined class's CUs / all the others
+  int confine_cus = 0;
   int loop_min_lds = 0;  // GHICP_LOOP_MIN_LDS=<bytes> (experiment hook): every solve slot asks for at least this much LDS, e.g. 46080 = three slots per CU with 25 KB of every CU left to other kernels
   std::vector<uint32_t> cu_mask;       // set by ghicp_ctx_set_cu_mask: the auxiliary streams are restricted to the same compute units
   std::vector<hipStream_t> aux_streams;

@@ -40,6 +40,7 @@ extern "C" int ghicp_ctx_create(int device, ghicp_ctx** out) {
   c->km_stats = getenv("GHICP_KM_STATS") != nullptr;
   c->km_force_hazard = getenv("GHICP_KM_FORCE_HAZARD") != nullptr;
   if (const char* e = getenv("GHICP_LOOP_SLOTS")) c->loop_slots_cap = atoi(e) > 0 ? atoi(e) : 0;
+  if (const char* e = getenv("GHICP_LOOP_CONFINE")) c->loop_confine = atoi(e) != 0;
   if (const char* e = getenv("GHICP_LOOP_MIN_LDS")) c->loop_min_lds = atoi(e) > 0 ? atoi(e) : 0;
   if (hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) { delete c; return GHICP_ERR_HIP; }
   c->pinned_cap = 4096;
@@ -63,6 +64,8 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   if (ctx->job_event) (void)hipEventDestroy(ctx->job_event);
   if (ctx->fb_pinned) (void)hipHostFree(ctx->fb_pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->confine_stream) (void)hipStreamDestroy(ctx->confine_stream);
+  if (ctx->rest_stream) (void)hipStreamDestroy(ctx->rest_stream);
   for (hipStream_t a : ctx->aux_streams) (void)hipStreamDestroy(a);
   for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
   if (ctx->progress_host) (void)hipHostFree(ctx->progress_host);

@@ -87,6 +87,8 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const 
     int nmax = 1;  // (with cost hints the first problem of a class is its costliest, not its largest)
     for (int t = i; t < j; t++) nmax = std::max(nmax, key[order[t]].second);
     plan->lds[nc] = gh_km4_lds_bytes(nmax);
+    plan->per_cu[nc] = key[order[i]].first;
+    for (int t = i; t < j; t++) plan->weight[nc] += cost ? (double)cost[order[t]] : (double)key[order[t]].second * (double)key[order[t]].second;
     nc++;
     i = j;
   }

@@ -23,6 +23,8 @@ struct Km4Plan {
   int nclass = 0;
   int begin[8] = {0}, count[8] = {0};
   size_t lds[8] = {0};
+  int per_cu[8] = {0};      // problems per CU of the class by LDS (capped at four)
+  double weight[8] = {0};   // the class's share of the batch's work: sum of the cost hints, or of n^2 without hints
   int* d_order = nullptr;  // device: problem indices, class after class
 };
 // cost: optional per-problem cost hints (host, nprob floats): within a class the costliest problems are queued first

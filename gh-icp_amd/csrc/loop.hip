@@ -685,6 +685,8 @@ struct Carver {
 // mask (ghicp_ctx_set_cu_mask); a masked stream handed in through ghicp_ctx_set_stream is not inspected: documented in ghicp_c.h.)
 static void gh_join_aux(ghicp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->confine_stream) (void)hipStreamSynchronize(ctx->confine_stream);
+  if (ctx->rest_stream) (void)hipStreamSynchronize(ctx->rest_stream);
   for (hipStream_t a : ctx->aux_streams) (void)hipStreamSynchronize(a);
 }
 #define GH_HIP_JOIN(call)                                                                                     \
@@ -703,7 +705,7 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     else GH_HIP(hipExtStreamCreateWithCUMask(&a, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));  // stay on the context's compute units
     ctx->aux_streams.push_back(a);
   }
-  while ((int)ctx->aux_events.size() < nc + 1) {
+  while ((int)ctx->aux_events.size() < nc + 2) {
     hipEvent_t e = nullptr;
     GH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->aux_events.push_back(e);
@@ -728,18 +730,49 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     GH_TRY(ctx->reserve(B_KM_LSTAT, (size_t)ghicp_ctx::KM_LSTAT_MAX * ghicp_ctx::KM_LSTAT_W, &lstat));
     lstat += ctx->km_launches * ghicp_ctx::KM_LSTAT_W;
   }
+  // ---- two classes, three and four slots per CU: the three-per-CU class on its own CUs (see ghicp_ctx::loop_confine).  Their number follows
+  // the class's share w of the batch's work: 3 B slots of 3 B + 4 (CUs - B) should do w of it, with a margin of 15 % (its queue must not
+  // outlast the other one: the four-per-CU slots may use every CU, the confined ones only theirs), spread evenly over the mask's bits.
+  int confine_b = 0;
+  if (ctx->loop_confine && nc == 2 && plan.per_cu[0] == 3 && plan.per_cu[1] == 4 && plan.count[0] > 0 && plan.count[1] > 0 && ctx->cu_mask.empty() &&
+      ctx->num_cu >= 8 && ctx->num_cu <= 2048 && plan.weight[0] > 0 && plan.weight[1] > 0) {
+    const double w = std::min(0.9, 1.15 * plan.weight[0] / (plan.weight[0] + plan.weight[1]));
+    int B = (int)std::ceil(w * 4.0 * ctx->num_cu / (3.0 + w));
+    B = std::max(B, (plan.count[0] >= 3 ? 1 : 0));
+    B = std::min(B, std::min(ctx->num_cu / 2, cdiv(plan.count[0], 3)));
+    if (B >= 1) {
+      if (ctx->confine_stream == nullptr || ctx->rest_stream == nullptr || ctx->confine_cus != B) {
+        for (hipStream_t* ps : {&ctx->confine_stream, &ctx->rest_stream})
+          if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
+        ctx->confine_cus = 0;
+        std::vector<uint32_t> mask((size_t)cdiv(ctx->num_cu, 32), 0u), rest((size_t)cdiv(ctx->num_cu, 32), 0u);
+        for (int i = 0; i < ctx->num_cu; i++) {
+          const bool in = (long long)(i + 1) * B / ctx->num_cu > (long long)i * B / ctx->num_cu;
+          (in ? mask : rest)[(size_t)i >> 5] |= 1u << (i & 31);
+        }
+        if (hipExtStreamCreateWithCUMask(&ctx->confine_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&ctx->rest_stream, (uint32_t)rest.size(), rest.data()) == hipSuccess)
+          ctx->confine_cus = B;
+      }
+      if (ctx->confine_cus == B) confine_b = B;
+    }
+  }
   hipEvent_t kt = ctx->kt_begin(KT_PAIR_LOOP);
   GH_HIP_JOIN(hipEventRecord(ctx->aux_events[0], s));
   for (int c = 0; c < nc; c++) {
     if (plan.count[c] <= 0) continue;
-    hipStream_t sc = c == 0 ? s : ctx->aux_streams[(size_t)c - 1];
-    if (c > 0) GH_HIP_JOIN(hipStreamWaitEvent(sc, ctx->aux_events[0], 0));
+    // confined: the three-per-CU class on its CUs; the four-per-CU class on all the OTHER CUs (if it could use every CU, its slots would
+    // take the confined class's CUs first and never leave) and, behind the confined class in stream order, on those CUs as well -- the
+    // same queue, so the late slots help drain it
+    const bool confined = confine_b > 0;
+    hipStream_t sc = confined ? (c == 0 ? ctx->confine_stream : ctx->rest_stream) : (c == 0 ? s : ctx->aux_streams[(size_t)c - 1]);
+    if (c > 0 || confined) GH_HIP_JOIN(hipStreamWaitEvent(sc, ctx->aux_events[0], 0));
     const size_t lds = std::max(std::max(plan.lds[c], (size_t)PL_SCRATCH + 64), (size_t)ctx->loop_min_lds);
     int per_cu = 0;
     GH_HIP_JOIN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, K4_T, lds));
     if (per_cu <= 0) gh_join_aux(ctx);
     if (per_cu <= 0) return ctx->fail(GHICP_ERR_INTERNAL, "pair loop: a workgroup with %zu bytes of LDS does not fit a CU", lds);
-    const int slots = per_cu * ctx->num_cu;
+    const int slots = per_cu * (confined ? (c == 0 ? confine_b : ctx->num_cu - confine_b) : ctx->num_cu);
     int grid = std::min(plan.count[c], slots);
     if (ctx->loop_slots_cap > 0) grid = std::min(grid, ctx->loop_slots_cap);  // test hook (GHICP_LOOP_SLOTS)
     batch_slots = std::max(batch_slots, slots);
@@ -751,9 +784,22 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
       hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
                          dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
     GH_HIP_JOIN(hipGetLastError());
-    if (c > 0) {
+    if (c > 0 || confined) {
       GH_HIP_JOIN(hipEventRecord(ctx->aux_events[(size_t)c + 1], sc));
       GH_HIP_JOIN(hipStreamWaitEvent(s, ctx->aux_events[(size_t)c + 1], 0));
+    }
+    if (confined && c == 1) {  // ... and the four-per-CU class once more, on the confined CUs, after the three-per-CU class
+      const int grid2 = std::min(plan.count[c], per_cu * confine_b);
+      if (prof)
+        hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid2), dim3(K4_T), lds, ctx->confine_stream, dprobs, (const int*)(plan.d_order + plan.begin[c]),
+                           plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+      else
+        hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid2), dim3(K4_T), lds, ctx->confine_stream, dprobs, (const int*)(plan.d_order + plan.begin[c]),
+                           plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+      GH_HIP_JOIN(hipGetLastError());
+      batch_grid += grid2;
+      GH_HIP_JOIN(hipEventRecord(ctx->aux_events[(size_t)nc + 1], ctx->confine_stream));
+      GH_HIP_JOIN(hipStreamWaitEvent(s, ctx->aux_events[(size_t)nc + 1], 0));
     }
   }
   ctx->kt_end(KT_PAIR_LOOP, kt);

@@ -273,7 +273,8 @@ def test_pair_loop_persistent_batch(ctx, api, synth, oracle):
     cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, dof=6, est_iou=0.6, voxel=0.2, pattern=pat, max_iter=25)
     p = synth.gauss_pair(n_kp=1000)
     bbx = float(oracle.bbx_magnitude(p.source))
-    shapes = [(600, 700), (150, 100), (40, 300), (900, 880), (64, 64), (0, 50), (300, 310), (2, 3)]
+    # (940, 930): a graph of the three-per-CU class beside the four-per-CU ones -- the launch that confines that class to its own CUs (round 5)
+    shapes = [(600, 700), (150, 100), (40, 300), (940, 930), (64, 64), (0, 50), (300, 310), (2, 3)]
     clouds, refs = [], []
     for ks, kt in shapes:
         kpS = p.source[p.kp_source[:ks]].astype(np.float64)
