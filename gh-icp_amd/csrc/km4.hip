@@ -88,7 +88,9 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const 
     for (int t = i; t < j; t++) nmax = std::max(nmax, key[order[t]].second);
     plan->lds[nc] = gh_km4_lds_bytes(nmax);
     plan->per_cu[nc] = key[order[i]].first;
-    for (int t = i; t < j; t++) plan->weight[nc] += cost ? (double)cost[order[t]] : (double)key[order[t]].second * (double)key[order[t]].second;
+    // (a pair's time in a slot goes with iterations x n rather than x n^2 -- a solve of n = 1131 takes 1.25 x one of n = 840 --, so callers
+    // hint with that, and without hints the share of a class is its share of the rows)
+    for (int t = i; t < j; t++) plan->weight[nc] += (cost && cost[order[t]] > 0.f) ? (double)cost[order[t]] : (double)key[order[t]].second;
     nc++;
     i = j;
   }

@@ -101,10 +101,12 @@ int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8);
  * (1 - slot lifetimes / (resident slots x span): the tail of a batch), share of the slot lifetimes spent inside Kuhn-Munkres solves }. */
 int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8);
 /* Scheduling hint for the NEXT batched Kuhn-Munkres registration on this context (ghicp_register_clouds / ghicp_register_pairs with
- * exactly n_pairs pairs; consumed by that call, ignored otherwise): cost[i] = expected relative cost of pair i, e.g. the iterations the
- * same pair needed last time, or any prior.  The solve slots of the persistent pair loop take the costliest pairs of each LDS class
- * first, so that the slowest registrations (112 iterations against a mean of 35 on the TLS bench scenes) do not start in the middle of
- * a batch and leave the chip to a handful of stragglers.  Results do not depend on the hints (pairs share nothing); [host] array. */
+ * exactly n_pairs pairs; consumed by that call, ignored otherwise): cost[i] = expected relative TIME of pair i in a solve slot, e.g.
+ * iterations x keypoints of the same pair last time, or any prior.  The solve slots of the persistent pair loop take the costliest pairs
+ * of each class first (graphs that fit four slots per CU form ONE class, i.e. one queue: longest processing time first over the batch),
+ * so that the slowest registrations (112 iterations against a mean of 35 on the TLS bench scenes) do not start in the middle of a batch
+ * and leave the chip to a handful of stragglers; the share of the CUs the three-slots-per-CU class is confined to follows the hints'
+ * sums.  Results do not depend on the hints (pairs share nothing); [host] array. */
 int ghicp_ctx_set_loop_cost_hints(ghicp_ctx* ctx, int32_t n_pairs, const float* cost);
 /* Diagnostics: the slot timeline of the LAST persistent batch that ran on this context while kernel timing was on -- per pair of the
  * batch (in the order of the call) three int64: when a solve slot took the pair, when it let go (device real-time clock, 100 MHz ticks),
