@@ -67,7 +67,9 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const 
     // pairs of the later classes -- the cost order is per class -- started 5-6 s into an 11 s batch: 798 pairs running with every queue
     // dry, a quarter of the slot-time idle (profiles/r04_slot_timeline_call4_hints.json).  One class for every graph that fits four
     // per CU = one queue in cost order = longest-processing-time-first over (almost) the whole batch.
-    key[i] = {(int)std::min<size_t>(4, (160 * 1024) / gh_km4_lds_bytes(n)), n};
+    // (4 KB of the 160 are left out of the count: four slots of exactly 40 KB fit a CU only when the allocator packs them without a gap --
+    // call 7: the four-per-CU class at 40.6 KB ran at 3.1 slots per CU on its CUs, 3.8 in call 6 -- so a class's slots must fit with room)
+    key[i] = {(int)std::min<size_t>(4, (156 * 1024) / gh_km4_lds_bytes(n)), n};
   }
   std::vector<int> order((size_t)nprob);
   for (int i = 0; i < nprob; i++) order[i] = i;

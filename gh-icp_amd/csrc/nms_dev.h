@@ -13,13 +13,10 @@
 //       previous wave of this chunk just added, then resolves its own 64 lanes greedily with ballots -- the lowest
 //       surviving lane is selected, its coordinates are broadcast with v_readlane, lanes within R die, repeat;
 //   (3) winners are appended (rank order) to the output, the LDS list and the global grid.
-//   Round 5: while the column lists are in use (every cfg2-sized cloud), a chunk is 1024 candidates: all four waves pre-test four candidates
-//   each against the keypoints selected so far and park them (coordinates + alive flag) in LDS; then ONE wave walks the chunk's sixteen
-//   groups of 64 in rank order -- groups without a survivor are skipped; a survivor is first re-tested against the column lists, which by
-//   then hold the winners of the earlier groups of this chunk, then the in-wave greedy as before.  Two barriers per 1024 candidates instead
-//   of five per 256, and no hand-over of the selected count between waves: the sweep is a dependency chain, what it cost was its barriers.
+//   (Round 5, measured and dropped: chunks of 1024 candidates with ONE wave walking the sixteen groups of survivors in rank order after a
+//   parallel pre-test -- two barriers per 1024 candidates instead of five per 256 -- 1.62 -> 2.48 ms per 32 clouds: the second look into the
+//   column lists and the serial groups cost more than the barriers they replace; profiles/r05_kernel_stats_fe_one_stream_call7.txt.)
 constexpr int NMS_T = 256;
-constexpr int NMS_BIG = 1024;      // candidates per chunk on the column-list path
 constexpr int NMS_SEL_CAP = 3072;  // selected keypoints kept in LDS as float4 (48 KB)
 constexpr int NMS_COL_CAP = 16384; // (x, y) columns with an LDS list head (32 KB): 190 m x 190 m at R = 1.5 m
 constexpr unsigned short NMS_NONE = 0xFFFF;
@@ -31,7 +28,6 @@ __device__ inline void gh_nms_greedy_cloud(const float* __restrict__ cpts, int c
   __shared__ float4 sel_pts[NMS_SEL_CAP];
   __shared__ unsigned short col_head[NMS_COL_CAP], sel_next[NMS_SEL_CAP];
   __shared__ int s_nsel;
-  __shared__ float4 s_chunk[NMS_BIG];  // the chunk's candidates: x, y, z, alive (1.f / 0.f)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncol = g.dim[0] * g.dim[1];
   const bool cols = ncol <= NMS_COL_CAP;
@@ -72,77 +68,7 @@ __device__ inline void gh_nms_greedy_cloud(const float* __restrict__ cpts, int c
           }
     return false;
   };
-  int base = 0;
-  // ---- column-list path: chunks of NMS_BIG candidates (see the header)
-  while (cols && base < c && s_nsel <= NMS_SEL_CAP - NMS_BIG) {  // (every winner of the chunk must fit the LDS list: at most NMS_BIG more)
-    for (int u = 0; u < NMS_BIG / NMS_T; u++) {
-      const int r = base + u * NMS_T + tid;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < c) {
-        q.x = cpts[(size_t)r * 3]; q.y = cpts[(size_t)r * 3 + 1]; q.z = cpts[(size_t)r * 3 + 2];
-        q.w = col_hit(q.x, q.y, q.z) ? 0.f : 1.f;
-      }
-      s_chunk[u * NMS_T + tid] = q;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      int nsel = s_nsel;
-      for (int gq = 0; gq < NMS_BIG / 64 && base + gq * 64 < c; gq++) {
-        const float4 q = s_chunk[gq * 64 + lane];
-        const float px = q.x, py = q.y, pz = q.z;
-        const int r = base + gq * 64 + lane;
-        bool alive = q.w != 0.f;
-        if (!__ballot(alive)) continue;
-        if (alive) alive = !col_hit(px, py, pz);  // the winners of the earlier groups of this chunk are in the column lists by now
-        unsigned long long m = __ballot(alive);
-        unsigned long long picked = 0ull;
-        while (m) {  // in-wave greedy over rank-ordered lanes
-          const int k = (int)__ffsll((long long)m) - 1;
-          picked |= 1ull << k;
-          const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), k));
-          const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), k));
-          const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), k));
-          if (alive && lane > k) {
-            const float dx = sx - px, dy = sy - py, dz = sz - pz;
-            float d2 = dx * dx;
-            d2 += dy * dy;
-            d2 += dz * dz;
-            if (d2 < r2) alive = false;
-          }
-          m = __ballot(alive) & ~((2ull << k) - 1ull);
-        }
-        if (!picked) continue;
-        const bool sel = (picked >> lane) & 1ull;
-        const int pos = nsel + __popcll(picked & ((1ull << lane) - 1ull));
-        if (sel) {
-          kp[pos] = cand[ord[r]] - idx_sub;
-          sel_pts[pos] = make_float4(px, py, pz, 0.f);
-          const int cx = gh_cell_coord(px, g.mn[0], g.inv, g.dim[0]);
-          const int cy = gh_cell_coord(py, g.mn[1], g.inv, g.dim[1]);
-          const int cz = gh_cell_coord(pz, g.mn[2], g.inv, g.dim[2]);
-          const int old = atomicExch(&head[((unsigned)cx * g.dim[1] + cy) * g.dim[2] + cz], r);
-          __hip_atomic_store(&next[r], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        for (unsigned long long pk = picked; pk; pk &= pk - 1ull) {  // into the column lists, one at a time (two winners may share a column)
-          const int k = (int)__ffsll((long long)pk) - 1;
-          if (lane == k) {
-            const int col = gh_cell_coord(px, g.mn[0], g.inv, g.dim[0]) * g.dim[1] + gh_cell_coord(py, g.mn[1], g.inv, g.dim[1]);
-            sel_next[pos] = col_head[col];
-            col_head[col] = (unsigned short)pos;
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-        __threadfence_block();  // the next group's re-test reads the lists this group's winners just joined
-        nsel += __popcll(picked);
-      }
-      __threadfence_block();
-      if (lane == 0) s_nsel = nsel;
-    }
-    __syncthreads();
-    base += NMS_BIG;
-  }
-  // ---- chunks of 256 (clouds without column lists, or with more keypoints than the LDS list holds)
-  for (; base < c; base += NMS_T) {
+  for (int base = 0; base < c; base += NMS_T) {
     const int r = base + tid;
     bool alive = r < c;
     float px = 0, py = 0, pz = 0;
