@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--group", type=int, default=0, help="1: build the process group even for ONE rank, so that the manifest broadcast and the all-gather of the "
                     "result records run through the chosen backend (RCCL with --backend nccl) on a single GPU; default: a group only when WORLD_SIZE > 1")
     ap.add_argument("--queue-hints", type=int, default=1, help="1: the persistent pair loop queues the pairs of a batch costliest first, the cost being what the SAME pair "
-                    "needed in the previous step (iterations x n; ghicp_ctx_set_loop_cost_hints): the 112-iteration pairs start first instead of in the middle "
+                    "needed in the previous step (iterations x n^2; ghicp_ctx_set_loop_cost_hints): the 112-iteration pairs start first instead of in the middle "
                     "of a batch.  0: largest graph first (no history).  Results do not depend on the order")
     ap.add_argument("--no-hints-steps", type=int, default=2, help="steps of each of the two comparison regions run AFTER the timed one (with and without the queue-order "
                     "prior) that give `value_no_hints`; 0 skips them")
@@ -499,9 +499,9 @@ def main():
                         loop_ctxs[gp].set_loop_cost_hints(pair_cost[g])
                     r = loop_ctxs[gp].register_clouds(cfg, pool_h[k % NBUF][bounds[g]:bounds[g + 1]]) if n_g else []
                     if n_g:
-                        # what the same pair cost last time, as a prior for the queue order and the classes' shares of the chip: a pair's time
-                        # in a solve slot goes with iterations x n (a solve of n = 1131 takes 1.25 x one of n = 840), not with x n^2
-                        pair_cost[g] = [float(st.iterations) * float(max(st.k_s, st.k_t)) for st in r]
+                        # what the same pair cost last time, as a prior for the queue order and the classes' shares of the chip
+                        # (iterations x n, calls 7 and 8 of round 5, scheduled worse than iterations x n^2: profiles/r05_call7_log.txt)
+                        pair_cost[g] = [float(st.iterations) * float(max(st.k_s, st.k_t)) ** 2 for st in r]
                     if n_g:
                         final_transform(gp, [mine[i] for i in range(bounds[g], bounds[g + 1])], r)
                         loop_ctxs[gp].sync()
@@ -671,7 +671,7 @@ def main():
     for c in ctxs:
         c.kernel_timing(False)
 
-    # ---- what the queue-order prior is worth (round-4 verdict, weak #7): the headline's queue order uses iterations x n of the SAME pair in
+    # ---- what the queue-order prior is worth (round-4 verdict, weak #7): the headline's queue order uses iterations x n^2 of the SAME pair in
     # the previous step, which a first-time caller does not have.  After the timed region: E more steps with the prior, E without ("largest
     # graph first"), each region timed like the headline; `value_no_hints` = value x (rate without / rate with) over regions of equal length
     # (a short region pays the pipeline's fill once, so it is compared with an equally short one, not with the headline directly).
@@ -920,7 +920,7 @@ def main():
                    "config_id": args.config, "fe_batch": args.fe_batch, "pairs_per_step": n_job if strong else nb, "distinct_scenes": len(by_scene),
                    "n_s": int(sts[0].n_s), "m_mean": round(m_mean), "k_mean": round(k_mean, 1), "n_km_max": int(max(max(s.k_s, s.k_t) for s in sts)),
                    "iterations_mean": round(it_mean, 1), "iterations_min_max": [int(min(s.iterations for s in sts)), int(max(s.iterations for s in sts))],
-                   "queue_order": ("costliest first, cost = iterations x n of the same pair in the previous step" if args.queue_hints and CF["corr"] == "KM" and not dynamic
+                   "queue_order": ("costliest first, cost = iterations x n^2 of the same pair in the previous step" if args.queue_hints and CF["corr"] == "KM" and not dynamic
                                    else "largest graph first"),
                    "parallelism": "pairs sharded over ranks (%s), no data-path collective" % args.queue, "backend": args.backend if dist is not None else None},
         "registered_ok": {"pairs_per_step_rank0": nb_eff, "reference_verdict_ok": int(reg_ok_pairs), "gt_ok": int(gt_ok_pairs),

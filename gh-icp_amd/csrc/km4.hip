@@ -67,9 +67,9 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const 
     // pairs of the later classes -- the cost order is per class -- started 5-6 s into an 11 s batch: 798 pairs running with every queue
     // dry, a quarter of the slot-time idle (profiles/r04_slot_timeline_call4_hints.json).  One class for every graph that fits four
     // per CU = one queue in cost order = longest-processing-time-first over (almost) the whole batch.
-    // (4 KB of the 160 are left out of the count: four slots of exactly 40 KB fit a CU only when the allocator packs them without a gap --
-    // call 7: the four-per-CU class at 40.6 KB ran at 3.1 slots per CU on its CUs, 3.8 in call 6 -- so a class's slots must fit with room)
-    key[i] = {(int)std::min<size_t>(4, (156 * 1024) / gh_km4_lds_bytes(n)), n};
+    // (measured and dropped, call 8: leaving 4 KB of the 160 out of the count -- n <= 902 instead of <= 924 in the four-per-CU class --
+    // did not bring its CUs to four slots each: 3.3 per CU, 384 pairs/s; the rule of call 6 stays)
+    key[i] = {(int)std::min<size_t>(4, (160 * 1024) / gh_km4_lds_bytes(n)), n};
   }
   std::vector<int> order((size_t)nprob);
   for (int i = 0; i < nprob; i++) order[i] = i;
@@ -90,9 +90,7 @@ int gh_km4_plan(ghicp_ctx* ctx, const int* h_n, int nprob, Km4Plan* plan, const 
     for (int t = i; t < j; t++) nmax = std::max(nmax, key[order[t]].second);
     plan->lds[nc] = gh_km4_lds_bytes(nmax);
     plan->per_cu[nc] = key[order[i]].first;
-    // (a pair's time in a slot goes with iterations x n rather than x n^2 -- a solve of n = 1131 takes 1.25 x one of n = 840 --, so callers
-    // hint with that, and without hints the share of a class is its share of the rows)
-    for (int t = i; t < j; t++) plan->weight[nc] += (cost && cost[order[t]] > 0.f) ? (double)cost[order[t]] : (double)key[order[t]].second;
+    for (int t = i; t < j; t++) plan->weight[nc] += (cost && cost[order[t]] > 0.f) ? (double)cost[order[t]] : (double)key[order[t]].second * (double)key[order[t]].second;
     nc++;
     i = j;
   }

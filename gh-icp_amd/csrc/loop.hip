@@ -731,12 +731,12 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     lstat += ctx->km_launches * ghicp_ctx::KM_LSTAT_W;
   }
   // ---- two classes, three and four slots per CU: the three-per-CU class on its own CUs (see ghicp_ctx::loop_confine).  Their number follows
-  // the class's share w of the batch's work: 3 B slots of 3 B + 4 (CUs - B) should do w of it, with a margin of 20 % (calls 6 and 7: the x n^2 prior gave the class 30 % too many CUs, x n with 10 % margin a tenth too few) (its queue must not
+  // the class's share w of the batch's work: 3 B slots of 3 B + 4 (CUs - B) should do w of it, with a margin of 15 % on the caller's prior (iterations x n^2 in bench.py: measured, call 6 -- 392.9 -> 421.5 pairs/s on one box; the prior iterations x n with 10-20 % margin, calls 7 and 8, gave the class fewer CUs and the batch a longer span: 375-384) (its queue must not
   // outlast the other one: the four-per-CU slots may use every CU, the confined ones only theirs), spread evenly over the mask's bits.
   int confine_b = 0;
   if (ctx->loop_confine && nc == 2 && plan.per_cu[0] == 3 && plan.per_cu[1] == 4 && plan.count[0] > 0 && plan.count[1] > 0 && ctx->cu_mask.empty() &&
       ctx->num_cu >= 8 && ctx->num_cu <= 2048 && plan.weight[0] > 0 && plan.weight[1] > 0) {
-    const double w = std::min(0.9, 1.20 * plan.weight[0] / (plan.weight[0] + plan.weight[1]));
+    const double w = std::min(0.9, 1.15 * plan.weight[0] / (plan.weight[0] + plan.weight[1]));
     int B = (int)std::ceil(w * 4.0 * ctx->num_cu / (3.0 + w));
     B = std::max(B, (plan.count[0] >= 3 ? 1 : 0));
     B = std::min(B, std::min(ctx->num_cu / 2, cdiv(plan.count[0], 3)));
