@@ -1,8 +1,7 @@
 #!/bin/bash
 # Round 5, final GPU call (~28 GPU-minutes) on the final tree, most important first: the whole GPU test suite; the default bench (cfg2) with the CPU
 # legs, the parity check of all 64 scenes and the no-hints comparison regions; a rocprofv3 kernel trace of the default command; FETCH_SIZE /
-# WRITE_SIZE passes of the default command (counters only, one per run); cfg4 with its CPU legs; the front end alone on one stream (uncontended
-# kernel times); cfg3 and cfg5 with their CPU legs ON THIS BOX (round-4 verdict: they had been timed on the build container).
+# WRITE_SIZE passes of the default command (counters only, one per run); cfg4 with its CPU legs; cfg3 and cfg5 with their CPU legs ON THIS BOX (round-4 verdict: they had been timed on the build container).
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -27,10 +26,6 @@ done
 cd $R
 timeout 400 python bench.py --config 4 --steps 4 --warmup 1 > $O/r05_bench_cfg4.json 2> $O/r05_bench_cfg4.err
 echo "bench cfg4 rc=$?"; tail -c 1500 $O/r05_bench_cfg4.json | cut -c1-1500
-cd /tmp
-B1="python $R/bench.py --steps 1 --warmup 1 --distinct 8 --pairs-per-step 512 --cpu-baseline 0 --no-hints-steps 0 --fe-batch 32 --fe-batch-streams 1 --fe-streams 1 --pipeline 0 --scene-cache /tmp/scenes64"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fe -o a -- $B1 > $O/r05_bench_rocprof_fe1.json 2> $O/r05_rocprof_fe.err
-python $R/scripts/rocprof_summary.py /tmp/prof_fe $O/r05_kernel_stats_fe_one_stream_final.txt "$B1" | head -14 | cut -c1-160
 cd $R
 timeout 600 python bench.py --config 3 --steps 2 --warmup 1 --cpu-procs 16 > $O/r05_bench_cfg3.json 2> $O/r05_bench_cfg3.err
 echo "bench cfg3 rc=$?"; tail -c 2500 $O/r05_bench_cfg3.json | cut -c1-2500
