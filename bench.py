@@ -912,11 +912,13 @@ def main():
     # fraction measured on rank 0's share (every rank cycles the same kind of scenes); the rate of all pairs pushed through is value_all_pairs
     rate_all = value
     value = rate_all * reg_ok_pairs / nb_eff
+    workload_fmt = ("%s, voxel %g " + ("cm" if CF.get("unit_m", 1.0) == 0.01 else "m") +
+                    ", r_pca %g, R_nms %g, %s+%s, %d-DoF; %d distinct scenes/GPU cycled over %d pairs/step%s; front end: %s; loops: %d group(s)")
     out = {
         "metric": "registered_pairs_per_sec", "value": round(value, 4), "value_all_pairs": round(rate_all, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": CF["scaling"], "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s, voxel %g " + ("cm" if CF.get("unit_m", 1.0) == 0.01 else "m") + ", r_pca %g, R_nms %g, %s+%s, %d-DoF; %d distinct scenes/GPU cycled over %d pairs/step%s; front end: %s; loops: %d group(s)"
+        "config": {"workload": workload_fmt
                                % (CF["name"], CF["voxel"], CF["r"], CF["R"], CF["feature"], CF["corr"], CF["dof"], len(by_scene),
                                   nb, " (job: %d over the ranks)" % n_job if strong else "/GPU",
                                   "%d clouds/launch sequence x %d streams" % (args.fe_batch, fe_n) if args.fe_batch > 1 else "cloud by cloud x %d streams" % fe_n, G),
