@@ -6,7 +6,7 @@
 
 #include <cstdlib>
 
-constexpr int PCA_CHUNK = 512;  // LDS tile of neighbour points (8 KB: 5 waves per SIMD)
+constexpr int PCA_CHUNK = 512;  // LDS tile of neighbour points (8 KB; a block stays resident in it up to 448 points: PCA_PAD)
 
 // CHUNK only sets how many neighbour points are staged per barrier pair.
 // Lane layout: a 0.5 m cell holds ~16 points, so one lane per query point would leave three quarters of the wave idle in the candidate
