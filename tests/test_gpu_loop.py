@@ -382,3 +382,49 @@ def test_one_slot_takes_many_pairs_in_any_order(api, synth, oracle, order):
         b.close()
     c.close()
     ref.close()
+
+
+def test_confined_three_per_cu_class_changes_nothing_but_the_schedule(api, synth, oracle):
+    """Round 5: graphs that fit only three slots per CU run on their own CUs (masked streams, loop.hip:run_pair_loop) and the four-per-CU
+    class on the others -- where a slot runs cannot reach a result: the same batch through a context with GHICP_LOOP_CONFINE=0 (one launch per
+    class on every CU, as in round 4) and through a default context gives the same iterations and the same 4x4 bits, pair by pair."""
+    import os
+
+    import torch
+
+    if os.environ.get("GHICP_SIM") != "1" and not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rng = np.random.default_rng(33)
+    pat = synth.bsc_pattern_glibc()
+    cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, dof=6, est_iou=0.6, voxel=0.2, pattern=pat, max_iter=4)
+    p = synth.gauss_pair(n_kp=1000)
+    bbx = float(oracle.bbx_magnitude(p.source))
+    shapes = [(940, 930), (600, 700), (300, 310), (950, 900), (120, 100)]
+    feats = []
+    for ks, kt in shapes:
+        fS = rng.integers(0, 256, size=(4, ks, 56), dtype=np.uint8)
+        fT = rng.integers(0, 256, size=(4, kt, 56), dtype=np.uint8)
+        m = min(ks, kt)
+        fT[0, :m] = fS[0, :m] ^ (rng.random((m, 56)) < 0.03).astype(np.uint8)
+        feats.append((p.source[p.kp_source[:ks]].astype(np.float64), fS, p.target[p.kp_target[:kt]].astype(np.float64), fT))
+    results = []
+    for confine in ("0", "1"):
+        os.environ["GHICP_LOOP_CONFINE"] = confine  # read once, when the context is created
+        try:
+            if os.environ.get("GHICP_SIM") == "1":
+                from hipsim import simctx
+
+                c = simctx.make_context(api)
+            else:
+                c = api.Context(0)
+        finally:
+            del os.environ["GHICP_LOOP_CONFINE"]
+        clouds = [(c.cloud_from_features(cfg, kS, fS, bbx), c.cloud_from_features(cfg, kT, fT, bbx)) for kS, fS, kT, fT in feats]
+        c.set_loop_cost_hints([float(max(ks, kt)) ** 2 for ks, kt in shapes])
+        results.append([(st.iterations, st.converged, list(st.Rt)) for st in c.register_clouds(cfg, clouds)])
+        for a, b in clouds:
+            a.close()
+            b.close()
+        c.close()
+    assert max(r[0] for r in results[0]) >= 2
+    assert results[0] == results[1]
