@@ -197,6 +197,8 @@ def main():
                     "-1 = calibrate: time both front ends on a sample before the warm-up and use the faster one")
     ap.add_argument("--fe-batch-size", type=int, default=32, help="clouds per launch sequence when --fe-batch -1 picks the batched front end")
     ap.add_argument("--fe-batch-streams", type=int, default=4, help="worker contexts of the batched front end")
+    ap.add_argument("--cpu-check", type=int, default=1, help="0: the CPU legs only TIME the restatement (no second run with the contract build, no parity_check): for the 5 M / "
+                    "10 M configurations when box time is short -- their parity at full size is asserted by tests/test_gpu_fullsize.py")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the many-core CPU leg (0 = 64, capped by the host's logical CPUs; the distinct scenes are cycled)")
     ap.add_argument("--scene-cache", default="", help="directory that keeps the generated synthetic scenes between runs (the generation is untimed)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the pair queue: nccl (= RCCL over xGMI, one rank per GPU) or "
@@ -856,7 +858,7 @@ def main():
         with mp.get_context("spawn").Pool(procs) as pool:
             # (the 5 M configuration checks ONE scene against the contract build here, the 10 M one none -- a second 1-4 minute run per scene
             # otherwise --; their parity at full size is tests/test_gpu_fullsize.py's, against committed oracle fixtures)
-            ora_all = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at, j < ((1 if hits < 8_000_000 else 0) if big else len(ids))) for j, sid in enumerate(jobs_cpu)], chunksize=1)
+            ora_all = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at, j < (0 if not args.cpu_check else ((1 if hits < 8_000_000 else 0) if big else len(ids)))) for j, sid in enumerate(jobs_cpu)], chunksize=1)
         wall = max(r["t1"] for r in ora_all) - min(r["t0"] for r in ora_all)
         if big:
             one = [r["seconds"] for r in ora_all]
@@ -894,7 +896,7 @@ def main():
                  "tolerance": "1e-4 rot (||R_gpu R_cpu^T - I||_F), 1e-3 m", "pairs_outside_tolerance": bad[:16],
                  "all_ok": (not bad) and it_ok == len(ora) and kp_ok == len(ora) and ok_ok == len(ora)}
         if not ora:
-            check = {"pairs_checked": 0, "note": "no scene re-run with the contract build in this run (10 M points: minutes per scene); parity at full size: tests/test_gpu_fullsize.py"}
+            check = {"pairs_checked": 0, "note": "no scene re-run with the contract build in this run (--cpu-check 0, or 10 M points: minutes per scene); parity at full size: tests/test_gpu_fullsize.py"}
 
     # ---- success accounting: the reference's own verdict (ghicp_reg.cpp:918-924) and the distance from ground truth
     gt = {sid: (synth.rot_err(np.array(st.Rt[:]).reshape(4, 4), scene[sid][2]), synth.trans_err(np.array(st.Rt[:]).reshape(4, 4), scene[sid][2]))
