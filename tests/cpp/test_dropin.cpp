@@ -90,7 +90,9 @@ int main(int argc, char** argv) {
     if (!fpfhS_k->points.empty() && !fpfhT_k->points.empty())
       printf("FPFHD %.9g\n", fpfh.compute_fpfh_distance(fpfhS_k->points[0].histogram, fpfhT_k->points[0].histogram));
   } else {
-    BSCEncoder<Point_T> bsc(1.5f, 7, true);  // glibc rand() sample pattern (Q2)
+    // default: the reference's READ path (bfe:103-115) -- ./sample_pattern.txt, written by the caller; "rand": the pattern drawn from
+    // rand() and written out (bfe:75-101, Q2), whose sequence depends on how often the process called rand() before (the HIP runtime does)
+    BSCEncoder<Point_T> bsc(1.5f, 7, argc > 4 && std::strcmp(argv[4], "rand") == 0);
     doubleVectorSBF bscT, bscS;
     bsc.extractBinaryFeatures(T, kT, 0, bscT);
     bsc.extractBinaryFeatures(S, kS, 6, bscS);
@@ -132,6 +134,8 @@ int main(int argc, char** argv) {
     printf("OVERLAP %.9g\n", creg.calOverlap(S1, T, 0.3f));
     const bool ok = creg.icp_reg(S1, T, S2, Ticp, 20, false, true, 0.3f, 0.1f);
     creg.invTransform(Ticp, Tinv);
+    printf("ICPSTATS done %d overlap %.9g\n", creg.last_stats.done, creg.last_stats.overlap);
+    if (!ok) Ticp = Rf;  // a refused registration leaves the caller's matrix alone (common_reg.cpp:66-70): print something defined
     printf("ICP %d %d %d %zu", ok ? 1 : 0, creg.last_stats.iterations, creg.last_stats.reason, S2->points.size());
     for (int i = 0; i < 16; i++) printf(" %.9g", Ticp(i / 4, i % 4));
     printf("\n");

@@ -121,3 +121,71 @@ def test_trimmed_rejector_splits_ties_by_index(ctx, api, oracle, synth):
         np.testing.assert_allclose(rg["mse"], ro["mse"], rtol=1e-9)
         assert rot_err(rg["T"].astype(np.float64), ro["T"].astype(np.float64)) <= 5e-6
         assert trans_err(rg["T"].astype(np.float64), ro["T"].astype(np.float64)) <= 5e-5
+
+
+def test_overlap_of_icp_equals_cal_overlap_back_to_back_in_host_pointer_mode(ctx, api, oracle, synth):
+    """Round-5 verdict, weak #1 (ii): CRegistration::calOverlap and then icp_reg on the SAME two host arrays (tests/cpp/test_dropin.cpp), in
+    host-pointer mode, right after a Kuhn-Munkres registration on the same context -- the second call finds both clouds in the staged-input
+    cache (ctx.h).  The ratio ghicp_icp computes for itself (common_reg.cpp:64-74) must be the float ghicp_cal_overlap returned, bit for
+    bit, and `done` must flip exactly at min_overlap_for_reg == that float (`ratio < min_overlap` refuses, common_reg.cpp:66)."""
+    import ctypes as C
+
+    if getattr(ctx, "simulated", False):
+        pytest.skip("the interpreter's contexts stage nothing")
+    lib = ctx.lib
+    h = C.c_void_p()
+    assert lib.ghicp_ctx_create(0, C.byref(h)) == 0
+    lib.ghicp_ctx_set_host_pointers(h, 1)
+    vp = C.c_void_p
+
+    def stats():
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        assert lib.ghicp_ctx_stage_stats(h, C.byref(a), C.byref(b), C.byref(c)) == 0
+        return a.value, b.value
+
+    try:
+        # a Kuhn-Munkres registration first (host arrays in, like GHRegistration::ghicp_reg through the drop-in header)
+        g = synth.gauss_pair(n=20_000, n_kp=300)
+        kpS = np.ascontiguousarray(g.source[g.kp_source], np.float64)
+        kpT = np.ascontiguousarray(g.target[g.kp_target], np.float64)
+        P = api.default_params(api.FEATURE_NONE, api.CORR_KM, 6, 0.9, 1.5, oracle.bbx_magnitude(g.source), max_iter=40)
+        Rt = (C.c_double * 16)()
+        n_iter = C.c_int32(0)
+        assert lib.ghicp_register(h, C.byref(P), kpS.ctypes.data_as(vp), C.c_int64(300), kpT.ctypes.data_as(vp), C.c_int64(300), None, Rt, None,
+                                  C.byref(n_iter), None) == 0
+        ro = oracle.register(oracle.default_params(oracle.NONE, oracle.KM, 6, 0.9, 1.5, oracle.bbx_magnitude(g.source), max_iter=40), kpS, kpT)
+        assert n_iter.value == ro["iters"] and np.abs(np.array(Rt[:]).reshape(4, 4) - ro["Rt"]).max() < 1e-6
+
+        pair = synth.tls_pair(120_000, pair_id=5)
+        S = np.ascontiguousarray(pair.source[oracle.voxel_filter(pair.source, 0.1)][:, :3], np.float32)
+        T = np.ascontiguousarray(pair.target[oracle.voxel_filter(pair.target, 0.1)][:, :3], np.float32)
+        assert S.nbytes >= 256 * 1024 and T.nbytes >= 256 * 1024  # both above the staging threshold: the cached path is the one under test
+        # coarse poses from "registered" to "barely overlapping": the ratio must agree at every one of them
+        for k, (deg, shift) in enumerate([(0.5, 0.05), (4.0, 1.5), (9.0, 4.0), (25.0, 12.0)]):
+            a = np.deg2rad(deg)
+            d = np.eye(4)
+            d[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+            d[:3, 3] = [shift, -0.5 * shift, 0.02]
+            S1 = np.ascontiguousarray(oracle.transform_cloud(S, d @ pair.gt), np.float32)
+            ratio = C.c_float(-1.0)
+            h0, m0 = stats()
+            assert lib.ghicp_cal_overlap(h, S1.ctypes.data_as(vp), C.c_int64(len(S1)), 3, T.ctypes.data_as(vp), C.c_int64(len(T)), 3, C.c_float(0.3),
+                                         C.byref(ratio)) == 0
+            r = np.float32(ratio.value)
+            assert r == np.float32(oracle.cal_overlap(S1, T, 0.3)), (k, r)
+            for min_ov, want_done in ((float(r), 1), (float(np.nextafter(r, np.float32(2.0))), 0), (0.1, int(r >= np.float32(0.1)))):
+                prm = api.icp_params(3, False, True, 0, 0.3, min_ov)
+                st = api.IcpStats()
+                T16 = np.zeros(16, np.float32)
+                out = np.zeros((len(S1), 3), np.float32)
+                assert lib.ghicp_icp(h, S1.ctypes.data_as(vp), C.c_int64(len(S1)), 3, T.ctypes.data_as(vp), C.c_int64(len(T)), 3, C.byref(prm),
+                                     T16.ctypes.data_as(vp), out.ctypes.data_as(vp), C.byref(st)) == 0
+                assert np.float32(st.overlap) == r, "pose %d: ghicp_icp overlap %r, ghicp_cal_overlap %r" % (k, st.overlap, float(r))
+                assert st.done == want_done, "pose %d: overlap %r against min_overlap %r -> done %d" % (k, float(r), min_ov, st.done)
+                io = oracle.icp(S1, T, oracle.icp_params(3, False, True, 0, 0.3, min_ov))
+                assert io["done"] == want_done and np.float32(io["overlap"]) == r
+            h1, m1 = stats()
+            # S1 is new at every pose (one upload), T is uploaded at the first pose only; the three ghicp_icp calls find both again
+            assert m1 - m0 == (2 if k == 0 else 1) and h1 - h0 == 6 + (0 if k == 0 else 1), (k, h0, m0, h1, m1)
+    finally:
+        lib.ghicp_ctx_destroy(h)
