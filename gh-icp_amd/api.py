@@ -46,7 +46,7 @@ class PairStats(C.Structure):
 
 
 EXPORTS = [
-    "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_stage_stats", "ghicp_ctx_set_cu_mask",
+    "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_stage_stats", "ghicp_ctx_stage_clear", "ghicp_ctx_set_cu_mask",
     "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_timeline", "ghicp_ctx_set_loop_cost_hints", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_cloud_bounds", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",

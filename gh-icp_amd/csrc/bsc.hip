@@ -90,7 +90,7 @@ extern "C" int ghicp_bsc_encode(ghicp_ctx* ctx, const float* xyz, int64_t m, int
   const int32_t* dk;
   uint8_t* df;
   float* dl;
-  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)m * stride, &d));
   GH_TRY(sg.in(kp_idx, (size_t)k, &dk));
   GH_TRY(sg.out(feat, (size_t)4 * k * 56, &df));
   GH_TRY(sg.out(lcs, (size_t)k * 12, &dl));

@@ -98,7 +98,7 @@ extern "C" int ghicp_cloud_create(ghicp_ctx* ctx, const ghicp_pair_config* cfg, 
   GH_ARG(cfg->reg.feature >= GHICP_FEATURE_BSC && cfg->reg.feature <= GHICP_FEATURE_NONE);
   Stager sg(ctx);
   const float* d;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   ghicp_cloud* c = new ghicp_cloud();
   c->ctx = ctx; c->cfg = *cfg;
   const int rc = cloud_fill(ctx, c, d, n, stride);
@@ -115,7 +115,7 @@ extern "C" int ghicp_cloud_recompute(ghicp_cloud* c, const float* xyz, int64_t n
   GH_ARG(stride >= 3 && n >= 0 && n < (1ll << 31) - 2);
   Stager sg(ctx);
   const float* d;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   return cloud_fill(ctx, c, d, n, stride);
 }
 

@@ -158,8 +158,10 @@ struct ghicp_ctx {
   // stays at three slots for the rest of the batch (round 5, call 5: 811 of 1024 slots busy from second 3.5 to the end of an 11 s batch).
   // GHICP_LOOP_CONFINE=0 switches it off (A/B measurements).
   bool loop_confine = true;
-  hipStream_t confine_stream = nullptr, rest_stream = nullptr;  // masks: the confined class's CUs / all the others
+  hipStream_t confine_stream = nullptr, rest_stream = nullptr;  // masks: the confined class's CUs / all the others (the pair in use, owned by confine_cache)
   int confine_cus = 0;
+  struct ConfinePair { int cus; hipStream_t confined, rest; };
+  std::vector<ConfinePair> confine_cache;  // one masked stream pair per share B seen (loop.hip run_pair_loop)
   int loop_min_lds = 0;  // GHICP_LOOP_MIN_LDS=<bytes> (experiment hook): every solve slot asks for at least this much LDS, e.g. 46080 = three slots per CU with 25 KB of every CU left to other kernels
   std::vector<uint32_t> cu_mask;       // set by ghicp_ctx_set_cu_mask: the auxiliary streams are restricted to the same compute units
   std::vector<hipStream_t> aux_streams;
@@ -175,6 +177,13 @@ struct ghicp_ctx {
   size_t staged_bytes = 0;
   uint64_t stage_tick = 0;
   long long staged_hits = 0, staged_misses = 0;
+  void stage_clear() {  // ghicp_ctx_stage_clear, ghicp_ctx_set_host_pointers(ctx, 0), ghicp_ctx_destroy
+    if (staged.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto& e : staged) (void)hipFree(e.dev);
+    staged.clear();
+    staged_bytes = 0;
+  }
   static constexpr size_t STAGED_MIN = 256 * 1024, STAGED_CAP = (size_t)1 << 30;
   std::string err;
   DevBuf buf[B_NUM];
@@ -235,28 +244,41 @@ struct Stager {
   struct Out { void* host; void* dev; size_t bytes; };
   std::vector<Out> outs;
   std::vector<void*> temps;
+  bool uploaded = false;  // this call put an upload of a kept (cached) copy on the stream
   explicit Stager(ghicp_ctx* c) : ctx(c) { ctx->stage_tick++; }
-  ~Stager() { for (void* p : temps) (void)hipFree(p); }
-  // content fingerprint of a host array: four independent multiply-xor lanes over 8-byte words (memory bound, ~10 GB/s per core)
+  // hipFree of a temporary waits for the device; a call that staged only KEPT copies and no outputs has nothing that does (round-5 advisor):
+  // the stream is joined here so that the caller may reuse or free its array as soon as the call is back
+  ~Stager() {
+    if (uploaded && temps.empty()) (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : temps) (void)hipFree(p);
+  }
+  // content fingerprint of a host array: four independent multiply-xor lanes over 8-byte words (memory bound, ~10 GB/s per core); the
+  // words are read with memcpy (a cloud's rows are 4-byte aligned at best)
   static uint64_t fingerprint(const void* p, size_t bytes) {
-    const uint64_t* w = reinterpret_cast<const uint64_t*>(p);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
     const size_t nw = bytes / 8;
     uint64_t h0 = 0x9E3779B97F4A7C15ull, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull, h3 = 0x27D4EB2F165667C5ull;
     size_t i = 0;
     for (; i + 4 <= nw; i += 4) {
-      h0 = (h0 ^ w[i]) * 0x100000001B3ull; h1 = (h1 ^ w[i + 1]) * 0x100000001B3ull;
-      h2 = (h2 ^ w[i + 2]) * 0x100000001B3ull; h3 = (h3 ^ w[i + 3]) * 0x100000001B3ull;
+      uint64_t w[4];
+      memcpy(w, b + i * 8, 32);
+      h0 = (h0 ^ w[0]) * 0x100000001B3ull; h1 = (h1 ^ w[1]) * 0x100000001B3ull;
+      h2 = (h2 ^ w[2]) * 0x100000001B3ull; h3 = (h3 ^ w[3]) * 0x100000001B3ull;
       h0 ^= h0 >> 29; h1 ^= h1 >> 31; h2 ^= h2 >> 27; h3 ^= h3 >> 33;
     }
-    for (; i < nw; i++) h0 = (h0 ^ w[i]) * 0x100000001B3ull;
-    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
+    for (; i < nw; i++) { uint64_t w; memcpy(&w, b + i * 8, 8); h0 = (h0 ^ w) * 0x100000001B3ull; }
     for (size_t k = nw * 8; k < bytes; k++) h1 = (h1 ^ b[k]) * 0x100000001B3ull;
     return (h0 ^ (h1 << 1) ^ (h2 << 2) ^ (h3 << 3)) + bytes;
   }
-  template <typename T> int in(const T* p, size_t count, const T** out) {
+  // in_cloud: a POINT CLOUD argument (xyz rows) -- the only kind of input the reference's call sequence hands over again and again; kept in
+  // the staged-input cache.  in: every other input (feature matrices, Kuhn-Munkres weights, index lists): staged for this call only, never
+  // fingerprinted (round-5 advisor: every input above 256 KB used to be hashed and kept).
+  template <typename T> int in_cloud(const T* p, size_t count, const T** out) { return stage_in(p, count, out, true); }
+  template <typename T> int in(const T* p, size_t count, const T** out) { return stage_in(p, count, out, false); }
+  template <typename T> int stage_in(const T* p, size_t count, const T** out, bool cacheable) {
     if (!ctx->host_ptrs || p == nullptr) { *out = p; return GHICP_OK; }
     const size_t bytes = count * sizeof(T);
-    if (bytes >= ghicp_ctx::STAGED_MIN && bytes <= ghicp_ctx::STAGED_CAP / 4) {  // large input: look for the copy an earlier call staged
+    if (cacheable && bytes >= ghicp_ctx::STAGED_MIN && bytes <= ghicp_ctx::STAGED_CAP / 4) {  // large cloud: look for the copy an earlier call staged
       const uint64_t fp = fingerprint(p, bytes);
       for (auto& e : ctx->staged)
         if (e.host == p && e.bytes == bytes && e.fp == fp) {
@@ -281,6 +303,7 @@ struct Stager {
       ctx->staged.push_back({p, bytes, fp, d, ctx->stage_tick});
       ctx->staged_bytes += bytes;
       ctx->staged_misses++;
+      uploaded = true;  // the copy out of the caller's buffer must have left it when the ABI call returns (~Stager)
       *out = reinterpret_cast<const T*>(d);
       return GHICP_OK;
     }

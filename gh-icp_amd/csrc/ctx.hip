@@ -58,14 +58,13 @@ extern "C" int ghicp_ctx_destroy(ghicp_ctx* ctx) {
   ctx->pair_clouds.clear();
   for (int i = 0; i < B_NUM; i++) ctx->buf[i].release();
   for (auto& b : ctx->pairbuf) b.release();
-  for (auto& e : ctx->staged) (void)hipFree(e.dev);
+  ctx->stage_clear();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->job_pinned) (void)hipHostFree(ctx->job_pinned);
   if (ctx->job_event) (void)hipEventDestroy(ctx->job_event);
   if (ctx->fb_pinned) (void)hipHostFree(ctx->fb_pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-  if (ctx->confine_stream) (void)hipStreamDestroy(ctx->confine_stream);
-  if (ctx->rest_stream) (void)hipStreamDestroy(ctx->rest_stream);
+  for (auto& e : ctx->confine_cache) { (void)hipStreamDestroy(e.confined); (void)hipStreamDestroy(e.rest); }
   for (hipStream_t a : ctx->aux_streams) (void)hipStreamDestroy(a);
   for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
   if (ctx->progress_host) (void)hipHostFree(ctx->progress_host);
@@ -109,6 +108,12 @@ extern "C" int ghicp_ctx_set_cu_mask(ghicp_ctx* ctx, const uint32_t* mask, int32
 extern "C" int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on) {
   GH_ENTER(ctx);
   ctx->host_ptrs = on != 0;
+  if (!ctx->host_ptrs) ctx->stage_clear();  // device-pointer mode stages nothing: the kept copies go with the mode
+  return GHICP_OK;
+}
+extern "C" int ghicp_ctx_stage_clear(ghicp_ctx* ctx) {
+  GH_ENTER(ctx);
+  ctx->stage_clear();
   return GHICP_OK;
 }
 extern "C" int ghicp_ctx_synchronize(ghicp_ctx* ctx) {
@@ -331,7 +336,7 @@ extern "C" int ghicp_cloud_bounds(ghicp_ctx* ctx, const float* xyz, int64_t n, i
   GH_ARG(out6 != nullptr && n > 0 && stride >= 3);
   Stager sg(ctx);
   const float* d;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   float mm[6];
   GH_TRY(gh_bbox_dev(ctx, d, n, stride, mm));
   for (int k = 0; k < 6; k++) out6[k] = (double)mm[k];
@@ -343,7 +348,7 @@ extern "C" int ghicp_bbx_magnitude(ghicp_ctx* ctx, const float* xyz, int64_t n, 
   GH_ARG(bbx != nullptr && n >= 0 && stride >= 3);
   Stager sg(ctx);
   const float* d;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   if (n == 0) { *bbx = 0.f; return GHICP_OK; }
   float mm[6];
   GH_TRY(gh_bbox_dev(ctx, d, n, stride, mm));
@@ -411,7 +416,7 @@ extern "C" int ghicp_transform_cloud(ghicp_ctx* ctx, const float* xyz, int64_t n
   Stager sg(ctx);
   const float* d;
   float* o;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   GH_TRY(sg.out(out, (size_t)n * 3, &o));
   M34 M;
   for (int r = 0; r < 3; r++)

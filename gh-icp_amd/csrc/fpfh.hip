@@ -353,7 +353,7 @@ extern "C" int ghicp_fpfh(ghicp_ctx* ctx, const float* xyz, int64_t m, int strid
   Stager sg(ctx);
   const float* d;
   float *dn, *dh;
-  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)m * stride, &d));
   GH_TRY(sg.out(normals, (size_t)m * 3, &dn));
   GH_TRY(sg.out(hist, (size_t)m * 33, &dh));
   GH_TRY(gh_fpfh_dev(ctx, d, m, stride, dn, dh));

@@ -217,7 +217,7 @@ extern "C" int ghicp_voxel_filter(ghicp_ctx* ctx, const float* xyz, int64_t n, i
   Stager sg(ctx);
   const float* d;
   int32_t* k;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   GH_TRY(sg.out(keep_idx, (size_t)n + 1, &k));
   long long mm = 0;
   GH_TRY(gh_voxel_filter_dev(ctx, d, n, stride, voxel, k, &mm));

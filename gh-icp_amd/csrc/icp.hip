@@ -711,8 +711,8 @@ extern "C" int ghicp_cal_overlap(ghicp_ctx* ctx, const float* xyz1, int64_t n1, 
   GH_ARG(n1 >= 0 && n2 >= 0 && n1 < (1ll << 31) - 2 && n2 < (1ll << 31) - 2 && stride1 >= 3 && stride2 >= 3 && thre_dis > 0.f && ratio != nullptr);
   Stager sg(ctx);
   const float *d1, *d2;
-  GH_TRY(sg.in(xyz1, (size_t)n1 * stride1, &d1));
-  GH_TRY(sg.in(xyz2, (size_t)n2 * stride2, &d2));
+  GH_TRY(sg.in_cloud(xyz1, (size_t)n1 * stride1, &d1));
+  GH_TRY(sg.in_cloud(xyz2, (size_t)n2 * stride2, &d2));
   return overlap_dev(ctx, d1, n1, stride1, d2, n2, stride2, thre_dis, ratio);
 }
 
@@ -722,7 +722,7 @@ extern "C" int ghicp_transform_cloud_f32(ghicp_ctx* ctx, const float* xyz, int64
   Stager sg(ctx);
   const float* d;
   float* o;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   GH_TRY(sg.out(out, (size_t)n * 3, &o));
   if (n > 0) {
     M16 M;
@@ -739,7 +739,7 @@ extern "C" int ghicp_knn_normals(ghicp_ctx* ctx, const float* xyz, int64_t n, in
   Stager sg(ctx);
   const float* d;
   float* o;
-  GH_TRY(sg.in(xyz, (size_t)n * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)n * stride, &d));
   GH_TRY(sg.out(normals, (size_t)n * 3, &o));
   GH_TRY(gh_knn_normals_dev(ctx, d, n, stride, k, o));
   return sg.finish();
@@ -754,7 +754,7 @@ extern "C" int ghicp_nn_search(ghicp_ctx* ctx, const float* query, int64_t nq, i
   int32_t* di;
   float* dd;
   GH_TRY(sg.in(query, (size_t)nq * strideQ, &dq));
-  GH_TRY(sg.in(xyzT, (size_t)nt * strideT, &dt));
+  GH_TRY(sg.in_cloud(xyzT, (size_t)nt * strideT, &dt));
   GH_TRY(sg.out(idx, (size_t)nq, &di));
   GH_TRY(sg.out(d2, (size_t)nq, &dd));
   if (nq > 0) {
@@ -779,8 +779,8 @@ extern "C" int ghicp_icp(ghicp_ctx* ctx, const float* xyzS, int64_t ns, int stri
   Stager sg(ctx);
   const float *dS, *dT;
   float* dOut;
-  GH_TRY(sg.in(xyzS, (size_t)ns * strideS, &dS));
-  GH_TRY(sg.in(xyzT, (size_t)nt * strideT, &dT));
+  GH_TRY(sg.in_cloud(xyzS, (size_t)ns * strideS, &dS));
+  GH_TRY(sg.in_cloud(xyzT, (size_t)nt * strideT, &dT));
   GH_TRY(sg.out(transformed, (size_t)ns * 3, &dOut));
 
   float ratio = 1.0f;

@@ -742,17 +742,36 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     B = std::min(B, std::min(ctx->num_cu / 2, cdiv(plan.count[0], 3)));
     if (B >= 1) {
       if (ctx->confine_stream == nullptr || ctx->rest_stream == nullptr || ctx->confine_cus != B) {
-        for (hipStream_t* ps : {&ctx->confine_stream, &ctx->rest_stream})
-          if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
+        // B follows the caller's cost prior from batch to batch: the masked stream pairs are kept per B (a handful of values in practice)
+        // instead of being destroyed and re-created -- with a stream synchronisation -- on the launch path (round-5 advisor)
+        ctx->confine_stream = ctx->rest_stream = nullptr;
         ctx->confine_cus = 0;
-        std::vector<uint32_t> mask((size_t)cdiv(ctx->num_cu, 32), 0u), rest((size_t)cdiv(ctx->num_cu, 32), 0u);
-        for (int i = 0; i < ctx->num_cu; i++) {
-          const bool in = (long long)(i + 1) * B / ctx->num_cu > (long long)i * B / ctx->num_cu;
-          (in ? mask : rest)[(size_t)i >> 5] |= 1u << (i & 31);
+        for (auto& e : ctx->confine_cache)
+          if (e.cus == B) { ctx->confine_stream = e.confined; ctx->rest_stream = e.rest; ctx->confine_cus = B; }
+        if (ctx->confine_cus != B) {
+          if (ctx->confine_cache.size() >= 16) {  // bounded: drop them all (nothing of this context runs on them between two batches)
+            for (auto& e : ctx->confine_cache) {
+              (void)hipStreamSynchronize(e.confined); (void)hipStreamDestroy(e.confined);
+              (void)hipStreamSynchronize(e.rest); (void)hipStreamDestroy(e.rest);
+            }
+            ctx->confine_cache.clear();
+          }
+          std::vector<uint32_t> mask((size_t)cdiv(ctx->num_cu, 32), 0u), rest((size_t)cdiv(ctx->num_cu, 32), 0u);
+          for (int i = 0; i < ctx->num_cu; i++) {
+            const bool in = (long long)(i + 1) * B / ctx->num_cu > (long long)i * B / ctx->num_cu;
+            (in ? mask : rest)[(size_t)i >> 5] |= 1u << (i & 31);
+          }
+          hipStream_t sa = nullptr, sb = nullptr;
+          if (hipExtStreamCreateWithCUMask(&sa, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+              hipExtStreamCreateWithCUMask(&sb, (uint32_t)rest.size(), rest.data()) == hipSuccess) {
+            ctx->confine_cache.push_back({B, sa, sb});
+            ctx->confine_stream = sa; ctx->rest_stream = sb; ctx->confine_cus = B;
+          } else {  // no masked streams on this runtime: the batch runs unconfined; the runtime's sticky error must not fail the launch below
+            if (sa) (void)hipStreamDestroy(sa);
+            if (sb) (void)hipStreamDestroy(sb);
+            (void)hipGetLastError();
+          }
         }
-        if (hipExtStreamCreateWithCUMask(&ctx->confine_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
-            hipExtStreamCreateWithCUMask(&ctx->rest_stream, (uint32_t)rest.size(), rest.data()) == hipSuccess)
-          ctx->confine_cus = B;
       }
       if (ctx->confine_cus == B) confine_b = B;
     }

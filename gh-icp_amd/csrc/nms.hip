@@ -161,7 +161,7 @@ extern "C" int ghicp_keypoints_adaptive(ghicp_ctx* ctx, const float* xyz, int64_
   Stager sg(ctx);
   const float* d;
   int32_t* dk;
-  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)m * stride, &d));
   GH_TRY(sg.out(kp_idx, (size_t)m, &dk));
   long long kk = 0;
   int nr = 0;
@@ -189,7 +189,7 @@ extern "C" int ghicp_keypoints(ghicp_ctx* ctx, const float* xyz, int64_t m, int 
   Stager sg(ctx);
   const float* d;
   int32_t* dk;
-  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)m * stride, &d));
   GH_TRY(sg.out(kp_idx, (size_t)m, &dk));
   long long kk = 0;
   GH_TRY(gh_keypoints_dev(ctx, d, m, stride, radius, ratio_max, min_n, nms_radius, dk, &kk));

@@ -154,8 +154,8 @@ extern "C" int ghicp_register_pair(ghicp_ctx* ctx, const ghicp_pair_config* cfg,
   hipStream_t s = ctx->stream;
   Stager sg(ctx);
   const float *dS, *dT;
-  GH_TRY(sg.in(xyzS, (size_t)nS * stride, &dS));
-  GH_TRY(sg.in(xyzT, (size_t)nT * stride, &dT));
+  GH_TRY(sg.in_cloud(xyzS, (size_t)nS * stride, &dS));
+  GH_TRY(sg.in_cloud(xyzT, (size_t)nT * stride, &dT));
   memset(stats, 0, sizeof(*stats));
   stats->n_s = nS; stats->n_t = nT;
   Ev ev[7];

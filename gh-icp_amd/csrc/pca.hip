@@ -118,7 +118,7 @@ extern "C" int ghicp_pca_curvature(ghicp_ctx* ctx, const float* xyz, int64_t m, 
   float* dl;
   double* dc;
   int32_t* dn;
-  GH_TRY(sg.in(xyz, (size_t)m * stride, &d));
+  GH_TRY(sg.in_cloud(xyz, (size_t)m * stride, &d));
   GH_TRY(sg.out(lambda, (size_t)m * 3, &dl));
   GH_TRY(sg.out(curvature, (size_t)m, &dc));
   GH_TRY(sg.out(count, (size_t)m, &dn));

@@ -146,7 +146,7 @@ __device__ inline void gh_pca_cell_body(const GridArgs& G, unsigned key, const P
   {
     const int np0 = (int)min(64u, qe - qb);
     int g0 = 1;
-    while (g0 * 2 * np0 <= 64) g0 *= 2;
+    while (np0 > 0 && g0 * 2 * np0 <= 64) g0 *= 2;  // (np0 == 0, an empty query cell, never comes from Unique() of occupied keys: any other caller's guard)
     if (lane / g0 < np0) P0 = G.pts[qb + lane / g0];
   }
   if (resident) {

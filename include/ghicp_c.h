@@ -78,12 +78,14 @@ int ghicp_ctx_set_stream(ghicp_ctx* ctx, void* hip_stream);
  * set before.  Lets a pipeline keep some CUs free of the LDS-filling solve waves for another context's small kernels. */
 int ghicp_ctx_set_cu_mask(ghicp_ctx* ctx, const uint32_t* mask, int32_t n_words);
 int ghicp_ctx_set_host_pointers(ghicp_ctx* ctx, int on);
-/* Host-pointer mode keeps the staged device copy of every LARGE input array (>= 256 KB) between calls, keyed on host address, size and a
- * fingerprint of the content, so that the reference's call sequence on one cloud -- CFilter::voxelfilter, CKeypointDetect, BSCEncoder /
+/* Host-pointer mode keeps the staged device copy of every LARGE POINT-CLOUD input (xyz rows, >= 256 KB; no other kind of argument)
+ * between calls, keyed on host address, size and a fingerprint of the content, so that the reference's call sequence on one cloud -- CFilter::voxelfilter, CKeypointDetect, BSCEncoder /
  * FPFHfeature, transformPointCloud (test/ghicp_main.cpp:86-153) -- uploads it once (at most 1 GiB / 16 arrays, least recently used out
  * first).  Counters since the context was created: inputs served from a kept copy, inputs uploaded, bytes currently kept.  [host] outputs,
  * any may be NULL. */
 int ghicp_ctx_stage_stats(const ghicp_ctx* ctx, int64_t* hits, int64_t* misses, int64_t* bytes_kept);
+/* Frees every kept copy now (ghicp_ctx_set_host_pointers(ctx, 0) and ghicp_ctx_destroy do the same). */
+int ghicp_ctx_stage_clear(ghicp_ctx* ctx);
 int ghicp_ctx_synchronize(ghicp_ctx* ctx);
 const char* ghicp_last_error(const ghicp_ctx* ctx);
 /* Optional per-kernel timing (hipEvent brackets on the context's stream around the named kernels:

@@ -108,8 +108,6 @@ def test_host_pointer_mode_uploads_a_cloud_once_and_sees_in_place_changes(ctx, a
     """The C++ drop-in classes run the context in host-pointer mode; the reference's call sequence on one cloud (main:86-116: bounds,
     keypoints, BSC) must upload it once -- the staged copy is found again by address + size + content fingerprint -- and a cloud that was
     CHANGED in place between two calls must be uploaded again (ghicp_ctx_stage_stats)."""
-    if getattr(ctx, "simulated", False):
-        pytest.skip("the interpreter's contexts stage nothing")
     lib = ctx.lib
     h = ctypes.c_void_p()
     assert lib.ghicp_ctx_create(0, ctypes.byref(h)) == 0
@@ -154,4 +152,16 @@ def test_host_pointer_mode_uploads_a_cloud_once_and_sees_in_place_changes(ctx, a
         bounds(o)
     hits, misses, kept = stats()
     assert (hits, misses) == (3, 22) and kept <= 16 * raw.nbytes
+    # only point clouds are kept: a 3 MB Kuhn-Munkres weight matrix is staged for its call and gone with it (no fingerprint, no entry)
+    W = np.ascontiguousarray(-np.abs(np.random.default_rng(3).normal(size=(620, 620))) - 1.0)
+    m = np.zeros(620, np.int32)
+    assert W.nbytes > 256 * 1024
+    assert lib.ghicp_km_solve(h, W.ctypes.data_as(vp), ctypes.c_int64(620), ctypes.c_double(0.01), m.ctypes.data_as(vp)) == 0
+    assert sorted(m.tolist()) == list(range(620)) and stats() == (hits, misses, kept)
+    # ghicp_ctx_stage_clear frees the kept copies; so does leaving host-pointer mode
+    assert kept > 0 and lib.ghicp_ctx_stage_clear(h) == 0 and stats() == (hits, misses, 0)
+    bounds(raw)
+    assert stats()[1:] == (misses + 1, raw.nbytes)
+    lib.ghicp_ctx_set_host_pointers(h, 0)
+    assert stats()[2] == 0
     lib.ghicp_ctx_destroy(h)

@@ -130,8 +130,6 @@ def test_overlap_of_icp_equals_cal_overlap_back_to_back_in_host_pointer_mode(ctx
     bit, and `done` must flip exactly at min_overlap_for_reg == that float (`ratio < min_overlap` refuses, common_reg.cpp:66)."""
     import ctypes as C
 
-    if getattr(ctx, "simulated", False):
-        pytest.skip("the interpreter's contexts stage nothing")
     lib = ctx.lib
     h = C.c_void_p()
     assert lib.ghicp_ctx_create(0, C.byref(h)) == 0
