@@ -56,6 +56,9 @@ EXPORTS = [
     "ghicp_transform_cloud_f32",
     "ghicp_cloud_create", "ghicp_cloud_recompute", "ghicp_clouds_recompute", "ghicp_cloud_from_features", "ghicp_cloud_destroy", "ghicp_cloud_get_info", "ghicp_cloud_download",
     "ghicp_register_clouds", "ghicp_sbf_write", "ghicp_sbf_read",
+    "ghicp_pairqueue_create", "ghicp_pairqueue_destroy", "ghicp_pairqueue_last_error", "ghicp_pairqueue_info", "ghicp_pairqueue_broadcast",
+    "ghicp_pairqueue_barrier", "ghicp_pairqueue_static_share", "ghicp_pairqueue_claim", "ghicp_pairqueue_counter_reset",
+    "ghicp_pairqueue_gather_records", "ghicp_pairqueue_pack_records", "ghicp_pairqueue_register_pairs",
 ]
 
 _lib = None
@@ -76,6 +79,7 @@ def load():
         _lib.ghicp_last_error.restype = C.c_char_p
         _lib.ghicp_version.restype = C.c_char_p
         _lib.ghicp_loop_destroy.restype = None
+        _lib.ghicp_pairqueue_last_error.restype = C.c_char_p
     return _lib
 
 

@@ -206,3 +206,104 @@ def run_sharded_dynamic(manifest: Sequence, register_chunk: Callable[[List[int],
         for i, rec in part:
             out[i] = rec
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The same queue behind the C ABI (include/ghicp_c.h, "Pair queue"; gh-icp_amd/csrc/pairqueue.hip): what a C++ caller of the drop-in
+# headers uses to shard pairs -- ncclBroadcast / ncclAllGather over RCCL, or the rendezvous segment alone (GHICP_PQ_HOST: ranks that
+# share a GPU, machines without one).  This class is a ctypes binding over it, nothing more.
+PQ_HOST, PQ_RCCL = 0, 1
+
+
+class NativeQueue:
+    """ghicp_pairqueue_*: create is collective (every rank, same `rendezvous` path, new per queue)."""
+
+    def __init__(self, rendezvous: str, rank: int, world: int, transport: int = PQ_HOST, ctx=None, timeout_s: float = 120.0):
+        import ctypes as C
+        import importlib
+
+        api = importlib.import_module("gh-icp_amd.api")
+        self._C, self._api = C, api
+        self.lib = ctx.lib if ctx is not None else api.load()
+        self.lib.ghicp_pairqueue_last_error.restype = C.c_char_p
+        self.ctx, self.rank, self.world, self.transport = ctx, int(rank), int(world), int(transport)
+        self.h = C.c_void_p()
+        rc = self.lib.ghicp_pairqueue_create(ctx.h if ctx is not None else None, rendezvous.encode(), C.c_int32(rank), C.c_int32(world),
+                                             C.c_int32(transport), C.c_double(timeout_s), C.byref(self.h))
+        if rc != 0:
+            why = self.lib.ghicp_last_error(ctx.h).decode() if ctx is not None else ""
+            raise api.GhicpError("ghicp_pairqueue_create failed (%d) %s" % (rc, why))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise self._api.GhicpError("pair queue error %d: %s" % (rc, self.lib.ghicp_pairqueue_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, None
+            self._check(self.lib.ghicp_pairqueue_destroy(h))
+
+    def broadcast_bytes(self, data: bytes, root: int = 0) -> bytes:
+        """Root's bytes on every rank (two broadcasts: the length, then the payload)."""
+        import numpy as np
+
+        C = self._C
+        n = np.array([len(data) if self.rank == root else 0], np.int64)
+        self._check(self.lib.ghicp_pairqueue_broadcast(self.h, n.ctypes.data_as(C.c_void_p), C.c_int64(8), C.c_int32(root)))
+        buf = np.frombuffer(data, np.uint8).copy() if self.rank == root else np.zeros(int(n[0]), np.uint8)
+        self._check(self.lib.ghicp_pairqueue_broadcast(self.h, buf.ctypes.data_as(C.c_void_p), C.c_int64(int(n[0])), C.c_int32(root)))
+        return buf.tobytes()
+
+    def broadcast_manifest(self, manifest, root: int = 0):
+        import json
+
+        return json.loads(self.broadcast_bytes(json.dumps(list(manifest)).encode() if self.rank == root else b"", root).decode())
+
+    def barrier(self):
+        self._check(self.lib.ghicp_pairqueue_barrier(self.h))
+
+    def static_share(self, n_pairs: int) -> List[int]:
+        import numpy as np
+
+        C = self._C
+        ids = np.zeros(max(1, -(-n_pairs // self.world)), np.int64)
+        n = C.c_int64(0)
+        self._check(self.lib.ghicp_pairqueue_static_share(self.h, C.c_int64(n_pairs), ids.ctypes.data_as(C.c_void_p), C.c_int64(ids.size), C.byref(n)))
+        return [int(v) for v in ids[:n.value]]
+
+    def claim(self, count: int, limit: int) -> List[int]:
+        C = self._C
+        first, n = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.ghicp_pairqueue_claim(self.h, C.c_int64(count), C.c_int64(limit), C.byref(first), C.byref(n)))
+        return list(range(first.value, first.value + n.value))
+
+    def counter_reset(self):
+        self._check(self.lib.ghicp_pairqueue_counter_reset(self.h))
+
+    def gather_records(self, block):
+        """block: (rows, RECORD_WIDTH) float64 numpy array of this rank -> dict pair id -> (iterations, converged, Rt16 list) of all ranks."""
+        import numpy as np
+
+        C = self._C
+        block = np.ascontiguousarray(block, np.float64)
+        assert block.ndim == 2 and block.shape[1] == RECORD_WIDTH
+        out = np.zeros((self.world * block.shape[0], RECORD_WIDTH))
+        self._check(self.lib.ghicp_pairqueue_gather_records(self.h, block.ctypes.data_as(C.c_void_p), C.c_int64(block.shape[0]), out.ctypes.data_as(C.c_void_p)))
+        return {int(r[0]): (int(r[1]), int(r[2]), [float(v) for v in r[3:]]) for r in out if r[0] >= 0}
+
+    def register_pairs(self, cfg, clouds_S, clouds_T, chunk: int = 0):
+        """ghicp_pairqueue_register_pairs: device tensors (n_i, stride) f32 indexed by GLOBAL pair id (entries of pairs another rank registers
+        may be None).  Returns the (n_pairs, RECORD_WIDTH) records of ALL pairs on every rank."""
+        import numpy as np
+
+        C = self._C
+        n = len(clouds_S)
+        stride = next(int(c.shape[1]) for c in list(clouds_S) + list(clouds_T) if c is not None)
+        xs = (C.c_void_p * n)(*[c.data_ptr() if c is not None else None for c in clouds_S])
+        xt = (C.c_void_p * n)(*[c.data_ptr() if c is not None else None for c in clouds_T])
+        ns = (C.c_int64 * n)(*[int(c.shape[0]) if c is not None else 0 for c in clouds_S])
+        nt = (C.c_int64 * n)(*[int(c.shape[0]) if c is not None else 0 for c in clouds_T])
+        rec = np.zeros((n, RECORD_WIDTH))
+        self._check(self.lib.ghicp_pairqueue_register_pairs(self.h, self.ctx.h, C.byref(cfg), C.c_int64(n), xs, ns, xt, nt, C.c_int(stride), C.c_int64(chunk),
+                                                            None, rec.ctypes.data_as(C.c_void_p)))
+        return rec

@@ -354,6 +354,50 @@ int ghicp_cloud_download(const ghicp_cloud* cloud, float* ds_xyz, int32_t* kp_id
 int ghicp_register_clouds(ghicp_ctx* ctx, const ghicp_pair_config* cfg, int32_t n_pairs, const ghicp_cloud* const* S,
                           const ghicp_cloud* const* T, ghicp_pair_stats* stats);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pair queue: independent scan pairs sharded over the GPUs of ONE node, one process per GPU (BASELINE configs[3]).
+ * The reference registers one pair per process run (test/ghicp_main.cpp:56-160) and has no counterpart; a caller of the drop-in
+ * headers that holds MANY pairs shards them with these calls.  Pairs share nothing, so there is NO collective on the data path --
+ * what the ranks exchange is
+ *   - the pair manifest (scene ids / paths / parameters, a few KB): ghicp_pairqueue_broadcast  = one ncclBroadcast,
+ *   - per step, every rank's block of result records:               ghicp_pairqueue_gather_records = one ncclAllGather,
+ *   - for the dynamic split, claims on one shared counter:          ghicp_pairqueue_claim (an atomic add in host shared memory).
+ * Transports: GHICP_PQ_RCCL -- an RCCL communicator over xGMI (librccl is opened when the first such queue is created; the
+ * ncclUniqueId travels through the rendezvous segment); GHICP_PQ_HOST -- the same three operations through the rendezvous segment
+ * alone (ranks that share a GPU, which RCCL refuses, and the world-size-2 tests on a machine without one).
+ * `rendezvous`: path of a file every rank of the job can map (e.g. under /dev/shm), new for every queue; rank 0 creates it, the
+ * others wait for it (up to timeout_s seconds).  All buffers of these calls are HOST memory.  Collective calls (create, broadcast,
+ * gather_records, barrier, counter_reset, destroy) must be made by every rank, in the same order. */
+enum { GHICP_PQ_HOST = 0, GHICP_PQ_RCCL = 1 };
+enum { GHICP_PQ_RECORD_WIDTH = 19 }; /* pair id, iterations, converged, the 16 entries of the 4x4 (row-major); pair id -1: unused row */
+typedef struct ghicp_pairqueue ghicp_pairqueue;
+/* ctx: the rank's context (its device and stream carry the RCCL transfers); may be NULL for GHICP_PQ_HOST. */
+int ghicp_pairqueue_create(ghicp_ctx* ctx, const char* rendezvous, int32_t rank, int32_t world, int32_t transport, double timeout_s,
+                           ghicp_pairqueue** queue);
+int ghicp_pairqueue_destroy(ghicp_pairqueue* queue);
+const char* ghicp_pairqueue_last_error(const ghicp_pairqueue* queue);
+int ghicp_pairqueue_info(const ghicp_pairqueue* queue, int32_t* rank, int32_t* world, int32_t* transport);
+/* `bytes` bytes of root's `buf` into every rank's `buf`. */
+int ghicp_pairqueue_broadcast(ghicp_pairqueue* queue, void* buf, int64_t bytes, int32_t root);
+int ghicp_pairqueue_barrier(ghicp_pairqueue* queue);
+/* Static split: pair p belongs to rank p mod world.  ids: capacity `cap`; *n = number of pairs of this rank (ascending). */
+int ghicp_pairqueue_static_share(const ghicp_pairqueue* queue, int64_t n_pairs, int64_t* ids, int64_t cap, int64_t* n);
+/* Dynamic split: the next `count` pair ids below `limit` from the queue's shared counter: [*first, *first + *n), *n == 0 when the job
+ * is drained.  Not collective.  ghicp_pairqueue_counter_reset (collective) starts the next job at 0. */
+int ghicp_pairqueue_claim(ghicp_pairqueue* queue, int64_t count, int64_t limit, int64_t* first, int64_t* n);
+int ghicp_pairqueue_counter_reset(ghicp_pairqueue* queue);
+/* Every rank's `rows` x GHICP_PQ_RECORD_WIDTH block (f64) into all[world x rows x GHICP_PQ_RECORD_WIDTH] on every rank, rank order. */
+int ghicp_pairqueue_gather_records(ghicp_pairqueue* queue, const double* block, int64_t rows, double* all);
+/* ghicp_pair_stats of this rank's pairs -> record rows (pair ids in `ids`); rows beyond n_mine get pair id -1. */
+int ghicp_pairqueue_pack_records(const int64_t* ids, const ghicp_pair_stats* stats, int64_t n_mine, int64_t rows, double* block);
+/* ghicp_register_pairs of THIS RANK'S SHARE of n_pairs pairs (static split when chunk <= 0, else claims of `chunk` pairs from the
+ * shared counter), then one gather: records[n_pairs x GHICP_PQ_RECORD_WIDTH] of ALL pairs, in pair order, on every rank.  xyzS / xyzT /
+ * nS / nT are indexed by GLOBAL pair id; a rank only touches the entries of the pairs it registers (device pointers, like
+ * ghicp_register_pairs).  stats (n_pairs, [host], may be NULL): filled for this rank's pairs only.  Collective. */
+int ghicp_pairqueue_register_pairs(ghicp_pairqueue* queue, ghicp_ctx* ctx, const ghicp_pair_config* cfg, int64_t n_pairs, const float* const* xyzS,
+                                   const int64_t* nS, const float* const* xyzT, const int64_t* nT, int stride, int64_t chunk,
+                                   ghicp_pair_stats* stats, double* records);
+
 /* StereoBinaryFeature::writeFeatures / readFeatures (src/stereo_binary_feature.cpp:107-148): the reference's dump
  * format for one vector of 441-bit strings.  Host memory.  ghicp_sbf_read with feat == NULL only reports *k. */
 int ghicp_sbf_write(const char* path, const uint8_t* feat /*k x 56*/, int64_t k);

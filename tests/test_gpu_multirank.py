@@ -95,3 +95,42 @@ def test_one_rank_rccl_group_runs_the_pair_queue_collectives_on_device_tensors(c
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     # (RCCL prints its library path on stdout when the group goes away: the line is looked for, not expected last)
     assert "[5, 3, 9] [0, 2] 7 0.5 [1.0, 1.0, 1.0, 1.0] [0, 1, 2, 3, 4, 5] nccl" in [l.strip() for l in r.stdout.splitlines()], r.stdout[-2000:]
+
+
+def _native(tmp, tag, world, transport, chunk, n_pairs=6):
+    """`world` processes on device 0, each a rank of one ghicp_pairqueue (tests/pq_native_worker.py); returns their JSON outputs."""
+    d = os.path.join(str(tmp), tag)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "rendezvous")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pq_native_worker.py"), path, str(r), str(world), str(transport), str(chunk), str(n_pairs),
+                               os.path.join(d, "out%d.json" % r)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(world)]
+    outs = []
+    for r, p in enumerate(procs):
+        try:
+            so, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for x in procs:
+                x.kill()
+            raise
+        assert p.returncode == 0, "rank %d: %s" % (r, so[-3000:])
+        outs.append(json.load(open(os.path.join(d, "out%d.json" % r))))
+    return outs
+
+
+def test_native_pair_queue_through_the_c_abi(ctx, tmp_path):
+    """ghicp_pairqueue_* (include/ghicp_c.h): the C entry a caller of the drop-in headers shards pairs with (round-5 verdict, missing #5).
+    (a) ONE rank over RCCL -- ncclCommInitRank, the manifest through ncclBroadcast, the records through ncclAllGather on the MI355X;
+    (b) TWO ranks on the one GPU over the rendezvous segment (RCCL refuses two ranks on one device), static split and claims from the
+    shared counter.  Every run must report the same 19-double record for every pair: same iterations, converged flag and 4x4 bits."""
+    if getattr(ctx, "simulated", False):
+        pytest.skip("needs the GPU (RCCL, two processes)")
+    one = _native(tmp_path, "rccl1", 1, 1, 0)[0]
+    assert one["manifest"] == [(3 * p + 1) % 7 for p in range(6)] and one["gathered_ids"] == [0, 1, 2, 3, 4]
+    ref = one["records"]
+    assert [int(r[0]) for r in ref] == list(range(6)) and all(r[1] > 0 for r in ref)
+    assert ref[0] != ref[1]  # different scenes, different results
+    for tag, world, transport, chunk in (("host1", 1, 0, 0), ("host2_static", 2, 0, 0), ("host2_dynamic", 2, 0, 2), ("rccl1_dynamic", 1, 1, 4)):
+        for o in _native(tmp_path, tag, world, transport, chunk):
+            assert o["manifest"] == one["manifest"]
+            assert o["records"] == ref, "%s rank %d reports other records than the one-rank RCCL run" % (tag, o["rank"])

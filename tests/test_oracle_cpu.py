@@ -402,7 +402,8 @@ def test_every_context_entry_point_rejects_a_null_context(api):
     anything else (the drop-in classes turn that code into an exception; nothing falls back to the CPU)."""
     lib = api.load()
     no_ctx = {"ghicp_version", "ghicp_params_default", "ghicp_icp_params_default", "ghicp_inv_transform", "ghicp_rigid_svd_host",
-              "ghicp_sbf_write", "ghicp_sbf_read", "ghicp_last_error", "ghicp_ctx_create", "ghicp_cloud_destroy", "ghicp_loop_destroy"}
+              "ghicp_sbf_write", "ghicp_sbf_read", "ghicp_last_error", "ghicp_ctx_create", "ghicp_cloud_destroy", "ghicp_loop_destroy",
+              "ghicp_pairqueue_last_error", "ghicp_pairqueue_pack_records"}
     zeros = [ctypes.c_void_p(0)] * 16
     for name in api.EXPORTS:
         if name in no_ctx:

@@ -276,3 +276,100 @@ def test_one_rank_group_runs_the_same_collectives():
     got = q.get(timeout=120)
     p.join(30)
     assert got == ([5, 3, 9], [0, 2], 7, 0.5, [0, 1, 2, 3, 4, 5], True)
+
+
+# ------------------------------------------------------------------ the queue behind the C ABI (ghicp_pairqueue_*, host transport: no GPU)
+def _native_rank(args):
+    """One rank of a ghicp_pairqueue job over the rendezvous segment (spawned process)."""
+    path, rank, world = args
+    import importlib
+    import os
+    import sys
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    pq = importlib.import_module("gh-icp_amd.pairqueue")
+    q = pq.NativeQueue(path, rank, world, pq.PQ_HOST, None, timeout_s=60.0)
+    out = {"rank": rank}
+    # manifest: rank 0's list on every rank; a payload larger than the 4 MB data window goes through in parts
+    out["manifest"] = q.broadcast_manifest([7, 3, 9, 11, 2] if rank == 0 else [])
+    big = np.arange(1_300_000, dtype=np.int64).tobytes() if rank == 1 % world else b""
+    got = q.broadcast_bytes(big, root=1 % world)
+    out["big_ok"] = bool(np.array_equal(np.frombuffer(got, np.int64), np.arange(1_300_000)))
+    # static split
+    out["static"] = q.static_share(23)
+    # dynamic split: two jobs on the same queue (counter_reset between them), claims of 3 below 40
+    claims = []
+    for job in range(2):
+        q.counter_reset()
+        mine = []
+        while True:
+            ids = q.claim(3, 40)
+            if not ids:
+                break
+            mine += ids
+        claims.append(mine)
+    out["claims"] = claims
+    # result records: this rank's pairs of the static split, one all-gather
+    mine = out["static"]
+    rows = pq.records_per_rank(23, world)
+    block = pq.pack_records(mine, [(10 + p, p % 2, [p + 0.5 * k for k in range(16)]) for p in mine], rows)
+    out["records"] = {k: v for k, v in q.gather_records(block).items()}
+    # a block larger than the window's per-rank share (rows x 152 B > 4 MB / world)
+    nbig = 40_000
+    blk = np.zeros((nbig, pq.RECORD_WIDTH))
+    blk[:, 0] = np.arange(nbig) * world + rank
+    blk[:, 5] = rank + 1
+    allr = q.gather_records(blk)
+    out["big_gather_ok"] = len(allr) == nbig * world and all(allr[p * world + r][2][2] == r + 1 for p in (0, 17, nbig - 1) for r in range(world))
+    q.barrier()
+    q.close()
+    return out
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_native_pair_queue_host_transport(world, tmp_path):
+    """ghicp_pairqueue_* (include/ghicp_c.h) with `world` processes over the rendezvous segment: the manifest broadcast, the static
+    p mod R split, disjoint and complete claims on the shared counter over two jobs, and the all-gather of the 19-double records --
+    the operations the RCCL transport runs as ncclBroadcast / ncclAllGather (tests/test_gpu_multirank.py runs those on the MI355X)."""
+    import multiprocessing as mp
+
+    path = str(tmp_path / "pq_rendezvous")
+    with mp.get_context("spawn").Pool(world) as pool:
+        res = pool.map(_native_rank, [(path, r, world) for r in range(world)], chunksize=1)
+    assert not os.path.exists(path)  # rank 0 removed the segment
+    for r in res:
+        assert r["manifest"] == [7, 3, 9, 11, 2] and r["big_ok"] and r["big_gather_ok"]
+        assert r["static"] == list(range(r["rank"], 23, world))
+        assert sorted(r["records"]) == list(range(23))
+        for p, (it, conv, Rt) in r["records"].items():
+            assert (it, conv) == (10 + p, p % 2) and Rt == [p + 0.5 * k for k in range(16)]
+    for job in range(2):
+        claimed = sorted(i for r in res for i in r["claims"][job])
+        assert claimed == list(range(40))  # every pair exactly once, whoever drew it
+        for r in res:  # chunks of consecutive ids
+            c = r["claims"][job]
+            assert all(c[i + 1] == c[i] + 1 or (c[i] + 1) % 3 == 0 or c[i] == 39 for i in range(len(c) - 1))
+
+
+def test_native_pair_queue_argument_errors(tmp_path):
+    import ctypes as C
+    import importlib
+
+    api = importlib.import_module("gh-icp_amd.api")
+    lib = api.load()
+    h = C.c_void_p()
+    # RCCL needs a context (its device and stream); rank outside the world; a rank that never finds rank 0's segment times out
+    assert lib.ghicp_pairqueue_create(None, str(tmp_path / "a").encode(), 0, 1, 1, C.c_double(1.0), C.byref(h)) == 1
+    assert lib.ghicp_pairqueue_create(None, str(tmp_path / "a").encode(), 2, 2, 0, C.c_double(1.0), C.byref(h)) == 1
+    assert lib.ghicp_pairqueue_create(None, str(tmp_path / "never").encode(), 1, 2, 0, C.c_double(0.5), C.byref(h)) == 5
+    assert lib.ghicp_pairqueue_create(None, str(tmp_path / "one").encode(), 0, 1, 0, C.c_double(1.0), C.byref(h)) == 0
+    first, n = C.c_int64(-1), C.c_int64(-1)
+    assert lib.ghicp_pairqueue_claim(h, C.c_int64(5), C.c_int64(7), C.byref(first), C.byref(n)) == 0 and (first.value, n.value) == (0, 5)
+    assert lib.ghicp_pairqueue_claim(h, C.c_int64(5), C.c_int64(7), C.byref(first), C.byref(n)) == 0 and (first.value, n.value) == (5, 2)
+    assert lib.ghicp_pairqueue_claim(h, C.c_int64(5), C.c_int64(7), C.byref(first), C.byref(n)) == 0 and (first.value, n.value) == (7, 0)
+    assert lib.ghicp_pairqueue_broadcast(h, None, C.c_int64(8), 0) == 1 and b"bad argument" in lib.ghicp_pairqueue_last_error(h)
+    assert lib.ghicp_pairqueue_destroy(h) == 0
