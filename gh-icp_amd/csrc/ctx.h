@@ -85,9 +85,10 @@ enum KtSlot { KT_PCA = 0, KT_BSC, KT_KM_SOLVE, KT_CD_ROWMIN, KT_KM_WEIGHTS, KT_F
               KT_FB_VOXEL, KT_FB_GRID, KT_FB_PRUNE, KT_FB_RANK, KT_FB_OUT,  // stages of the batched front end (batch.hip) around the kernels above
               KT_PAIR_LOOP,                                                  // the persistent pair loop (loop.hip): all classes of a batch, fork -> join
               KT_TRANSFORM,                                                  // S7 of a batch (ghicp_transform_clouds)
+              KT_PAIR_LOOP_DISPATCH,                                         // ONE k_pair_loop dispatch (a class launch of a batch), timed on the stream it runs on -- what rocprofv3's kernel trace reports per row
               KT_NUM };
 static const char* const kKtNames[KT_NUM] = {"pca_cells", "bsc", "km_solve", "cd_rowmin", "km_weights", "fd_bsc", "nms_round", "voxel_sort",
-                                             "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out", "pair_loop", "transform"};
+                                             "fb_voxel", "fb_grid", "fb_prune", "fb_rank", "fb_out", "pair_loop", "transform", "pair_loop_dispatch"};
 
 struct ghicp_ctx {
   // optional per-kernel timing
@@ -103,17 +104,20 @@ struct ghicp_ctx {
     (void)hipEventCreate(&e);
     return e;
   }
-  hipEvent_t kt_begin(int slot) {
+  hipEvent_t kt_begin(int slot) { return kt_begin_on(slot, stream); }
+  void kt_end(int slot, hipEvent_t a) { kt_end_on(slot, a, stream); }
+  // the same bracket on ANOTHER stream (the class streams of the persistent pair loop): an event only sees the stream it is recorded on
+  hipEvent_t kt_begin_on(int slot, hipStream_t st) {
     if (!kt_on) return nullptr;
     hipEvent_t a = kt_event();
-    (void)hipEventRecord(a, stream);
+    (void)hipEventRecord(a, st);
     (void)slot;
     return a;
   }
-  void kt_end(int slot, hipEvent_t a) {
+  void kt_end_on(int slot, hipEvent_t a, hipStream_t st) {
     if (!kt_on || !a) return;
     hipEvent_t b = kt_event();
-    (void)hipEventRecord(b, stream);
+    (void)hipEventRecord(b, st);
     kt_pending.push_back({slot, a, b});
   }
   void kt_collect() {  // stream must be idle

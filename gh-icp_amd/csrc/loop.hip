@@ -796,12 +796,14 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     if (ctx->loop_slots_cap > 0) grid = std::min(grid, ctx->loop_slots_cap);  // test hook (GHICP_LOOP_SLOTS)
     batch_slots = confined ? batch_slots + slots : std::max(batch_slots, slots);  // confined: the two classes have their own CUs, the capacities add up
     batch_grid += grid;
+    hipEvent_t kd = ctx->kt_begin_on(KT_PAIR_LOOP_DISPATCH, sc);  // this dispatch alone, on its own stream (behind the fork event)
     if (prof)
       hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
                          dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
     else
       hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
                          dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+    ctx->kt_end_on(KT_PAIR_LOOP_DISPATCH, kd, sc);
     GH_HIP_JOIN(hipGetLastError());
     if (c > 0 || confined) {
       GH_HIP_JOIN(hipEventRecord(ctx->aux_events[(size_t)c + 1], sc));
@@ -809,12 +811,14 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     }
     if (confined && c == 1) {  // ... and the four-per-CU class once more, on the confined CUs, after the three-per-CU class
       const int grid2 = std::min(plan.count[c], per_cu * confine_b);
+      hipEvent_t kd2 = ctx->kt_begin_on(KT_PAIR_LOOP_DISPATCH, ctx->confine_stream);
       if (prof)
         hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid2), dim3(K4_T), lds, ctx->confine_stream, dprobs, (const int*)(plan.d_order + plan.begin[c]),
                            plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
       else
         hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid2), dim3(K4_T), lds, ctx->confine_stream, dprobs, (const int*)(plan.d_order + plan.begin[c]),
                            plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+      ctx->kt_end_on(KT_PAIR_LOOP_DISPATCH, kd2, ctx->confine_stream);
       GH_HIP_JOIN(hipGetLastError());
       batch_grid += grid2;
       GH_HIP_JOIN(hipEventRecord(ctx->aux_events[(size_t)nc + 1], ctx->confine_stream));

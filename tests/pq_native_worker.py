@@ -19,11 +19,17 @@ def main():
     api = importlib.import_module("gh-icp_amd.api")
     pq = importlib.import_module("gh-icp_amd.pairqueue")
     synth = importlib.import_module("gh-icp_amd.synth")
-    ctx = api.Context(0)
+    if os.environ.get("GHICP_SIM") == "1":  # development aid: the same worker on the host SIMT interpreter (tests/hipsim), host transport only
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from hipsim import simctx
+
+        ctx = simctx.make_context(api)
+    else:
+        ctx = api.Context(0)
     q = pq.NativeQueue(path, rank, world, transport, ctx, timeout_s=240.0)
     # the manifest travels from rank 0 (ncclBroadcast / the segment): pair p registers scene manifest[p]
     manifest = q.broadcast_manifest([(3 * p + 1) % 7 for p in range(n_pairs)] if rank == 0 else [])
-    pairs = {sid: synth.tls_pair(60_000, pair_id=sid) for sid in sorted(set(manifest))}
+    pairs = {sid: synth.tls_pair(int(os.environ.get("GHICP_PQ_HITS", "60000")), pair_id=sid) for sid in sorted(set(manifest))}
     S = [torch.from_numpy(pairs[sid].source).to(ctx.dev) for sid in manifest]
     T = [torch.from_numpy(pairs[sid].target).to(ctx.dev) for sid in manifest]
     cfg = api.pair_config(api.FEATURE_BSC, api.CORR_KM, 6, 0.6, 0.2, 0.5, 1.5, synth.bsc_pattern_glibc(), max_iter=60)
