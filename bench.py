@@ -54,15 +54,23 @@ CONFIGS = {
             distinct=64, scaling="strong", unit_m=0.01),
     # (scene 0 of cfg5 never converges -- GPU and oracle both stop at the 200-iteration guard the reference does not have --, so the benchmark
     # pair is scene 1: 77 iterations on both sides, tests/golden/fullsize.json)
+    # the variants of cfg3 / cfg4 as SURVEY.md §8d wrote them (rounds 1-4; round-5 advisor: both must stay runnable): the reference algorithm
+    # does not register these on either side, parity with the oracle holds all the same
+    13: dict(name="cfg3 (surveyed stations 17 m / 40 deg apart): synthetic WHU-like TLS pairs, 5 M pts/scan", hits=5_000_000, voxel=0.1, r=0.5, R=1.5, feature="FPFH", corr="NNR", dof=6,
+             iou=0.6, B=16, distinct=2, scaling="weak", base=3, variant="surveyed"),
+    14: dict(name="cfg4 (surveyed: one depth frame, metres, 0.8 m / 25 deg apart): 64 3DMatch-like indoor fragment pairs, 100 k pts", hits=100_000, voxel=0.025, r=0.10, R=0.30,
+             feature="BSC", corr="NN", dof=6, iou=0.6, B=64, distinct=64, scaling="strong", base=4, variant="surveyed"),
     5: dict(name="cfg5: low-overlap levelled TLS pair, 10 M pts/scan", hits=10_000_000, voxel=0.1, r=0.5, R=1.5, feature="BSC", corr="KM", dof=4, iou=0.3, B=8, distinct=8, scaling="weak", first=8),  # seeds 8..15 (round 5: the acceptance rate is MEASURED over eight scenes -- round 4 quoted pair 8 alone, the one of seeds 0..15 the reference's verdict accepts: profiles/r04_cfg5_pair_search.json)
 }
 
 
 def make_pair(config_id, pair_id, hits):
     synth = importlib.import_module("gh-icp_amd.synth")
-    if config_id == 4:
-        return synth.indoor_pair(pair_id, hits)
-    return synth.tls_pair(hits, config_id=config_id, pair_id=pair_id)
+    variant = CONFIGS[config_id].get("variant", "registering")
+    base = CONFIGS[config_id].get("base", config_id)
+    if base == 4:
+        return synth.indoor_pair_surveyed(pair_id, hits) if variant == "surveyed" else synth.indoor_pair(pair_id, hits)
+    return synth.tls_pair(hits, config_id=base, pair_id=pair_id, variant=variant)
 
 
 def _gen_worker(a):
@@ -864,9 +872,9 @@ def main():
         jobs_cpu = [ids[i % len(ids)] for i in range(max(procs, len(ids)))]
         start_at = time.time() + (25.0 if big else 12.0) + 0.1 * len(jobs_cpu)
         with mp.get_context("spawn").Pool(procs) as pool:
-            # (the 5 M configuration checks ONE scene against the contract build here, the 10 M one none -- a second 1-4 minute run per scene
-            # otherwise --; their parity at full size is tests/test_gpu_fullsize.py's, against committed oracle fixtures)
-            ora_all = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at, j < (0 if not args.cpu_check else ((1 if hits < 8_000_000 else 0) if big else len(ids)))) for j, sid in enumerate(jobs_cpu)], chunksize=1)
+            # (the 5 M and 10 M configurations check ONE scene against the contract build here -- a second run of 10-60 s per scene --; every
+            # scene's parity at full size is tests/test_gpu_fullsize.py's, against committed oracle fixtures)
+            ora_all = pool.map(_oracle_worker, [(args.config, sid, hits, native, start_at, j < (0 if not args.cpu_check else (1 if big else len(ids)))) for j, sid in enumerate(jobs_cpu)], chunksize=1)
         wall = max(r["t1"] for r in ora_all) - min(r["t0"] for r in ora_all)
         t_pair = float(np.median([o["total"] for o in one]))
         stage_med = {k: round(float(np.median([o[k] for o in one])), 3) for k in one[0]}

@@ -4,11 +4,16 @@ Everything here is a pure function of an integer seed; the RNG is SplitMix64 use
 counter-style (value i of stream `seed` = mix(seed + (i+1)*GAMMA)), so the same
 arrays can be regenerated anywhere (numpy only, no GPU, no files).
 
-Configs (BASELINE.json `configs`, geometry fixed by SURVEY.md §8d):
+Configs (BASELINE.json `configs`).  cfg1, cfg2 and cfg5 have the geometry SURVEY.md §8d fixes.  cfg3 and cfg4 exist in TWO variants since
+round 5 (round-5 advisor: the change must be explicit, BASELINE.md §4 reports both):
   cfg1  gauss_pair        two 50k-pt Gaussian blobs, explicit keypoints, N/N, 6-DoF
   cfg2  tls_pair(1M)      ray-cast TLS scene 120x120 m, stations 13 m / 30 deg apart
-  cfg3  tls_pair(5M)      same scene, finer angular grid, station B = (5,-2.5,0), yaw -12 (round 5; rounds 1-4: (15,-8,0), yaw -40)
-  cfg4  indoor_pair       3DMatch-like fragments: three fused depth frustums, cluttered room, centimetres (~100k pts)
+  cfg3  tls_pair(5M)      same scene, finer angular grid.  variant "registering" (default; bench.py --config 3): station B = (5,-2.5,0), yaw -12 --
+                          inside the basin of the reference's FPFH + reciprocal-NN loop.  variant "surveyed" (bench.py --config 13): SURVEY.md
+                          §8d's station B = (15,-8,0), yaw -40 (rounds 1-4) -- the reference algorithm does NOT register it, on either side
+  cfg4  indoor_pair       3DMatch-like fragments.  variant "registering" (default; --config 4): three fused depth frustums, cluttered room,
+                          CENTIMETRES, poses 0.4 m / 12 deg apart.  variant "surveyed" (--config 14): SURVEY.md §8d's single frustum in metres,
+                          poses 0.8 m / 25 deg apart, voxel 0.025 / r_pca 0.10 / R_nms 0.30 (rounds 1-4: 19-53 keypoints, 1 of 64 pairs accepted)
   cfg5  tls_pair(10M)     200x200 m scene, station B = (38,12,0), yaw 55, levelled
 """
 from __future__ import annotations
@@ -217,10 +222,14 @@ def _scan(scene: Scene, rng: SplitMix64, pos, R: np.ndarray, n_hits: int, tmax: 
     return np.concatenate(out)[:n_hits]
 
 
-def tls_pair(n_hits: int = 1_000_000, config_id: int = 2, pair_id: int = 0) -> Pair:
-    """cfg2/3/5. Target = station A (identity attitude), Source = station B."""
+def tls_pair(n_hits: int = 1_000_000, config_id: int = 2, pair_id: int = 0, variant: str = "registering") -> Pair:
+    """cfg2/3/5. Target = station A (identity attitude), Source = station B.  `variant` only matters for cfg3."""
+    if variant not in ("registering", "surveyed"):
+        raise ValueError("variant must be 'registering' or 'surveyed'")
     rng = SplitMix64(seed_for(config_id, pair_id))
-    if config_id == 3:
+    if config_id == 3 and variant == "surveyed":
+        half, tmax, b_xy, yaw, pr = 60.0, 60.0, (15.0, -8.0), -40.0, 1.0  # SURVEY.md §8d as written (rounds 1-4)
+    elif config_id == 3:
         # FPFH + reciprocal NN has no global stage: its energy is CD = ED / FD^(1/k), i.e. the Euclidean distance as soon as the histograms
         # agree (they do on man-made surfaces: median |correlation| 0.9998), so the pair must start inside the basin of a reciprocal-NN ICP.
         # 17 m / 40 deg (rounds 1-4) ended 0.9 rad / 16 m from the truth on BOTH sides; 5.6 m / 12 deg registers (oracle at full size, seeds
@@ -248,8 +257,54 @@ def tls_pair(n_hits: int = 1_000_000, config_id: int = 2, pair_id: int = 0) -> P
 INDOOR_UNIT_M = 0.01  # cfg4 coordinates are CENTIMETRES (see indoor_pair)
 
 
+def indoor_pair_surveyed(pair_id: int = 0, n_pts: int = 100_000) -> Pair:
+    """cfg4 as SURVEY.md §8d wrote it (rounds 1-4): room 6 x 5 x 3 m + 8-15 furniture boxes, ONE pin-hole depth frustum 58 x 45 deg,
+    0.4-3.5 m, two poses ~0.8 m / 25 deg apart, sigma 2 mm, METRES in each camera frame (x fwd, y left, z up)."""
+    rng = SplitMix64(seed_for(4, pair_id))
+    nb = 8 + int(rng.uniform(1)[0] * 8)
+    boxes = []
+    for _ in range(nb):
+        u = rng.uniform(5)
+        sx, sy, h = 0.3 + 1.2 * u[0], 0.3 + 1.2 * u[1], 0.3 + 1.5 * u[2]
+        cx, cy = (2 * u[3] - 1) * (3.0 - sx / 2), (2 * u[4] - 1) * (2.5 - sy / 2)
+        if math.hypot(cx, cy) < 1.0 + max(sx, sy) / 2:
+            continue
+        boxes.append([cx - sx / 2, cy - sy / 2, cx + sx / 2, cy + sy / 2, 0.0, h])
+    walls = np.array([[-3.2, -2.5, -3.0, 2.5, 0, 3.0], [3.0, -2.5, 3.2, 2.5, 0, 3.0],
+                      [-3.0, -2.7, 3.0, -2.5, 0, 3.0], [-3.0, 2.5, 3.0, 2.7, 0, 3.0],
+                      [-3.2, -2.7, 3.2, 2.7, 3.0, 3.2]])
+    scene = Scene(3.0, np.concatenate([np.array(boxes).reshape(-1, 6), walls]), np.zeros((0, 4)))
+    u = rng.uniform(6)
+    yaw0 = 360.0 * u[0]
+    pa = np.array([0.4 * (2 * u[1] - 1), 0.4 * (2 * u[2] - 1), 1.3])
+    Ra = rot_zyx(yaw0, 8.0, 0.0)
+    pb = pa + rot_zyx(yaw0 + 90.0, 0, 0) @ np.array([0.8, 0.0, 0.0]) * (0.8 + 0.4 * u[3])
+    Rb = rot_zyx(yaw0 + 25.0 * (1 if u[4] > 0.5 else -1), 8.0 + 4 * (u[5] - 0.5), 2.0)
+
+    def frame(pos, R):
+        hx, hy = math.tan(math.radians(29.0)), math.tan(math.radians(22.5))
+        side = int(math.sqrt(n_pts * 1.6))
+        out, got = [], 0
+        while got < n_pts:
+            j = rng.uniform(2 * side * side)
+            gx = (np.tile(np.arange(side), side) + j[: side * side]) / side * 2 - 1
+            gy = (np.repeat(np.arange(side), side) + j[side * side:]) / side * 2 - 1
+            d = np.stack([np.ones_like(gx), gx * hx, gy * hy], axis=1)
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            t = _raycast(scene, pos, d @ R.T, 3.5)
+            hit = np.isfinite(t) & (t > 0.4)
+            t = t[hit] + 0.002 * rng.normal(t.size)[hit]
+            out.append((d[hit] * t[:, None]).astype(np.float32))
+            got += out[-1].shape[0]
+        return np.concatenate(out)[:n_pts]
+
+    T = frame(pa, Ra)
+    S = frame(pb, Rb)
+    return Pair(S, T, rt44(Ra.T @ Rb, Ra.T @ (pb - pa)), "indoor_surveyed%d" % pair_id)
+
+
 def indoor_pair(pair_id: int = 0, n_pts: int = 100_000) -> Pair:
-    """cfg4: 3DMatch-like fragment pairs.  Room 6 x 5 x 3 m with 8-15 furniture boxes, ~30 small objects (5-40 cm boxes on the floor or on
+    """cfg4 (variant "registering"; `indoor_pair_surveyed` is SURVEY.md §8d's): 3DMatch-like fragment pairs.  Room 6 x 5 x 3 m with 8-15 furniture boxes, ~30 small objects (5-40 cm boxes on the floor or on
     shelves) and ~12 thin posts / lamp stands (vertical cylinders, r 3-15 cm).  A fragment is what a 3DMatch fragment is: SEVERAL depth frames
     fused in the frame of the middle one -- three pin-hole frustums of 58 x 45 deg, 0.4-3.5 m, from one position, 20 deg of yaw apart, range
     noise sigma 2 mm.  The two fragments are ~0.4 m / 12 deg apart.  Coordinates are in CENTIMETRES in each fragment's frame (x fwd, y left,
