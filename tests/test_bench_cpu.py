@@ -45,7 +45,9 @@ def test_compact_keeps_the_line_below_the_drivers_tail():
 
 def test_config_table_matches_baseline_json():
     cfgs = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
-    assert len(cfgs) == 5 and sorted(bench.CONFIGS) == [2, 3, 4, 5]  # configs[0] is the CPU-runnable cfg1 (tests), 2..5 are bench lines
+    # configs[0] is the CPU-runnable cfg1 (tests), 2..5 are bench lines; 13 / 14 = cfg3 / cfg4 with the geometry SURVEY.md §8d wrote
+    assert len(cfgs) == 5 and sorted(bench.CONFIGS) == [2, 3, 4, 5, 13, 14]
+    assert bench.CONFIGS[13]["base"] == 3 and bench.CONFIGS[14]["base"] == 4 and (bench.CONFIGS[14]["voxel"], bench.CONFIGS[14]["r"], bench.CONFIGS[14]["R"]) == (0.025, 0.10, 0.30)
     assert bench.CONFIGS[2]["feature"] == "BSC" and bench.CONFIGS[2]["corr"] == "KM" and bench.CONFIGS[2]["hits"] == 1_000_000 and bench.CONFIGS[2]["voxel"] == 0.1
     assert bench.CONFIGS[3]["feature"] == "FPFH" and bench.CONFIGS[3]["corr"] == "NNR" and bench.CONFIGS[3]["hits"] == 5_000_000
     assert bench.CONFIGS[4]["B"] == 64 and bench.CONFIGS[4]["scaling"] == "strong"

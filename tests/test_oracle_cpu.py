@@ -556,3 +556,20 @@ def test_bsc_bits_under_the_correctly_rounded_exp(oracle, synth):
         kps += f0.shape[1]
     assert flipped <= max(4, int(2e-5 * bits)), (flipped, bits)
     assert changed <= max(2, kps // 50), (changed, kps)
+
+
+def test_surveyed_scene_variants_are_the_geometry_of_survey_8d(synth):
+    """cfg3 / cfg4 exist in two variants since round 5 (round-5 advisor): the default ones register, the `surveyed` ones are SURVEY.md §8d's
+    geometry -- stations (15, -8, 0) / yaw -40 for cfg3; one depth frame in metres, poses ~0.8 m / 25 deg apart for cfg4."""
+    a = synth.tls_pair(4000, config_id=3, pair_id=1, variant="surveyed")
+    b = synth.tls_pair(4000, config_id=3, pair_id=1)
+    np.testing.assert_allclose(a.gt[:3, 3], [15.0, -8.0, 0.0], atol=1e-12)
+    np.testing.assert_allclose(b.gt[:3, 3], [5.0, -2.5, 0.0], atol=1e-12)
+    assert abs(np.degrees(np.arctan2(a.gt[1, 0], a.gt[0, 0])) + 40.0) < 0.1 and abs(np.degrees(np.arctan2(b.gt[1, 0], b.gt[0, 0])) + 12.0) < 0.1
+    s = synth.indoor_pair_surveyed(3, 5000)
+    r = synth.indoor_pair(3, 5000)
+    assert s.source.shape == (5000, 3) and np.abs(s.source).max() < 8.0 and np.abs(r.source).max() > 50.0  # metres against centimetres
+    ang = np.degrees(np.arccos(np.clip((np.trace(s.gt[:3, :3]) - 1) / 2, -1, 1)))
+    assert 20.0 < ang < 32.0 and 0.6 < np.linalg.norm(s.gt[:3, 3]) < 1.0
+    with pytest.raises(ValueError):
+        synth.tls_pair(100, config_id=3, variant="nope")
