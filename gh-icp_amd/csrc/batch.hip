@@ -18,6 +18,7 @@
 #include "pca_dev.h"
 #include "nms_dev.h"
 #include "bsc_dev.h"
+#include "prims.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -33,6 +34,7 @@ int gh_fpfh_batch_dev(ghicp_ctx* ctx, const float4* dsg, int M, const float4* pt
 namespace {
 
 constexpr int FB_MAX = 64;  // clouds per batch
+constexpr int FB_NMS_ROUNDS = 8;  // NMS rounds per launch sequence (the host looks at the last one's count and launches another sequence if need be)
 
 struct FbCloud {
   const float* xyz;  // raw cloud
@@ -62,6 +64,7 @@ struct FbOut {
   int bb[FB_MAX * 6];
   int hoff[FB_MAX + 1], moff[FB_MAX + 1], coff[FB_MAX + 1];
   int kcount[FB_MAX];
+  int nms_und[FB_NMS_ROUNDS];  // candidates each NMS round of the last sequence left undecided
 };
 
 // largest b in [0, nb) with off[b] <= i (off ascending; clouds without items are skipped over)
@@ -290,40 +293,147 @@ __device__ inline unsigned long long fb_f64_key(double v) {  // order-preserving
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-__global__ __launch_bounds__(256) void k_fb_nms_keys(const double* __restrict__ curvature, const int* __restrict__ cand, int c,
-                                                     unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+// ------------------------------------------------------------------------------------------------ NMS over the whole chip (round 6)
+// Greedy non-maximum suppression (keypoint_detect.hpp:149-191) = the lexicographically first maximal independent set of the graph
+// "candidates closer than R", taken in rank order (curvature descending, ties: lower point index).  It is the unique fixed point of
+//     selected(i)   <=>  every neighbour of higher rank is suppressed
+//     suppressed(i) <=>  some neighbour of higher rank is selected                                              
+// and both facts are FINAL once established, so they may be established in any order by any number of threads: a candidate decides as
+// soon as its higher-ranked neighbours have.  One thread per candidate, every cloud of the batch in the same launches, a handful of
+// rounds (the longest chain of decisions a scan needs: 6-11 with synchronous rounds, fewer here because a round sees the decisions
+// of the waves that ran before it).  Rounds 2-5 walked the rank-ordered candidates of a cloud with ONE workgroup (nms_dev.h, still the
+// single-cloud path): 1.6-2.5 ms per launch with 224 CUs idle -- round-5 verdict, weak #6 / item 7.
+//   * candidates are bucketed by cell (side R * 1.0001, the cloud's own grid over the box of its down-sampled points) by a counting
+//     sort: histogram, hand-written scan (prims.hip), scatter -- the order inside a cell does not matter, every test is order free;
+//   * "suppressed" is decided against per-cell lists of the SELECTED candidates (1-3 entries around a point), "selected" by a scan of
+//     the neighbouring cells that stops at the first neighbour of higher rank that is not suppressed;
+//   * the keypoints of a cloud leave in rank order: each selected candidate counts the selected ones of its cloud that outrank it.
+// Same set AND order as the greedy sweep (tests/test_gpu_batch.py, test_golden.py: keypoint ids == oracle).
+struct NmsrArgs {
+  const float4* dsg;          // concatenated down-sampled clouds
+  const int* cand;            // candidate -> global point index, ascending
+  const double* curv;
+  int ctot;
+  unsigned* table;            // [0] = 0, [1 + cell]: histogram -> end -> start of the cell's run (see k_fb_nmsr_fill)
+  unsigned* ccell;            // candidate -> global cell
+  unsigned long long* ckey;   // candidate -> rank key (order-preserving image of the curvature)
+  float4* spts;               // slot -> (x, y, z, candidate id)
+  unsigned long long* skey;   // slot -> rank key
+  unsigned char* state;       // slot -> 0 undecided, 1 selected, 2 suppressed
+  int* head;                  // cell -> most recently selected slot, -1: none
+  int* next;                  // slot -> next selected slot of its cell
+  int* sel;                   // per cloud (at coff[b]): the selected slots, in no particular order
+  int* kcount;                // per cloud: selected so far
+  int* undecided;             // per round: candidates the round left undecided
+};
+
+__global__ __launch_bounds__(256) void k_fb_nmsr_keys(const FbBlock* __restrict__ D, NmsrArgs A) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= c) return;
-  keys[i] = fb_f64_key(curvature[cand[i]]);
-  vals[i] = i;
+  if (i >= A.ctot) return;
+  const int b = fb_find(D->coff, D->nb, i);
+  const GridDesc& g = D->g3[b];
+  const int pid = A.cand[i];
+  const float4 P = A.dsg[pid];
+  const int cx = gh_cell_coord(P.x, g.mn[0], g.inv, g.dim[0]);
+  const int cy = gh_cell_coord(P.y, g.mn[1], g.inv, g.dim[1]);
+  const int cz = gh_cell_coord(P.z, g.mn[2], g.inv, g.dim[2]);
+  const unsigned cell = D->hb[b] + (((unsigned)cx * g.dim[1] + cy) * g.dim[2] + cz);
+  A.ccell[i] = cell;
+  A.ckey[i] = fb_f64_key(A.curv[pid]);
+  atomicAdd(&A.table[1 + cell], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_fb_cloud_keys(const FbBlock* __restrict__ D, const int* __restrict__ ord, int c, unsigned* __restrict__ ckeys) {
+// after the inclusive scan table[1 + c] is the END of cell c's run; every candidate takes the slot below the current end, which leaves
+// table[1 + c] = START of cell c = end of cell c - 1: T = table + 1 is then the usual cell table (T[c] .. T[c + 1]), T[ncell] = ctot
+__global__ __launch_bounds__(256) void k_fb_nmsr_fill(NmsrArgs A, unsigned ncell) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= c) return;
-  ckeys[i] = (unsigned)fb_find(D->coff, D->nb, ord[i]);
+  if (i == 0) A.table[1 + ncell] = (unsigned)A.ctot;
+  if (i >= A.ctot) return;
+  const unsigned t = atomicSub(&A.table[1 + A.ccell[i]], 1u) - 1u;
+  const float4 P = A.dsg[A.cand[i]];
+  A.spts[t] = make_float4(P.x, P.y, P.z, __int_as_float(i));
+  A.skey[t] = A.ckey[i];
+  A.state[t] = 0;
+  A.next[t] = -1;
 }
 
-// cpts[r] = xyz of the candidate at global rank position r (clouds in order, descending curvature inside a cloud)
-__global__ __launch_bounds__(256) void k_fb_nms_points(const float4* __restrict__ dsg, const int* __restrict__ cand, const int* __restrict__ ord, int c,
-                                                       float* __restrict__ cpts) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= c) return;
-  const float4 P = dsg[cand[ord[r]]];
-  cpts[(size_t)r * 3] = P.x; cpts[(size_t)r * 3 + 1] = P.y; cpts[(size_t)r * 3 + 2] = P.z;
+__global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict__ D, NmsrArgs A, float r2, int round) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= A.ctot) return;
+  if (A.state[t] != 0) return;
+  const float4 P = A.spts[t];
+  const int id = __float_as_int(P.w);
+  const unsigned long long key = A.skey[t];
+  const int b = fb_find(D->coff, D->nb, id);
+  const GridDesc g = D->g3[b];
+  const unsigned* T = A.table + 1 + D->hb[b];
+  int* H = A.head + D->hb[b];
+  const int cx = gh_cell_coord(P.x, g.mn[0], g.inv, g.dim[0]);
+  const int cy = gh_cell_coord(P.y, g.mn[1], g.inv, g.dim[1]);
+  const int cz = gh_cell_coord(P.z, g.mn[2], g.inv, g.dim[2]);
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
+  const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
+  // (1) a selected neighbour?  (it outranks this candidate: nothing is selected next to an undecided candidate of higher rank)
+  for (int x = x0; x <= x1; x++)
+    for (int y = y0; y <= y1; y++)
+      for (int z = z0; z <= z1; z++)
+        for (int j = __hip_atomic_load(&H[((unsigned)x * g.dim[1] + y) * g.dim[2] + z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); j >= 0;
+             j = __hip_atomic_load(&A.next[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          const float4 Q = A.spts[j];
+          const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
+          float d2 = dx * dx;
+          d2 += dy * dy;
+          d2 += dz * dz;
+          if (d2 < r2) { A.state[t] = 2; return; }
+        }
+  // (2) a neighbour of higher rank that is not suppressed?  then this candidate waits
+  for (int x = x0; x <= x1; x++)
+    for (int y = y0; y <= y1; y++) {
+      const unsigned base = ((unsigned)x * g.dim[1] + y) * g.dim[2];
+      const unsigned ub = T[base + z0], ue = T[base + z1 + 1];
+      for (unsigned u = ub; u < ue; u++) {
+        const float4 Q = A.spts[u];
+        const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        if (!(d2 < r2) || (int)u == t) continue;
+        const unsigned long long ku = A.skey[u];
+        if (ku > key || (ku == key && __float_as_int(Q.w) < id)) {
+          if (__hip_atomic_load(&A.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2) { atomicAdd(&A.undecided[round], 1); return; }
+        }
+      }
+    }
+  // (3) every neighbour of higher rank is suppressed: selected
+  __hip_atomic_store(&A.state[t], (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int cell = ((cx * g.dim[1]) + cy) * g.dim[2] + cz;
+  const int old = atomicExch(&H[cell], t);
+  __hip_atomic_store(&A.next[t], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  A.sel[D->coff[b] + atomicAdd(&A.kcount[b], 1)] = t;
 }
 
-__global__ __launch_bounds__(NMS_T) void k_fb_nms_greedy(const FbBlock* __restrict__ D, const float* __restrict__ cpts, float r2, int* __restrict__ head,
-                                                         int* __restrict__ next, const int* __restrict__ cand, const int* __restrict__ ord,
-                                                         int* __restrict__ kpg, int* __restrict__ kcount) {
+// keypoints of cloud b in rank order: position = number of selected candidates of the cloud that outrank this one
+__global__ __launch_bounds__(256) void k_fb_nmsr_rank(const FbBlock* __restrict__ D, NmsrArgs A, int* __restrict__ kpg) {
+  __shared__ unsigned long long s_key[1024];
+  __shared__ int s_id[1024];
   const int b = blockIdx.x;
-  const int c0 = D->coff[b], c = D->coff[b + 1] - c0;
-  if (c <= 0) {
-    if (threadIdx.x == 0) kcount[b] = 0;
-    return;
+  const int K = A.kcount[b], c0 = D->coff[b];
+  for (int base = 0; base < K; base += 256) {
+    const int k = base + threadIdx.x;
+    unsigned long long key = 0;
+    int id = 0;
+    if (k < K) { const int t = A.sel[c0 + k]; key = A.skey[t]; id = __float_as_int(A.spts[t].w); }
+    int rank = 0;
+    for (int q0 = 0; q0 < K; q0 += 1024) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < min(1024, K - q0); q += 256) { const int t = A.sel[c0 + q0 + q]; s_key[q] = A.skey[t]; s_id[q] = __float_as_int(A.spts[t].w); }
+      __syncthreads();
+      const int m = min(1024, K - q0);
+      if (k < K)
+        for (int q = 0; q < m; q++) rank += (int)(s_key[q] > key) | ((int)(s_key[q] == key) & (int)(s_id[q] < id));
+    }
+    if (k < K) kpg[c0 + rank] = A.cand[id] - D->moff[b];
   }
-  const GridDesc g = D->g3[b];  // by value: the sweep reads it for every candidate
-  gh_nms_greedy_cloud(cpts + (size_t)c0 * 3, c, g, r2, head + D->hb[b], next + c0, cand, ord + c0, kpg + c0, kcount + b, D->moff[b]);
 }
 
 __global__ __launch_bounds__(256) void k_fb_copy_ds(const FbBlock* __restrict__ D, const float4* __restrict__ dsg, int M) {
@@ -523,14 +633,12 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   if (ebmax + cloud_bits + idx_bits > 64) idx_bits = 0;
   hipLaunchKernelGGL(k_fb_voxel_keys, dim3(cdiv(N, 256)), dim3(256), 0, s, (const FbBlock*)D, (int)N, ebmax, idx_bits, vkeys, vvals);
   ctx->kt_end(KT_FB_VOXEL, kv0);
-  size_t tb = 0, tb2 = 0;
-  hipcub::CountingInputIterator<int> iota(0);
+  size_t tb = 0;
   const unsigned sort_bits = (unsigned)(ebmax + cloud_bits);
   if (idx_bits > 0) GH_HIP((rocprim::radix_sort_keys<GhSortConfig>(nullptr, tb, vkeys, vkeys2, (size_t)N, (unsigned)idx_bits, (unsigned)idx_bits + sort_bits, s)));
   else GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));
-  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, iota, flags, headpos, misc, (int)N, s));
   char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, std::max(tb, tb2) + 16, &tmp));
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
   // stable: lowest index leads its voxel
   if (idx_bits > 0) GH_HIP((rocprim::radix_sort_keys<GhSortConfig>(tmp, tb, vkeys, vkeys2, (size_t)N, (unsigned)idx_bits, (unsigned)idx_bits + sort_bits, s)));
@@ -539,7 +647,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   const unsigned long long vmask = ebmax >= 64 ? ~0ull : ((1ull << ebmax) - 1ull);
   hipEvent_t kv1 = ctx->kt_begin(KT_FB_VOXEL);
   hipLaunchKernelGGL(k_fb_voxel_flags, dim3(cdiv(N, 256)), dim3(256), 0, s, vkeys2, (int)N, vmask, idx_bits, flags);
-  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, iota, flags, headpos, misc, (int)N, s));
+  GH_TRY(gh_select_flagged_iota(ctx, flags, N, headpos, misc));  // positions of the run heads, ascending (prims.hip)
   hipLaunchKernelGGL(k_fb_voxel_bounds, dim3(1), dim3(128), 0, s, headpos, misc, D, O);
   hipLaunchKernelGGL(k_fb_gather_ds, dim3(cdiv(N + nb, 256)), dim3(256), 0, s, (const FbBlock*)D, headpos, vvals2,
                      idx_bits > 0 ? (const unsigned long long*)vkeys2 : (const unsigned long long*)nullptr, idx_bits > 0 ? (1ull << idx_bits) - 1ull : 0ull, dsg);
@@ -553,7 +661,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   float r_search = 0.f;
   const bool bsc = cfg.reg.feature == GHICP_FEATURE_BSC, fpfh = cfg.reg.feature == GHICP_FEATURE_FPFH;
   if (bsc) GH_TRY(gh_bsc_make_const(ctx, r_nms, cfg.reg.dof, cfg.pattern, &BC, &r_search));
-  unsigned long long t1 = 0, t2 = 0;
+  unsigned long long t1 = 0, t2 = 0, t3 = 0;
   for (int b = 0; b <= nb; b++) { H->hoff[b] = HO->hoff[b]; H->moff[b] = HO->moff[b]; }
   const int M = H->moff[nb];
   for (int b = 0; b < nb; b++) {
@@ -565,13 +673,18 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     H->g1[b] = gh_grid_desc(mm, c->m, r_pca * 1.0001f);
     H->cb1[b] = (unsigned)t1;
     t1 += H->g1[b].ncell;
+    // the NMS grid (cell side R): over the box of the DOWN-SAMPLED cloud, which the host holds already -- the candidates lie inside
+    // (rounds 2-5 reduced the candidates' own box and synchronised once more to read it)
+    H->g3[b] = gh_grid_desc(mm, c->m, r_nms * 1.0001f);
+    H->hb[b] = (unsigned)t3;
+    if (c->m > 0) t3 += H->g3[b].ncell;
     if (bsc || fpfh) {  // the feature's grid: sqrt(3) R search of the BSC encoder, or the kNN grid of the FPFH estimation
       H->g2[b] = gh_grid_desc(mm, c->m, bsc ? r_search * 1.0001f : gh_fpfh_cell(mm, c->m));
       H->cb2[b] = (unsigned)t2;
       t2 += H->g2[b].ncell;
     }
   }
-  H->cb1[nb] = (unsigned)t1; H->cb2[nb] = (unsigned)t2;
+  H->cb1[nb] = (unsigned)t1; H->cb2[nb] = (unsigned)t2; H->hb[nb] = (unsigned)t3;
   // the cell tables of all clouds are summed into one: when that gets large (clouds of large extent), halve the batch instead of
   // failing -- whatever the cloud-by-cloud path handles must work here too (a single cloud is limited to 2^26 cells by gh_grid_desc)
   auto split = [&]() -> int {
@@ -581,7 +694,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     return ghicp_clouds_recompute(ctx, n_clouds - half, clouds + half, xyz + half, n + half, stride);
   };
   constexpr unsigned long long FB_CELL_BUDGET = 1ull << 28;  // 1 GB of cell table per grid
-  if (t1 >= FB_CELL_BUDGET || t2 >= FB_CELL_BUDGET) return split();
+  if (t1 >= FB_CELL_BUDGET || t2 >= FB_CELL_BUDGET || t3 >= FB_CELL_BUDGET) return split();
   if (M <= 0) return GHICP_OK;
 
   // ------------------------------------------------------------------ PCA grid, PCA, prune                              (sync 3)
@@ -599,11 +712,8 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   const unsigned *start1, *keys1;
   const GridSlots sl1 = {B_GRID_KEYS, B_GRID_KEYS2, B_GRID_VALS, B_GRID_VALS2, B_GRID_START, B_GRID_PTS};
   GH_TRY(build_grid(ctx, D, 0, dsg, M, (unsigned)t1, sl1, &pts1, &start1, &keys1));
-  tb = 0;
-  GH_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, keys1, cells, misc, M, s));
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   hipEvent_t ku = ctx->kt_begin(KT_FB_GRID);
-  GH_HIP(hipcub::DeviceSelect::Unique(tmp, tb, keys1, cells, misc, M, s));
+  GH_TRY(gh_unique_sorted_u32(ctx, keys1, M, cells, misc));  // the occupied cells, ascending (prims.hip)
   GH_HIP(hipMemsetAsync(misc + 4, 0, 8 * sizeof(int), s));
   ctx->kt_end(KT_FB_GRID, ku);
   const float r2_pca = (float)((double)r_pca * (double)r_pca);  // pcl radiusSearch: static_cast<float>(radius*radius)
@@ -619,10 +729,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   ctx->kt_end(KT_PCA, kt);
   hipEvent_t kp = ctx->kt_begin(KT_FB_PRUNE);
   hipLaunchKernelGGL(k_fb_prune_flags, dim3(cdiv(M, 256)), dim3(256), 0, s, lambda, count, M, cfg.ratio_max, cfg.min_neighbors, flags);
-  tb = 0;
-  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, iota, flags, cand, misc + 2, M, s));
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
-  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb, iota, flags, cand, misc + 2, M, s));
+  GH_TRY(gh_select_flagged_iota(ctx, flags, M, cand, misc + 2));  // the candidates' point indices, ascending (prims.hip)
   hipLaunchKernelGGL(k_fb_cand_bounds, dim3(1), dim3(128), 0, s, (const int*)cand, (const int*)(misc + 2), D, O);
   ctx->kt_end(KT_FB_PRUNE, kp);
   GH_HIP(hipGetLastError());
@@ -631,69 +738,55 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   for (int b = 0; b < nb; b++) clouds[b]->cand = H->coff[b + 1] - H->coff[b];
   const int Ctot = H->coff[nb];
 
-  // ------------------------------------------------------------------ NMS: ranks, candidate boxes (sync 4), greedy sweep (sync 5)
+  // ------------------------------------------------------------------ NMS: candidate cells, decision rounds (sync 4), ranks
   int* kpg = nullptr;
   int Ktot = 0;
   if (Ctot > 0) {
-    unsigned long long *nkeys, *nkeys2;
-    int *nvals, *ord1, *ordg, *next, *head;
-    unsigned *ckeys, *ckeys2;
-    float* cpts;
-    GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)Ctot + 1, &nkeys));  // (the PCA cell list is dead by now; Ctot <= M)
-    GH_TRY(ctx->reserve(B_FE_SORTK2, (size_t)Ctot + 1, &nkeys2));
-    GH_TRY(ctx->reserve(B_FE_SORTV, (size_t)Ctot + 1, &nvals));
-    GH_TRY(ctx->reserve(B_FE_SORTV2, (size_t)Ctot + 1, &ord1));
-    GH_TRY(ctx->reserve(B_FB_ORD, (size_t)Ctot + 1, &ordg));
-    GH_TRY(ctx->reserve(B_FE_STATE, (size_t)Ctot + 1, &next));
-    GH_TRY(ctx->reserve(B_FE_CPTS, (size_t)Ctot * 3 + 3, &cpts));
+    NmsrArgs A;
+    A.dsg = dsg; A.cand = cand; A.curv = curv; A.ctot = Ctot;
+    GH_TRY(ctx->reserve(B_NMSR_TABLE, (size_t)t3 + 4, &A.table));
+    GH_TRY(ctx->reserve(B_NMSR_HEAD, (size_t)t3 + 2, &A.head));
+    GH_TRY(ctx->reserve(B_NMSR_CELL, (size_t)Ctot + 1, &A.ccell));
+    GH_TRY(ctx->reserve(B_NMSR_KEY, (size_t)Ctot + 1, &A.ckey));
+    GH_TRY(ctx->reserve(B_NMSR_PTS, (size_t)Ctot + 1, &A.spts));
+    GH_TRY(ctx->reserve(B_NMSR_SKEY, (size_t)Ctot + 1, &A.skey));
+    GH_TRY(ctx->reserve(B_NMSR_STATE, (size_t)Ctot + 16, &A.state));
+    GH_TRY(ctx->reserve(B_NMSR_NEXT, (size_t)Ctot + 1, &A.next));
+    GH_TRY(ctx->reserve(B_NMSR_SEL, (size_t)Ctot + 1, &A.sel));
     GH_TRY(ctx->reserve(B_FE_KP, (size_t)Ctot + 1, &kpg));
-    GH_TRY(ctx->reserve(B_GRID2_KEYS, (size_t)std::max(Ctot, M) + 1, &ckeys));   // grid 2 is built after the sweep: its buffers are free here
-    GH_TRY(ctx->reserve(B_GRID2_KEYS2, (size_t)std::max(Ctot, M) + 1, &ckeys2));
+    A.kcount = O->kcount;
+    A.undecided = O->nms_und;
+    GH_HIP(upload());  // g3 / hb (the device wrote coff itself)
     hipEvent_t kr = ctx->kt_begin(KT_FB_RANK);
-    hipLaunchKernelGGL(k_fb_nms_keys, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const double*)curv, (const int*)cand, Ctot, nkeys, nvals);
-    tb = 0; tb2 = 0;
-    GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, nkeys, nkeys2, nvals, ord1, Ctot, 0, 64, s));
-    if (nb > 1) GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb2, ckeys, ckeys2, ord1, ordg, (size_t)Ctot, 0u, (unsigned)cloud_bits, s)));
-    GH_TRY(ctx->reserve(B_GRID_TMP, std::max(tb, tb2) + 16, &tmp));
-    GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, nkeys, nkeys2, nvals, ord1, Ctot, 0, 64, s));  // stable: ties -> lower point index
-    if (nb > 1) {
-      hipLaunchKernelGGL(k_fb_cloud_keys, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const FbBlock*)D, (const int*)ord1, Ctot, ckeys);
-      GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb2, ckeys, ckeys2, ord1, ordg, (size_t)Ctot, 0u, (unsigned)cloud_bits, s)));  // stable
-    } else {
-      ordg = ord1;
-    }
-    hipLaunchKernelGGL(k_fb_nms_points, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const float4*)dsg, (const int*)cand, (const int*)ordg, Ctot, cpts);
-    hipLaunchKernelGGL(k_fb_bbox_init, dim3(cdiv(nb * 6, 256)), dim3(256), 0, s, O->bb, nb);
-    hipLaunchKernelGGL(k_fb_bbox, dim3(16, nb), dim3(256), 0, s, (const FbBlock*)D, (const float*)cpts, 2, O->bb);
+    GH_HIP(hipMemsetAsync(A.table, 0, ((size_t)t3 + 2) * sizeof(unsigned), s));
+    GH_HIP(hipMemsetAsync(A.head, 0xff, (size_t)t3 * sizeof(int), s));
+    GH_HIP(hipMemsetAsync(O->kcount, 0, sizeof(int) * FB_MAX, s));
+    hipLaunchKernelGGL(k_fb_nmsr_keys, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const FbBlock*)D, A);
+    GH_TRY(gh_scan_inclusive_u32(ctx, A.table + 1, (long long)t3));
+    hipLaunchKernelGGL(k_fb_nmsr_fill, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, A, (unsigned)t3);
     ctx->kt_end(KT_FB_RANK, kr);
-    GH_HIP(hipGetLastError());
-    GH_HIP(report());
-    unsigned long long t3 = 0;
-    for (int b = 0; b < nb; b++) {
-      const int cb = H->coff[b + 1] - H->coff[b];
-      float mm[6] = {0, 0, 0, 0, 0, 0};
-      if (cb > 0) decode_box(HO->bb + b * 6, mm);
-      H->g3[b] = gh_grid_desc(mm, cb, r_nms * 1.0001f);
-      H->hb[b] = (unsigned)t3;
-      if (cb > 0) t3 += H->g3[b].ncell;
-    }
-    H->hb[nb] = (unsigned)t3;
-    if (t3 >= FB_CELL_BUDGET) return split();
-    GH_TRY(ctx->reserve(B_GRID_START, (size_t)std::max<unsigned long long>(t3, t1) + 2, &head));  // the PCA cell table is dead by now
-    GH_HIP(hipMemsetAsync(head, 0xff, (size_t)t3 * sizeof(int), s));
-    GH_HIP(upload());
     const float r2_nms = (float)((double)r_nms * (double)r_nms);
-    hipEvent_t kn = ctx->kt_begin(KT_NMS_ROUND);
-    hipLaunchKernelGGL(k_fb_nms_greedy, dim3(nb), dim3(NMS_T), 0, s, (const FbBlock*)D, (const float*)cpts, r2_nms, head, next, (const int*)cand,
-                       (const int*)ordg, kpg, O->kcount);
-    ctx->kt_end(KT_NMS_ROUND, kn);
-    GH_HIP(hipGetLastError());
-    GH_HIP(report());
+    for (int seq = 0;; seq++) {
+      hipEvent_t kn = ctx->kt_begin(KT_NMS_ROUND);
+      GH_HIP(hipMemsetAsync(O->nms_und, 0, sizeof(int) * FB_NMS_ROUNDS, s));
+      for (int r = 0; r < FB_NMS_ROUNDS; r++)
+        hipLaunchKernelGGL(k_fb_nmsr_round, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const FbBlock*)D, A, r2_nms, r);
+      ctx->kt_end(KT_NMS_ROUND, kn);
+      GH_HIP(hipGetLastError());
+      GH_HIP(report());
+      if (HO->nms_und[FB_NMS_ROUNDS - 1] == 0) break;  // every candidate has decided
+      if (seq > 4096) return ctx->fail(GHICP_ERR_INTERNAL, "ghicp_clouds_recompute: the NMS rounds do not terminate");  // (each sequence decides at least one candidate)
+    }
     for (int b = 0; b < nb; b++) {
       clouds[b]->k = HO->kcount[b];
       H->koff[b + 1] = H->koff[b] + HO->kcount[b];
     }
     Ktot = H->koff[nb];
+    if (Ktot > 0) {
+      hipEvent_t kk = ctx->kt_begin(KT_NMS_ROUND);
+      hipLaunchKernelGGL(k_fb_nmsr_rank, dim3(nb), dim3(256), 0, s, (const FbBlock*)D, A, kpg);
+      ctx->kt_end(KT_NMS_ROUND, kk);
+    }
   }
 
   // ------------------------------------------------------------------ outputs into the handles, BSC                     (sync 6)

@@ -794,7 +794,11 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     const int slots = per_cu * (confined ? (c == 0 ? confine_b : ctx->num_cu - confine_b) : ctx->num_cu);
     int grid = std::min(plan.count[c], slots);
     if (ctx->loop_slots_cap > 0) grid = std::min(grid, ctx->loop_slots_cap);  // test hook (GHICP_LOOP_SLOTS)
-    batch_slots = confined ? batch_slots + slots : std::max(batch_slots, slots);  // confined: the two classes have their own CUs, the capacities add up
+    // capacity of the batch = the most slots the chip can hold at once: the roomiest class on EVERY CU.  (Round 5 added up the confined
+    // classes' shares, 3 B + 4 (CUs - B); but once the three-per-CU class has drained, its CUs take four slots of the other class, so the
+    // slot lifetimes of a batch could exceed that "capacity" x span: idle_slot_fraction -0.14 in profiles/r05_bench_confine1.json --
+    // round-5 verdict, weak #5.  Against this bound the LDS the three-per-CU slots leave unused counts as idle, which it is.)
+    batch_slots = std::max(batch_slots, per_cu * ctx->num_cu);
     batch_grid += grid;
     hipEvent_t kd = ctx->kt_begin_on(KT_PAIR_LOOP_DISPATCH, sc);  // this dispatch alone, on its own stream (behind the fork event)
     if (prof)
