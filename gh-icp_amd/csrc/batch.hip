@@ -34,7 +34,7 @@ int gh_fpfh_batch_dev(ghicp_ctx* ctx, const float4* dsg, int M, const float4* pt
 namespace {
 
 constexpr int FB_MAX = 64;  // clouds per batch
-constexpr int FB_NMS_ROUNDS = 8;  // NMS rounds per launch sequence (the host looks at the last one's count and launches another sequence if need be)
+constexpr int FB_NMS_ROUNDS = 14;  // NMS rounds per launch sequence (the host looks at the last one's count and launches another sequence if need be)
 
 struct FbCloud {
   const float* xyz;  // raw cloud
@@ -357,59 +357,68 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_fill(NmsrArgs A, unsigned ncell
   A.next[t] = -1;
 }
 
-__global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict__ D, NmsrArgs A, float r2, int round) {
+__global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict__ D, NmsrArgs A, float r2, int round, int first) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= A.ctot) return;
-  if (A.state[t] != 0) return;
-  const float4 P = A.spts[t];
-  const int id = __float_as_int(P.w);
-  const unsigned long long key = A.skey[t];
-  const int b = fb_find(D->coff, D->nb, id);
-  const GridDesc g = D->g3[b];
-  const unsigned* T = A.table + 1 + D->hb[b];
-  int* H = A.head + D->hb[b];
-  const int cx = gh_cell_coord(P.x, g.mn[0], g.inv, g.dim[0]);
-  const int cy = gh_cell_coord(P.y, g.mn[1], g.inv, g.dim[1]);
-  const int cz = gh_cell_coord(P.z, g.mn[2], g.inv, g.dim[2]);
-  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
-  const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
-  // (1) a selected neighbour?  (it outranks this candidate: nothing is selected next to an undecided candidate of higher rank)
-  for (int x = x0; x <= x1; x++)
-    for (int y = y0; y <= y1; y++)
-      for (int z = z0; z <= z1; z++)
-        for (int j = __hip_atomic_load(&H[((unsigned)x * g.dim[1] + y) * g.dim[2] + z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); j >= 0;
-             j = __hip_atomic_load(&A.next[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          const float4 Q = A.spts[j];
+  // 0: decided before / out of range, 1: still undecided after this round.  No early return: the wave counts its undecided lanes with ONE
+  // atomic at the end (call 2 of round 6: one atomicAdd per undecided candidate on a single address cost 2.4 ms in the first round)
+  int waiting = 0;
+  if (t < A.ctot && A.state[t] == 0) {
+    const float4 P = A.spts[t];
+    const int id = __float_as_int(P.w);
+    const unsigned long long key = A.skey[t];
+    const int b = fb_find(D->coff, D->nb, id);
+    const GridDesc g = D->g3[b];
+    const unsigned* T = A.table + 1 + D->hb[b];
+    int* H = A.head + D->hb[b];
+    const int cx = gh_cell_coord(P.x, g.mn[0], g.inv, g.dim[0]);
+    const int cy = gh_cell_coord(P.y, g.mn[1], g.inv, g.dim[1]);
+    const int cz = gh_cell_coord(P.z, g.mn[2], g.inv, g.dim[2]);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
+    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
+    int verdict = 0;  // 0 none yet, 1 wait, 2 suppressed
+    // (1) a selected neighbour?  (it outranks this candidate: nothing is selected next to an undecided candidate of higher rank.)  Plain
+    // loads: a stale list only postpones the decision to the next round, and the very first round has no list to look at
+    if (!first) {
+      for (int x = x0; x <= x1 && verdict == 0; x++)
+        for (int y = y0; y <= y1 && verdict == 0; y++)
+          for (int z = z0; z <= z1 && verdict == 0; z++)
+            for (int j = H[((unsigned)x * g.dim[1] + y) * g.dim[2] + z]; j >= 0; j = A.next[j]) {
+              const float4 Q = A.spts[j];
+              const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
+              float d2 = dx * dx;
+              d2 += dy * dy;
+              d2 += dz * dz;
+              if (d2 < r2) { verdict = 2; break; }
+            }
+    }
+    // (2) a neighbour of higher rank that is not suppressed?  then this candidate waits
+    for (int x = x0; x <= x1 && verdict == 0; x++)
+      for (int y = y0; y <= y1 && verdict == 0; y++) {
+        const unsigned base = ((unsigned)x * g.dim[1] + y) * g.dim[2];
+        const unsigned ub = T[base + z0], ue = T[base + z1 + 1];
+        for (unsigned u = ub; u < ue; u++) {
+          const float4 Q = A.spts[u];
           const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
           float d2 = dx * dx;
           d2 += dy * dy;
           d2 += dz * dz;
-          if (d2 < r2) { A.state[t] = 2; return; }
-        }
-  // (2) a neighbour of higher rank that is not suppressed?  then this candidate waits
-  for (int x = x0; x <= x1; x++)
-    for (int y = y0; y <= y1; y++) {
-      const unsigned base = ((unsigned)x * g.dim[1] + y) * g.dim[2];
-      const unsigned ub = T[base + z0], ue = T[base + z1 + 1];
-      for (unsigned u = ub; u < ue; u++) {
-        const float4 Q = A.spts[u];
-        const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
-        float d2 = dx * dx;
-        d2 += dy * dy;
-        d2 += dz * dz;
-        if (!(d2 < r2) || (int)u == t) continue;
-        const unsigned long long ku = A.skey[u];
-        if (ku > key || (ku == key && __float_as_int(Q.w) < id)) {
-          if (__hip_atomic_load(&A.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2) { atomicAdd(&A.undecided[round], 1); return; }
+          if (!(d2 < r2) || (int)u == t) continue;
+          const unsigned long long ku = A.skey[u];
+          if ((ku > key || (ku == key && __float_as_int(Q.w) < id)) && A.state[u] != 2) { verdict = 1; break; }
         }
       }
+    if (verdict == 2) A.state[t] = 2;
+    else if (verdict == 1) waiting = 1;
+    else {  // (3) every neighbour of higher rank is suppressed: selected
+      A.state[t] = 1;
+      const int cell = ((cx * g.dim[1]) + cy) * g.dim[2] + cz;
+      const int old = atomicExch(&H[cell], t);
+      A.next[t] = old;
+      A.sel[D->coff[b] + atomicAdd(&A.kcount[b], 1)] = t;
     }
-  // (3) every neighbour of higher rank is suppressed: selected
-  __hip_atomic_store(&A.state[t], (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int cell = ((cx * g.dim[1]) + cy) * g.dim[2] + cz;
-  const int old = atomicExch(&H[cell], t);
-  __hip_atomic_store(&A.next[t], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  A.sel[D->coff[b] + atomicAdd(&A.kcount[b], 1)] = t;
+  }
+  const unsigned long long wm = __ballot(waiting != 0);
+  if ((threadIdx.x & 63) == 0 && wm) atomicAdd(&A.undecided[round], (int)__popcll(wm));
 }
 
 // keypoints of cloud b in rank order: position = number of selected candidates of the cloud that outrank this one
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_rank(const FbBlock* __restrict_
   __shared__ int s_id[1024];
   const int b = blockIdx.x;
   const int K = A.kcount[b], c0 = D->coff[b];
-  for (int base = 0; base < K; base += 256) {
+  for (int base = blockIdx.y * 256; base < K; base += 256 * gridDim.y) {  // (the trip count is uniform over the workgroup: barriers below)
     const int k = base + threadIdx.x;
     unsigned long long key = 0;
     int id = 0;
@@ -770,7 +779,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
       hipEvent_t kn = ctx->kt_begin(KT_NMS_ROUND);
       GH_HIP(hipMemsetAsync(O->nms_und, 0, sizeof(int) * FB_NMS_ROUNDS, s));
       for (int r = 0; r < FB_NMS_ROUNDS; r++)
-        hipLaunchKernelGGL(k_fb_nmsr_round, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const FbBlock*)D, A, r2_nms, r);
+        hipLaunchKernelGGL(k_fb_nmsr_round, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const FbBlock*)D, A, r2_nms, r, (seq == 0 && r == 0) ? 1 : 0);
       ctx->kt_end(KT_NMS_ROUND, kn);
       GH_HIP(hipGetLastError());
       GH_HIP(report());
@@ -784,7 +793,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     Ktot = H->koff[nb];
     if (Ktot > 0) {
       hipEvent_t kk = ctx->kt_begin(KT_NMS_ROUND);
-      hipLaunchKernelGGL(k_fb_nmsr_rank, dim3(nb), dim3(256), 0, s, (const FbBlock*)D, A, kpg);
+      hipLaunchKernelGGL(k_fb_nmsr_rank, dim3(nb, 8), dim3(256), 0, s, (const FbBlock*)D, A, kpg);
       ctx->kt_end(KT_NMS_ROUND, kk);
     }
   }
