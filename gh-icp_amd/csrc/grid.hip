@@ -1,6 +1,7 @@
 // Uniform-grid build (cell keys -> stable radix sort -> cell table -> points in cell order) and the
 // voxel down-sampling filter.  rocPRIM/hipCUB is used for the radix sort / select primitives only.
 #include "grid.h"
+#include "prims.h"
 
 #include <algorithm>
 
@@ -193,17 +194,16 @@ int gh_voxel_filter_dev(ghicp_ctx* ctx, const float* xyz, long long n, int strid
   hipLaunchKernelGGL(k_voxel_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, n, stride, v, keys, vals);
   const unsigned long long maxkey = (maxv[0] - 1) * v.mul_x + (maxv[1] - 1) * v.mul_y + (maxv[2] - 1);
   const int eb = bits_for(maxkey);
-  size_t tb = 0, tb2 = 0;
+  size_t tb = 0;
   GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));
-  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));
   char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, (tb > tb2 ? tb : tb2) + 16, &tmp));
+  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
   GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));  // stable: lowest input index leads its voxel
   ctx->kt_end(KT_VOXEL_SORT, kev);
   hipLaunchKernelGGL(k_voxel_flags, dim3(cdiv(n, 256)), dim3(256), 0, s, keys2, n, flags);
   hipLaunchKernelGGL(k_set_first, dim3(1), dim3(1), 0, s, keep);
-  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb2, (int*)vals2, flags, keep + 1, dcount, (int)n, s));
+  GH_TRY(gh_select_flagged_u32(ctx, vals2, flags, n, reinterpret_cast<unsigned*>(keep + 1), dcount));  // the run heads' point indices, in voxel order (prims.hip)
   int* hc = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->pinned) + 320);  // pinned: see gh_bbox_dev
   GH_HIP(hipMemcpyAsync(hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
   GH_HIP(hipStreamSynchronize(s));

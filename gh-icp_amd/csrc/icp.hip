@@ -14,7 +14,6 @@
 #include "grid.h"
 #include "devmath.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdlib>

@@ -56,7 +56,6 @@ constexpr double K4_INF = 1000.0;  // km.cpp:42
 typedef __attribute__((address_space(1))) const int* k4_gint;
 typedef __attribute__((address_space(1))) const double* k4_gf64;
 typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
-typedef __attribute__((address_space(1))) const volatile unsigned* k4_gvu32;
 
 enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_UNCERT, SH_LROW, SH_CH2, SH_NUM = 16 };
 
@@ -314,9 +313,6 @@ __device__ inline bool k4_flood(const K4& s, int qh0, int qt0, double lflood0, i
       const int i = base + lane;
       const bool act = i < qe;
       const int xr = s.stx[min(i, qe - 1)];
-      // (round 6) every lane asks for its row's CSR extent at once: a flagged row's scan below then starts with the entries themselves
-      // instead of a dependent extent load per flagged row (the table is (n + 1) words: cache resident)
-      const unsigned cb_pf = reinterpret_cast<k4_gvu32>(s.rptr)[xr], ce_pf = reinterpret_cast<k4_gvu32>(s.rptr)[xr + 1];
       const double lxr = s.lx[xr];
       const int tn = s.tln[xr];
       int lc[K4_CAP], mc[K4_CAP];
@@ -339,7 +335,7 @@ __device__ inline bool k4_flood(const K4& s, int qh0, int qt0, double lflood0, i
         ob &= ob - 1ull;
         const int xo = __builtin_amdgcn_readlane(xr, l);
         const double lxo = s.lx[xo];
-        const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)cb_pf, l), ce = (unsigned)__builtin_amdgcn_readlane((int)ce_pf, l);
+        const unsigned cb = s.rptr[xo], ce = s.rptr[xo + 1];
         for (unsigned c0 = cb; c0 < ce; c0 += 64) {
           const unsigned c = c0 + lane, cc = min(c, ce - 1u);
           const int col = s.cols[cc];
@@ -406,11 +402,11 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
     const long long t_it0 = PROF ? (long long)__builtin_readcyclecounter() : 0;
     int it_type = 0;  // PROF: 0 flagged row, 1 listed-only row, 2 background-tight row with a list, 3 march, 4 ended in a pop
     // ---- round trip 1: the row record
-    // (round 6) the extent of the row's CSR entries is asked for NOW, whatever kind of row this is: a flagged row scans its CSR row, and its
-    // two dependent global round trips -- extent, then entries -- were 1.8-3.3 k cycles per flagged-row step against ~1.0 k for a listed
-    // row (profiles/r05_km4_stages.txt); here the first one hides behind the LDS round trips every step makes anyway.  Volatile: the
-    // compiler otherwise sinks the load back into the branch that uses it (it did so with the owner of the best listed column).
-    const unsigned cb_pf = reinterpret_cast<k4_gvu32>(s.rptr)[x], ce_pf = reinterpret_cast<k4_gvu32>(s.rptr)[x + 1];
+    // (round 6, measured and dropped: asking for the row's CSR extent HERE, for every kind of row, so that a flagged row's two dependent
+    // global round trips -- extent, then entries: 1.8-3.3 k cycles per flagged-row step -- become one.  The load has to be volatile or the
+    // compiler sinks it back into the flagged branch, and a volatile load is waited for at the loop's back edge: every step then pays a
+    // global latency.  47.7 / 72.0 / 38.0 / 342.4 / 57.6 -> 51.6 / 75.0 / 43.0 / 346.7 / 65.7 ms on the five real matrices, mean solve of
+    // the bench 44.3 -> 48.3 ms: profiles/r06_km_variants_call3.txt)
     const double lxv = s.lx[x];
     const int tn = s.tln[x];
     const int lc = s.tlc[x * K4_CAP + lk];
@@ -439,7 +435,7 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
     int mW = s.match[ywc];
     int best = INT_MAX, mbest = K4_NONE;
     if (k4_flagged(tn)) {  // flagged row: lowest tight unvisited good column of the CSR row
-      const unsigned cb = cb_pf, ce = ce_pf;
+      const unsigned cb = s.rptr[x], ce = s.rptr[x + 1];
       for (unsigned c0 = cb; c0 < ce; c0 += 64) {
         const unsigned c = c0 + lane, cc = min(c, ce - 1u);
         const int col = s.cols[cc];

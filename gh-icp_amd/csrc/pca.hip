@@ -13,7 +13,7 @@
 #include "devmath.h"
 #include "pca_dev.h"
 
-#include <hipcub/hipcub.hpp>
+#include "prims.h"
 
 namespace {
 
@@ -68,11 +68,7 @@ int gh_pca_dev(ghicp_ctx* ctx, const float* xyz, long long m, int stride, float 
   int* misc;
   GH_TRY(ctx->reserve(B_FE_SORTK, (size_t)m + 1, &cells));
   GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
-  size_t tb = 0;
-  GH_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, G.keys, cells, misc, (int)m, s));
-  char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
-  GH_HIP(hipcub::DeviceSelect::Unique(tmp, tb, G.keys, cells, misc, (int)m, s));
+  GH_TRY(gh_unique_sorted_u32(ctx, G.keys, m, cells, misc));  // prims.hip
   GH_HIP(hipMemsetAsync(misc + 4, 0, 8 * sizeof(int), s));
   GridArgs A = {G.d, G.pts, G.start};
   const float r2 = (float)((double)radius * (double)radius);  // pcl radiusSearch: static_cast<float>(radius*radius)
@@ -96,12 +92,7 @@ int gh_prune_dev(ghicp_ctx* ctx, const float* lambda, const int32_t* count, long
   GH_TRY(ctx->reserve(B_FE_FLAGS, (size_t)m + 16, &flags));
   GH_TRY(ctx->reserve(B_FE_SCAN, 16, &dcount));
   hipLaunchKernelGGL(k_prune_flags, dim3(cdiv(m, 256)), dim3(256), 0, s, lambda, count, m, ratio_max, min_n, flags);
-  hipcub::CountingInputIterator<int> iota(0);
-  size_t tb = 0;
-  GH_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, iota, flags, cand, dcount, (int)m, s));
-  char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
-  GH_HIP(hipcub::DeviceSelect::Flagged(tmp, tb, iota, flags, cand, dcount, (int)m, s));
+  GH_TRY(gh_select_flagged_iota(ctx, flags, m, cand, dcount));  // prims.hip
   int* hc = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->pinned) + 320);  // pinned: see gh_bbox_dev
   GH_HIP(hipMemcpyAsync(hc, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
   GH_HIP(hipStreamSynchronize(s));

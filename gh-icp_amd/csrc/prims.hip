@@ -117,7 +117,8 @@ __global__ __launch_bounds__(PT) void k_scan_apply(unsigned* __restrict__ data, 
 // ---- (3b) select: out[rank] = i for every flagged (MODE 1) / run-head (MODE 2) position i, ascending; MODE 2 writes the KEY instead
 // (unique).  Items are taken wave-contiguously (a wave instruction covers 64 consecutive items), ranks from ballots.
 template <int MODE>
-__global__ __launch_bounds__(PT) void k_select_apply(const void* __restrict__ in, long long n, const unsigned* __restrict__ totals, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(PT) void k_select_apply(const void* __restrict__ in, long long n, const unsigned* __restrict__ totals, unsigned* __restrict__ out,
+                                                     const unsigned* __restrict__ vals) {
   __shared__ unsigned sh_w[4][PI];  // per wave and round: hits of that wave in that round
   __shared__ unsigned sh_base[4][PI];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(PT) void k_select_apply(const void* __restrict__ in
     if ((hit[k] >> lane) & 1ull) {
       const long long i = t0 + (long long)(k * 4 + wave) * 64 + lane;
       const unsigned pos = sh_base[wave][k] + (unsigned)__popcll(hit[k] & ((1ull << lane) - 1ull));
-      out[pos] = MODE == 1 ? (unsigned)i : reinterpret_cast<const unsigned*>(in)[i];
+      out[pos] = MODE == 1 ? (vals ? vals[i] : (unsigned)i) : reinterpret_cast<const unsigned*>(in)[i];
     }
   }
 }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(PT) void k_select_apply(const void* __restrict__ in
 int tiles_of(long long n) { return (int)((n + TILE - 1) / TILE); }
 
 template <int MODE>
-int select_impl(ghicp_ctx* ctx, const void* in, long long n, unsigned* out, int* d_count) {
+int select_impl(ghicp_ctx* ctx, const void* in, long long n, unsigned* out, int* d_count, const unsigned* vals = nullptr) {
   hipStream_t s = ctx->stream;
   if (n <= 0) {
     if (d_count) GH_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
@@ -169,7 +170,7 @@ int select_impl(ghicp_ctx* ctx, const void* in, long long n, unsigned* out, int*
   GH_TRY(ctx->reserve(B_PRIM_TMP, (size_t)nt + 2, &totals));
   hipLaunchKernelGGL((k_tile_totals<MODE>), dim3(nt), dim3(PT), 0, s, in, n, totals);
   hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(PT), 0, s, totals, nt, d_count);
-  hipLaunchKernelGGL((k_select_apply<MODE>), dim3(nt), dim3(PT), 0, s, in, n, (const unsigned*)totals, out);
+  hipLaunchKernelGGL((k_select_apply<MODE>), dim3(nt), dim3(PT), 0, s, in, n, (const unsigned*)totals, out, vals);
   GH_HIP(hipGetLastError());
   return GHICP_OK;
 }
@@ -191,6 +192,10 @@ int gh_scan_inclusive_u32(ghicp_ctx* ctx, unsigned* data, long long n) {
 
 int gh_select_flagged_iota(ghicp_ctx* ctx, const unsigned char* flags, long long n, int* out_idx, int* d_count) {
   return select_impl<1>(ctx, flags, n, reinterpret_cast<unsigned*>(out_idx), d_count);
+}
+
+int gh_select_flagged_u32(ghicp_ctx* ctx, const unsigned* vals, const unsigned char* flags, long long n, unsigned* out, int* d_count) {
+  return select_impl<1>(ctx, flags, n, out, d_count, vals);
 }
 
 int gh_unique_sorted_u32(ghicp_ctx* ctx, const unsigned* keys, long long n, unsigned* out, int* d_count) {
