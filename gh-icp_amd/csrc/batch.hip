@@ -389,21 +389,29 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict
     const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
     int* H = A.head + D->hb[b];
     int verdict = 0;  // 0 go on, 1 wait, 2 suppressed
-    if (!first) {     // (1); plain loads: a stale list only postpones the decision by a round
-      for (int r = 0; r < 9 && verdict == 0; r++) {
+    if (!first) {     // (1); plain loads: a stale list only postpones the decision by a round.  All 27 list heads are asked for at once
+      int hd[27];     // (independent loads: one round trip to L2 instead of 27 dependent ones -- the round is bound by load latency)
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
         const int x = cx - 1 + r / 3, y = cy - 1 + r % 3;
-        if (x < 0 || x >= g.dim[0] || y < 0 || y >= g.dim[1]) continue;
-        const unsigned base = ((unsigned)x * g.dim[1] + y) * g.dim[2];
-        for (int z = z0; z <= z1 && verdict == 0; z++)
-          for (int j = H[base + z]; j >= 0; j = A.next[j]) {
-            const float4 Q = A.spts[j];
-            const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
-            float d2 = dx * dx;
-            d2 += dy * dy;
-            d2 += dz * dz;
-            if (d2 < r2) { verdict = 2; break; }
-          }
+        const bool in = x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1];
+        const unsigned base = in ? ((unsigned)x * g.dim[1] + y) * g.dim[2] : 0u;
+#pragma unroll
+        for (int dz = 0; dz < 3; dz++) {
+          const int z = cz - 1 + dz;
+          hd[r * 3 + dz] = (in && z >= 0 && z < g.dim[2]) ? H[base + z] : -1;
+        }
       }
+#pragma unroll
+      for (int q = 0; q < 27; q++)
+        for (int j = hd[q]; j >= 0 && verdict == 0; j = A.next[j]) {
+          const float4 Q = A.spts[j];
+          const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
+          float d2 = dx * dx;
+          d2 += dy * dy;
+          d2 += dz * dz;
+          if (d2 < r2) verdict = 2;
+        }
     }
     if (verdict == 0) {  // (2)
       const int bl = A.blk[t];
@@ -415,28 +423,48 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict
     if (verdict == 0) {
       const unsigned long long key = A.skey[t];
       const unsigned* T = A.table + 1 + D->hb[b];
-      int r = A.urun[t];
-      unsigned u_from = A.upos[t];
-      for (; r < 9 && verdict == 0; r++, u_from = 0u) {
-        const int x = cx - 1 + r / 3, y = cy - 1 + r % 3;
-        if (x < 0 || x >= g.dim[0] || y < 0 || y >= g.dim[1]) continue;
-        const unsigned base = ((unsigned)x * g.dim[1] + y) * g.dim[2];
-        const unsigned ub = T[base + z0], ue = T[base + z1 + 1];
-        for (unsigned u = max(ub, u_from); u < ue; u++) {
-          const float4 Q = A.spts[u];
-          const float dx = Q.x - P.x, dy = Q.y - P.y, dz = Q.z - P.z;
-          float d2 = dx * dx;
-          d2 += dy * dy;
-          d2 += dz * dz;
-          if (!(d2 < r2) || (int)u == t) continue;
-          const unsigned long long ku = A.skey[u];
-          if (!(ku > key || (ku == key && __float_as_int(Q.w) < id))) continue;
-          const int su = A.state[u];
-          if (su == 2) continue;
-          if (su == 1) { verdict = 2; break; }
-          A.blk[t] = (int)u; A.urun[t] = (unsigned char)r; A.upos[t] = u + 1u;
-          verdict = 1;
-          break;
+      unsigned rb[9], re[9];  // the nine runs' bounds, asked for at once
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        const int x = cx - 1 + q / 3, y = cy - 1 + q % 3;
+        const bool in = x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1];
+        const unsigned base = in ? ((unsigned)x * g.dim[1] + y) * g.dim[2] : 0u;
+        rb[q] = in ? T[base + z0] : 0u;
+        re[q] = in ? T[base + z1 + 1] : 0u;
+      }
+      const int r_from = A.urun[t];
+      const unsigned u_res = A.upos[t];
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        if (verdict != 0 || r < r_from) continue;
+        const unsigned u_from = r == r_from ? u_res : 0u;
+        const unsigned ub = rb[r], ue = re[r];
+        // four entries per step, everything a verdict may need asked for at once (position, rank key, state: independent loads); they
+        // are LOOKED AT in slot order, so the walk stops exactly where the one-entry-at-a-time walk would
+        for (unsigned u0 = max(ub, u_from); u0 < ue && verdict == 0; u0 += 4u) {
+          float4 Q[4];
+          unsigned long long K[4];
+          int S[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const unsigned u = min(u0 + (unsigned)e, ue - 1u);
+            Q[e] = A.spts[u]; K[e] = A.skey[u]; S[e] = A.state[u];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const unsigned u = u0 + (unsigned)e;
+            if (verdict != 0 || u >= ue) continue;
+            const float dx = Q[e].x - P.x, dy = Q[e].y - P.y, dz = Q[e].z - P.z;
+            float d2 = dx * dx;
+            d2 += dy * dy;
+            d2 += dz * dz;
+            if (!(d2 < r2) || (int)u == t) continue;
+            if (!(K[e] > key || (K[e] == key && __float_as_int(Q[e].w) < id))) continue;
+            if (S[e] == 2) continue;
+            if (S[e] == 1) { verdict = 2; continue; }
+            A.blk[t] = (int)u; A.urun[t] = (unsigned char)r; A.upos[t] = u + 1u;
+            verdict = 1;
+          }
         }
       }
       if (verdict == 0) {  // (3)
