@@ -318,8 +318,10 @@ struct NmsrArgs {
   unsigned* table;            // [0] = 0, [1 + cell]: histogram -> end -> start of the cell's run (see k_fb_nmsr_fill)
   unsigned* ccell;            // candidate -> global cell
   unsigned long long* ckey;   // candidate -> rank key (order-preserving image of the curvature)
-  float4* spts;               // slot -> (x, y, z, candidate id)
+  float4* spts;               // slot -> (x, y, z, candidate id); inside a cell the slots are in RANK order (k_fb_nmsr_sort)
   unsigned long long* skey;   // slot -> rank key
+  float4* spts0;              // the same two arrays as the scatter left them (cell by cell, arbitrary order inside a cell)
+  unsigned long long* skey0;
   unsigned char* state;       // slot -> 0 undecided, 1 selected, 2 suppressed
   int* head;                  // cell -> most recently selected slot, -1: none
   int* next;                  // slot -> next selected slot of its cell
@@ -355,13 +357,36 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_fill(NmsrArgs A, unsigned ncell
   if (i >= A.ctot) return;
   const unsigned t = atomicSub(&A.table[1 + A.ccell[i]], 1u) - 1u;
   const float4 P = A.dsg[A.cand[i]];
-  A.spts[t] = make_float4(P.x, P.y, P.z, __int_as_float(i));
-  A.skey[t] = A.ckey[i];
-  A.state[t] = 0;
-  A.blk[t] = -1;
-  A.next[t] = -1;
-  A.urun[t] = 0;
-  A.upos[t] = 0u;
+  A.spts0[t] = make_float4(P.x, P.y, P.z, __int_as_float(i));
+  A.skey0[t] = A.ckey[i];
+}
+
+// Inside a cell the candidates go in RANK order (highest first): every candidate counts the members of its cell that outrank it -- cells
+// hold ~10 candidates, a few hundred at most -- and takes that position.  A walk over a cell can then stop at the first entry of lower
+// rank, so a candidate near the top of its neighbourhood (the ones that stay undecided longest, and the ones that end up selected)
+// looks at a handful of entries per cell instead of all of them (call 6 of round 6: rounds 2-9 were 100-220 us each, held up by the
+// few candidates per wave that had to walk their whole neighbourhood, ~200 entries, to find nobody left above them).
+__global__ __launch_bounds__(256) void k_fb_nmsr_sort(NmsrArgs A) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= A.ctot) return;
+  const float4 P = A.spts0[t];
+  const int id = __float_as_int(P.w);
+  const unsigned long long key = A.skey0[t];
+  const unsigned c = A.ccell[id];
+  const unsigned ub = A.table[1 + c], ue = A.table[2 + c];
+  unsigned rank = 0;
+  for (unsigned u = ub; u < ue; u++) {
+    const unsigned long long ku = A.skey0[u];
+    rank += (ku > key || (ku == key && __float_as_int(A.spts0[u].w) < id)) ? 1u : 0u;
+  }
+  const unsigned d = ub + rank;
+  A.spts[d] = P;
+  A.skey[d] = key;
+  A.state[d] = 0;
+  A.blk[d] = -1;
+  A.next[d] = -1;
+  A.urun[d] = 0;
+  A.upos[d] = 0u;
 }
 
 // One round, for every candidate that has not decided yet:
@@ -423,25 +448,31 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict
     if (verdict == 0) {
       const unsigned long long key = A.skey[t];
       const unsigned* T = A.table + 1 + D->hb[b];
-      unsigned rb[9], re[9];  // the nine runs' bounds, asked for at once
+      unsigned tb[9][4];  // the cell table around the candidate: nine columns x (three cells + 1), asked for at once
 #pragma unroll
       for (int q = 0; q < 9; q++) {
         const int x = cx - 1 + q / 3, y = cy - 1 + q % 3;
         const bool in = x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1];
         const unsigned base = in ? ((unsigned)x * g.dim[1] + y) * g.dim[2] : 0u;
-        rb[q] = in ? T[base + z0] : 0u;
-        re[q] = in ? T[base + z1 + 1] : 0u;
+#pragma unroll
+        for (int dz = 0; dz < 4; dz++) {
+          const int z = cz - 1 + dz;
+          tb[q][dz] = (in && z >= 0 && z <= g.dim[2]) ? T[base + z] : 0u;
+        }
       }
-      const int r_from = A.urun[t];
+      const int c_from = A.urun[t];  // cell 0..26 the walk stands in
       const unsigned u_res = A.upos[t];
 #pragma unroll
-      for (int r = 0; r < 9; r++) {
-        if (verdict != 0 || r < r_from) continue;
-        const unsigned u_from = r == r_from ? u_res : 0u;
-        const unsigned ub = rb[r], ue = re[r];
+      for (int c = 0; c < 27; c++) {
+        if (verdict != 0 || c < c_from) continue;
+        const int q = c / 3, dz = c % 3;
+        const int z = cz - 1 + dz;
+        if (z < 0 || z >= g.dim[2]) continue;
+        const unsigned ub = tb[q][dz], ue = tb[q][dz + 1];
         // four entries per step, everything a verdict may need asked for at once (position, rank key, state: independent loads); they
-        // are LOOKED AT in slot order, so the walk stops exactly where the one-entry-at-a-time walk would
-        for (unsigned u0 = max(ub, u_from); u0 < ue && verdict == 0; u0 += 4u) {
+        // are LOOKED AT in slot order = rank order, and the cell is left at the first entry that does not outrank this candidate
+        bool below = false;
+        for (unsigned u0 = max(ub, c == c_from ? u_res : 0u); u0 < ue && verdict == 0 && !below; u0 += 4u) {
           float4 Q[4];
           unsigned long long K[4];
           int S[4];
@@ -453,16 +484,16 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const unsigned u = u0 + (unsigned)e;
-            if (verdict != 0 || u >= ue) continue;
-            const float dx = Q[e].x - P.x, dy = Q[e].y - P.y, dz = Q[e].z - P.z;
+            if (verdict != 0 || below || u >= ue) continue;
+            if (!(K[e] > key || (K[e] == key && __float_as_int(Q[e].w) < id))) { below = true; continue; }  // this entry and the rest of the cell rank lower (or it is the candidate itself)
+            const float dx = Q[e].x - P.x, dy = Q[e].y - P.y, dz2 = Q[e].z - P.z;
             float d2 = dx * dx;
             d2 += dy * dy;
-            d2 += dz * dz;
-            if (!(d2 < r2) || (int)u == t) continue;
-            if (!(K[e] > key || (K[e] == key && __float_as_int(Q[e].w) < id))) continue;
+            d2 += dz2 * dz2;
+            if (!(d2 < r2)) continue;
             if (S[e] == 2) continue;
             if (S[e] == 1) { verdict = 2; continue; }
-            A.blk[t] = (int)u; A.urun[t] = (unsigned char)r; A.upos[t] = u + 1u;
+            A.blk[t] = (int)u; A.urun[t] = (unsigned char)c; A.upos[t] = u + 1u;
             verdict = 1;
           }
         }
@@ -819,6 +850,8 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     GH_TRY(ctx->reserve(B_NMSR_KEY, (size_t)Ctot + 1, &A.ckey));
     GH_TRY(ctx->reserve(B_NMSR_PTS, (size_t)Ctot + 1, &A.spts));
     GH_TRY(ctx->reserve(B_NMSR_SKEY, (size_t)Ctot + 1, &A.skey));
+    GH_TRY(ctx->reserve(B_NMSR_PTS0, (size_t)Ctot + 1, &A.spts0));
+    GH_TRY(ctx->reserve(B_NMSR_SKEY0, (size_t)Ctot + 1, &A.skey0));
     GH_TRY(ctx->reserve(B_NMSR_STATE, (size_t)Ctot * 2 + 32, &A.state));
     A.urun = A.state + (((size_t)Ctot + 15) & ~(size_t)15);
     GH_TRY(ctx->reserve(B_NMSR_NEXT, (size_t)Ctot * 2 + 2, &A.blk));
@@ -836,6 +869,7 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
     hipLaunchKernelGGL(k_fb_nmsr_keys, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, (const FbBlock*)D, A);
     GH_TRY(gh_scan_inclusive_u32(ctx, A.table + 1, (long long)t3));
     hipLaunchKernelGGL(k_fb_nmsr_fill, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, A, (unsigned)t3);
+    hipLaunchKernelGGL(k_fb_nmsr_sort, dim3(cdiv(Ctot, 256)), dim3(256), 0, s, A);
     ctx->kt_end(KT_FB_RANK, kr);
     const float r2_nms = (float)((double)r_nms * (double)r_nms);
     for (int seq = 0;; seq++) {

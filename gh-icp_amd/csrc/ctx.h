@@ -74,7 +74,7 @@ enum BufSlot {
   // batched front end (batch.hip)
   B_FB_DESC, B_FB_HEADPOS, B_FB_DS, B_FB_ORD,
   // hand-written scan / select primitives (prims.hip): tile totals; round-based NMS of the batched front end (batch.hip)
-  B_PRIM_TMP, B_NMSR_KEY, B_NMSR_CELL, B_NMSR_TABLE, B_NMSR_HEAD, B_NMSR_PTS, B_NMSR_SKEY, B_NMSR_STATE, B_NMSR_NEXT, B_NMSR_SEL, B_NMSR_MISC, B_NMSR_LIST,
+  B_PRIM_TMP, B_NMSR_KEY, B_NMSR_CELL, B_NMSR_TABLE, B_NMSR_HEAD, B_NMSR_PTS, B_NMSR_SKEY, B_NMSR_STATE, B_NMSR_NEXT, B_NMSR_SEL, B_NMSR_MISC, B_NMSR_LIST, B_NMSR_PTS0, B_NMSR_SKEY0,
   // fine registration (icp.hip): coarse target grid, source grids (reciprocal), per-point state
   B_ICP_TC_KEYS, B_ICP_TC_KEYS2, B_ICP_TC_VALS, B_ICP_TC_VALS2, B_ICP_TC_START, B_ICP_TC_PTS,
   B_ICP_SC_KEYS, B_ICP_SC_KEYS2, B_ICP_SC_VALS, B_ICP_SC_VALS2, B_ICP_SC_START, B_ICP_SC_PTS,
