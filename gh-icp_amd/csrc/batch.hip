@@ -411,7 +411,6 @@ __global__ __launch_bounds__(256) void k_fb_nmsr_round(const FbBlock* __restrict
     const int cx = gh_cell_coord(P.x, g.mn[0], g.inv, g.dim[0]);
     const int cy = gh_cell_coord(P.y, g.mn[1], g.inv, g.dim[1]);
     const int cz = gh_cell_coord(P.z, g.mn[2], g.inv, g.dim[2]);
-    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
     int* H = A.head + D->hb[b];
     int verdict = 0;  // 0 go on, 1 wait, 2 suppressed
     if (!first) {     // (1); plain loads: a stale list only postpones the decision by a round.  All 27 list heads are asked for at once

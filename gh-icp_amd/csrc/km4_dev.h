@@ -57,7 +57,7 @@ typedef __attribute__((address_space(1))) const int* k4_gint;
 typedef __attribute__((address_space(1))) const double* k4_gf64;
 typedef __attribute__((address_space(1))) const unsigned* k4_gu32;
 
-enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_UNCERT, SH_LROW, SH_CH2, SH_NUM = 16 };
+enum { SH_QT = 0, SH_FREE, SH_RES, SH_QTF, SH_HAZ, SH_CH0, SH_CH1, SH_BAD, SH_NF, SH_UNCERT, SH_LROW, SH_CH2, SH_DFS, SH_NUM = 16 };
 
 struct K4 {
   double *lx, *ly, *slack, *red;
@@ -210,15 +210,17 @@ __device__ inline void k4_revalidate(const K4& s, int tid) {
 // the pops that followed, profiles/r03_km_dfs_kinds.txt).  Pooling EVERY flagged row cost more in the S rounds than it saved in the DFS
 // (profiles/r03_km4_second_half.txt, v1); with the hints only the few rows beyond six entries come here.
 // The S rounds cannot afford a CSR scan per flagged row per round, so the rows' tight columns are gathered ONCE per augmenting
-// phase into a pool: the flood's queue stx is dead by then and the DFS has not started, so stx is the pool (region r = `region`
-// u16 per flagged row: count, then the columns, ascending) and sty holds the list of flagged rows.  A row with more tight entries than
+// phase into a pool (region r = `region` u16 per flagged row: count, then the columns, ascending) next to the list of flagged rows.  Both live
+// in the SLACK array's storage, which is dead from the start of an augmenting phase to the next root (8 n bytes: the row -> column map of
+// the matching, the flagged rows, the pool: n + n + 2 n u16).  Until round 6 they lived in the flood's queue and the DFS's column stack
+// (stx / sty), which the lazy S of rule R5' needs intact: S is now computed in the MIDDLE of the search.  A row with more tight entries than
 // its region holds joins S unconditionally, as before (any superset of good is valid, R5).  16 lanes per row, as in k4_bulk.
-__device__ inline void k4_pool_build(const K4& s, int nf, int region, int wave, int lane) {
+__device__ inline void k4_pool_build(const K4& s, const unsigned short* __restrict__ flist, unsigned short* __restrict__ pool, int nf, int region, int wave, int lane) {
   const int grp = lane >> 4, lig = lane & 15, capf = region - 1;
   for (int base = 0; base < nf; base += 16) {
     const int i = base + wave * 4 + grp;
     int x = -1;
-    if (i < nf) x = s.sty[i];
+    if (i < nf) x = flist[i];
     unsigned cb = 0, ce = 0;
     double lxr = 0.0;
     if (x >= 0) { cb = s.rptr[x]; ce = s.rptr[x + 1]; lxr = s.lx[x]; }
@@ -242,14 +244,14 @@ __device__ inline void k4_pool_build(const K4& s, int nf, int region, int wave, 
         const unsigned gb = (unsigned)(__ballot(td) >> (grp * 16)) & 0xffffu;
         if (td) {
           const int rk = cnt + __popc(gb & ((1u << lig) - 1u));
-          if (rk < capf) s.stx[i * region + 1 + rk] = (unsigned short)col[j];
+          if (rk < capf) pool[i * region + 1 + rk] = (unsigned short)col[j];
         }
         cnt += __popc(gb);
       }
     }
     if (lig == 0 && x >= 0) {
       if (cnt > capf) { atomicOr(&s.good[x >> 5], 1u << (x & 31)); cnt = 0; }
-      s.stx[i * region] = (unsigned short)cnt;
+      pool[i * region] = (unsigned short)cnt;
     }
   }
 }
@@ -387,15 +389,21 @@ __device__ inline bool k4_flood(const K4& s, int qh0, int qt0, double lflood0, i
 // One iteration == one findpath() activation or resumption (km.cpp:13-37) and costs two dependent LDS round trips: (1) the
 // row record (label, listed columns), (2) everything the verdict needs -- the visited / S words and the owner of the <= 3 listed
 // columns, and for a 64-column window of background candidates at the E7 pointer of the row's label: ly, visited / S words, owner.
+// The search's registers, kept by the caller across the S computation of rule R5' (lazy S).
+struct K4Dfs {
+  int sp, x, ystart, cp, cnext;
+  double ck;  // E7 cache, one label per lane
+};
+// Returns 1: augmented; 0: internal error; 2 (only with lazy): the search is about to take its first step back -- D holds its state, the
+// stacks stx / sty its frames; the caller computes S, cuts the stack back to its deepest good frame (k4_dfs_unwind) and calls again with
+// lazy = false.  A fresh search: D.sp = 0, D.x = root, D.ystart = 0, D.ck = NaN (never matches), D.cp = D.cnext = 0, stx[0] = root.
 template <bool PROF>
-__device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter, long long* q_act, long long* pd) {
+__device__ inline int k4_dfs(const K4& s, K4Dfs& D, const bool lazy, int lane, long long* q_iter, long long* q_act, long long* pd) {
   const int n = s.n;
   const double bg = s.bg, eps = s.eps;
-  if (lane == 0) { s.stx[0] = (unsigned short)root; s.sty[0] = (unsigned short)K4_NONE; }
-  __builtin_amdgcn_wave_barrier();
-  int sp = 0, x = root, ystart = 0;
-  double ck = __longlong_as_double(0x7ff8000000000000ll);  // E7 cache, one label per lane: NaN never matches
-  int cp = 0, cnext = 0;
+  int sp = D.sp, x = D.x, ystart = D.ystart;
+  double ck = D.ck;
+  int cp = D.cp, cnext = D.cnext;
   const int lk = min(lane, K4_CAP - 1);
   for (;;) {
     if (PROF) { ++*q_iter; ++*q_act; }
@@ -528,8 +536,13 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
       if (lane == 0) { s.stx[sp] = (unsigned short)mbest; s.sty[sp] = (unsigned short)K4_NONE; }
       x = mbest; ystart = 0;
     } else {
+      if (lazy) {  // R5': the first step back -- S is due.  The row x (frame sp) has no candidate left under "every column passes"
+        D.sp = sp; D.x = x; D.ystart = ystart; D.ck = ck; D.cp = cp; D.cnext = cnext;
+        __builtin_amdgcn_wave_barrier();
+        return 2;
+      }
       sp--;
-      if (sp < 0) return false;
+      if (sp < 0) return 0;
       x = s.stx[sp]; ystart = (int)s.sty[sp] + 1;
       if (PROF) { pd[4]++; pd[9] += (long long)__builtin_readcyclecounter() - t_it0; }
     }
@@ -540,6 +553,28 @@ __device__ inline bool k4_dfs(const K4& s, int root, int lane, long long* q_iter
   const int ylast = s.sty[sp];
   for (int f = lane; f <= sp; f += 64) s.match[s.sty[f]] = s.stx[f];
   if (lane == 0) atomicAnd(&s.freey[ylast >> 5], ~(1u << (ylast & 31)));
+  return 1;
+}
+
+// R5', after S has been computed: the stack back to its deepest frame whose row is in S.  Every frame above a row that is not good holds
+// a row that is not good either (a row that reaches a good row is good), and S is a superset of good whose complement holds no good row:
+// frames are cut from the first row outside S on.  The search then goes on after the column that frame was waiting on; if every frame's
+// row is in S the same row is looked at again, now under S.  Returns false when the root itself is outside S (impossible: the flood
+// reached a free column from it).
+__device__ inline bool k4_dfs_unwind(const K4& s, K4Dfs& D, int lane) {
+  int keep = D.sp + 1;
+  for (int base = 0; base <= D.sp; base += 64) {
+    const int f = base + lane;
+    const bool out = f <= D.sp && !k4_bit(s.good, s.stx[min(f, D.sp)]);
+    const unsigned long long b = __ballot(out);
+    if (b) { keep = base + (int)__ffsll((long long)b) - 1; break; }
+  }
+  if (keep == 0) return false;
+  if (keep <= D.sp) {
+    D.sp = keep - 1;
+    D.x = s.stx[D.sp];
+    D.ystart = (int)s.sty[D.sp] + 1;
+  }
   return true;
 }
 
@@ -781,26 +816,42 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         if (phase > 4 * n + 16) { bad = 2; break; }  // only reachable with non-finite weights
         continue;
       }
-      // ---- R5: augmenting phase.  S by pull rounds ...
-      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.good[w] = 0u; s.goody[w] = s.freey[w]; }
+      // ---- R5 / R5': augmenting phase.  The search starts WITHOUT S (every column passes); S is computed when it first steps back.
+      for (int w = tid; w < nw; w += K4_T) { s.visx[w] = 0u; s.visy[w] = 0u; s.goody[w] = ~0u; }
+      __syncthreads();
+      K4Dfs dfs;
+      dfs.sp = 0; dfs.x = root; dfs.ystart = 0; dfs.cp = 0; dfs.cnext = 0;
+      dfs.ck = __longlong_as_double(0x7ff8000000000000ll);  // NaN never matches
+      if (wave == sw) {
+        if (lane == 0) { s.stx[0] = (unsigned short)root; s.sty[0] = (unsigned short)K4_NONE; }
+        __builtin_amdgcn_wave_barrier();
+        const int r = k4_dfs<PROF>(s, dfs, true, lane, &q_iter, &q_act, pd);
+        if (lane == 0) s.sh[SH_DFS] = r;
+      }
+      __syncthreads();
+      const long long t1b = PROF ? (long long)__builtin_readcyclecounter() : 0;
+      if (PROF) c_dfs += t1b - t1;
+      long long t2 = t1b;
+      if (s.sh[SH_DFS] == 2) {
+      // ---- S by pull rounds (the search's stacks stx / sty stay as they are: everything S needs lives in the slack array's storage)
+      for (int w = tid; w < nw; w += K4_T) { s.good[w] = 0u; s.goody[w] = s.freey[w]; }
       if (tid == 0) { s.sh[SH_CH0] = 0; s.sh[SH_CH1] = 0; s.sh[SH_CH2] = 0; s.sh[SH_NF] = 0; }
-      if (wave == 0) {  // the flagged rows without hints, ascending, into sty (without the pool they would all be members of S: measured, v4)
+      // row -> column map of the matching, the list of flagged rows without hints and the pool of their tight columns: an augmenting phase
+      // is the LAST phase of its root and the next root starts by resetting slack, so its 8 n bytes are dead from here to the end of the phase
+      unsigned short* mx = reinterpret_cast<unsigned short*>(s.slack);
+      unsigned short* flist = mx + n;
+      unsigned short* pool = mx + 2 * (size_t)n;
+      if (wave == 0) {  // the flagged rows without hints, ascending (without the pool they would all be members of S: measured, v4)
         int cnt = 0;
         for (int base = 0; base < n; base += 64) {
           const int x = base + lane;
           const bool f = x < n && k4_bit(s.ovf, x);
           const unsigned long long b = __ballot(f);
-          if (f) s.sty[cnt + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)x;
+          if (f) flist[cnt + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)x;
           cnt += __popcll(b);
         }
         if (lane == 0) s.sh[SH_NF] = cnt;
       }
-      __syncthreads();
-      // (branch next/km-s-rounds-fused) row -> column map of the matching, in the slack array's storage: an augmenting phase is the LAST phase of
-      // its root and the next root starts by resetting slack, so the 8 n bytes are dead from here to the end of the phase.  With it a row
-      // that joins S takes its own column along in the same pass: no column pass, one barrier per round, and rows later in the pass can
-      // already see the column (the fixed point is the same: the least one of a monotone rule, whatever the order).
-      unsigned short* mx = reinterpret_cast<unsigned short*>(s.slack);
       for (int i = tid; i < n; i += K4_T) mx[i] = (unsigned short)K4_NONE;
       __syncthreads();
       for (int y = tid; y < n; y += K4_T) {
@@ -809,9 +860,9 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
       }
       __syncthreads();
       const int nf = s.sh[SH_NF];
-      const int region = nf > 0 ? min(64, (n + 2) / nf) : 0;  // u16 of stx per flagged row: count + columns (region 1: every flagged row stays in S)
+      const int region = nf > 0 ? min(64, (n + 2) / nf) : 0;  // u16 of the pool per flagged row: count + columns (region 1: every flagged row stays in S)
       if (nf > 0) {
-        k4_pool_build(s, nf, region, wave, lane);
+        k4_pool_build(s, flist, pool, nf, region, wave, lane);
         __syncthreads();
       }
       for (int round = 0;; round++) {
@@ -863,10 +914,10 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         for (int fb = 0; fb < nf; fb += 16) {  // flagged rows: a pooled tight column in S (16 lanes per row)
           const int i = fb + wave * 4 + (lane >> 4), lig = lane & 15;
           int x = -1, cnt = 0;
-          if (i < nf) { x = s.sty[i]; cnt = s.stx[i * region]; }
+          if (i < nf) { x = flist[i]; cnt = pool[i * region]; }
           bool hit = false;
           if (x >= 0 && !k4_bit(s.good, x))
-            for (int e = lig; e < cnt; e += 16) hit |= k4_bit(s.goody, s.stx[i * region + 1 + e]);
+            for (int e = lig; e < cnt; e += 16) hit |= k4_bit(s.goody, pool[i * region + 1 + e]);
           const unsigned gb = (unsigned)(__ballot(hit) >> (lane & 48)) & 0xffffu;
           if (gb && lig == 0) {
             atomicOr(&s.good[x >> 5], 1u << (x & 31));
@@ -879,20 +930,24 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
         __syncthreads();
         if (!s.sh[chslot[round % 3]]) break;
         if (round >= 40) {  // give up pruning for this phase: any superset of good is valid (R5)
-          for (int w = tid; w < nw; w += K4_T) s.goody[w] = ~0u;
+          for (int w = tid; w < nw; w += K4_T) { s.goody[w] = ~0u; s.good[w] = ~0u; }
           break;
         }
       }
       __syncthreads();
-      const long long t2 = PROF ? (long long)__builtin_readcyclecounter() : 0;
-      if (PROF) c_pull += t2 - t1;
-      // ... then the DFS (wave 0)
+      t2 = PROF ? (long long)__builtin_readcyclecounter() : 0;
+      if (PROF) c_pull += t2 - t1b;
+      // ... then the search goes on under S, from its deepest good frame (wave 0)
       if (wave == sw) {
-        const bool ok = k4_dfs<PROF>(s, root, lane, &q_iter, &q_act, pd);
-        if (!ok && lane == 0) s.sh[SH_BAD] = 3;
+        int r = 0;
+        if (k4_dfs_unwind(s, dfs, lane)) r = k4_dfs<PROF>(s, dfs, false, lane, &q_iter, &q_act, pd);
+        if (lane == 0) s.sh[SH_DFS] = r;
       }
       __syncthreads();
       if (PROF) c_dfs += (long long)__builtin_readcyclecounter() - t2;
+      }
+      if (s.sh[SH_DFS] != 1 && tid == 0) s.sh[SH_BAD] = 3;
+      __syncthreads();
       if (s.sh[SH_BAD]) bad = s.sh[SH_BAD];
       break;
     }

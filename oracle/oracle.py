@@ -370,18 +370,21 @@ def km_model(w, eps=0.01, march=True, sweep_first=False, full=False, flood_dead=
     return out + (int(st[3]), int(st[4]), int(st[5]), int(st[6])) if full else out
 
 
-def km4_model(w, eps=0.01, cap=3, prune=True, hint=0, exact_rest=False, exact_s=False, seed=False):
+def km4_model(w, eps=0.01, cap=3, prune=True, hint=0, exact_rest=False, exact_s=False, seed=False, lazy=False):
     """Rule-level model of the flood-first Kuhn-Munkres kernel k_km4 (oracle/km4_model.inc).  Returns (match, stats) with
-    stats = dict(phases, failed, flood_rows, push_rows, rebuild_rows, pull_rounds, dfs_steps, dfs_pops, overflow_rows);
-    match is None when the model reports the slack hazard (rule R4) -- the kernel then falls back to its literal solver.
-    The kernel's configuration is cap=3, hint=6, exact_rest=True (flagged rows: rule R5); the defaults are round 2's."""
+    stats = dict(phases, failed, flood_rows, push_rows, rebuild_rows, pull_rounds, dfs_steps, dfs_pops, overflow_rows, seeded, unseeded,
+    lazy_none, lazy_unwound); match is None when the model reports the slack hazard (rule R4) -- the kernel then falls back to its
+    literal solver.  The kernel's configuration is cap=3, hint=6, exact_rest=True, seed=True, lazy=True (rules R5, R3', R5'); the defaults
+    are round 2's."""
     w = np.ascontiguousarray(w, np.float64)
     n = w.shape[0]
     match = np.empty(n, np.int32)
-    st = np.zeros(11, np.int64)
+    st = np.zeros(13, np.int64)
     rc = lib().orc_km4_model(_p(w, C.c_double), n, C.c_double(eps), _p(match, C.c_int), _p(st, C.c_longlong),
-                             int(cap) | (0 if prune else 0x100) | (0x200 if exact_s else 0) | ((int(hint) & 0x3f) << 10) | (0x10000 if exact_rest else 0) | (0x20000 if seed else 0))
-    names = ("phases", "failed", "flood_rows", "push_rows", "rebuild_rows", "pull_rounds", "dfs_steps", "dfs_pops", "overflow_rows", "seeded", "unseeded")
+                             int(cap) | (0 if prune else 0x100) | (0x200 if exact_s else 0) | ((int(hint) & 0x3f) << 10) | (0x10000 if exact_rest else 0) | (0x20000 if seed else 0)
+                             | (0x40000 if lazy else 0))
+    names = ("phases", "failed", "flood_rows", "push_rows", "rebuild_rows", "pull_rounds", "dfs_steps", "dfs_pops", "overflow_rows", "seeded", "unseeded",
+             "lazy_none", "lazy_unwound")
     stats = dict(zip(names, (int(v) for v in st)))
     if rc == 4:
         return None, stats

@@ -44,7 +44,8 @@ def main():
         w = gen(rng, n, t % 5)
         ref, _ = O.km(w)
         for cap, prune, kw in ((1, True, {}), (3, True, {}), (3, False, {}), (6, True, {}), (3, True, dict(hint=6, exact_rest=True)),
-                               (3, True, dict(hint=6, exact_rest=True, seed=True))):  # the kernel's rule R5; R3' (groundwork, self-checked)
+                               (3, True, dict(hint=6, exact_rest=True, seed=True)), (3, True, dict(hint=6, exact_rest=True, seed=True, lazy=True)), (1, True, dict(lazy=True)),
+                               (3, True, dict(hint=6, lazy=True))):  # the kernel's rules R5, R3' (self-checked) and R5' (lazy S)
             m, _st = O.km4_model(w, cap=cap, prune=prune, **kw)
             if m is None:
                 hazards += 1
