@@ -821,7 +821,8 @@ def main():
                     "longest_solve_ms": round(max(s["longest_solve_ms"] for s in pls), 2),
                     "mean_launch_span_ms": round(sum(s["mean_launch_span_ms"] * s["launches"] for s in pls) / Lp, 1),
                     "idle_slot_fraction": round(float(np.mean([s["idle_slot_fraction"] for s in pls if s["launches"]])), 4),
-                    "solve_share_of_slot_time": round(float(np.mean([s["solve_share_of_slot_time"] for s in pls if s["launches"]])), 4)}
+                    "solve_share_of_slot_time": round(float(np.mean([s["solve_share_of_slot_time"] for s in pls if s["launches"]])), 4),
+                    "solves_through_the_literal_fallback": int(sum(c.loop_hazards() for c in loop_ctxs))}
     if pl_stats and dom == "pair_loop" and pl_stats["mean_launch_span_ms"] > 0:
         # `frac` above divides a batch's bytes by its fork -> join SPAN (the class launches of a batch overlap in it): the chip-level figure.
         # Per DISPATCH -- what a row of rocprofv3's kernel trace is (profiles/r0N_kernel_stats_bench_default.txt) -- the same bytes over the

@@ -47,7 +47,7 @@ class PairStats(C.Structure):
 
 EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_stage_stats", "ghicp_ctx_stage_clear", "ghicp_ctx_set_cu_mask",
-    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_timeline", "ghicp_ctx_set_loop_cost_hints", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
+    "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_timeline", "ghicp_ctx_set_loop_cost_hints", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_ctx_loop_hazards", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
     "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_cloud_bounds", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_loop_create", "ghicp_iterate", "ghicp_loop_result", "ghicp_loop_destroy", "ghicp_transform_cloud", "ghicp_transform_clouds", "ghicp_register_pair",
@@ -228,6 +228,12 @@ class Context:
         out = np.zeros((max(1, n.value), 3), np.int64)
         self._check(self.lib.ghicp_ctx_loop_timeline(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(n.value), C.byref(n)))
         return out[: n.value]
+
+    def loop_hazards(self):
+        """Kuhn-Munkres solves of this context's batched loops that took the solver's literal fallback (diagnostics; expected 0)."""
+        n = C.c_int64(0)
+        self._check(self.lib.ghicp_ctx_loop_hazards(self.h, C.byref(n)))
+        return n.value
 
     def kernel_time(self, name):
         """(total_ms, launches) of a named kernel since kernel_timing(True)."""

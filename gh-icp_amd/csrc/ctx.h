@@ -138,6 +138,7 @@ struct ghicp_ctx {
   static constexpr int KM_LSTAT_W = 8;
   long long km_launches = 0;
   std::vector<int> km_slots;
+  long long loop_hazards = 0;            // Kuhn-Munkres solves of this context's batched loops that took the literal fallback of rule R4 (ghicp_ctx_loop_hazards)
   std::vector<float> loop_cost_hints;    // ghicp_ctx_set_loop_cost_hints: queue order of the next persistent batch of exactly this many pairs
   std::vector<long long> loop_timeline;  // last persistent batch with kernel timing on: per pair (begin, end) in 100 MHz ticks and iterations
   // progress of the batched loop that is running on this context (pairs still iterating / pairs of the batch), readable from

@@ -250,7 +250,7 @@ extern "C" int ghicp_km_solve(ghicp_ctx* ctx, const double* w, int64_t n, double
   if (n > 0) {
     int st = 0;
     GH_HIP(hipMemcpy(&st, v2 ? ctx->buf[B_P_MISC].p : ctx->buf[B_KM_MISC].p, sizeof(int), hipMemcpyDeviceToHost));
-    if (st != 0) return ctx->fail(GHICP_ERR_INTERNAL, "km_solve: solver status %d (non-finite weights?)", st);
+    if ((st & 0xFFFF) != 0) return ctx->fail(GHICP_ERR_INTERNAL, "km_solve: solver status %d (non-finite weights?)", st & 0xFFFF);  // (bits 16+: a count of literal-fallback solves, diagnostics)
   }
   return GHICP_OK;
 }

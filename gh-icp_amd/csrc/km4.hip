@@ -146,6 +146,13 @@ extern "C" int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8) {
 // capacity = the slots one class can keep resident (the classes compete for the same CUs; a slot is busy from its start to the moment
 // its queue is empty, so what is idle is the tail of a batch, when the last pairs iterate alone), [7] share of the slot lifetimes spent
 // inside Kuhn-Munkres solves (the rest: sweeps, graph build, rigid solve).
+extern "C" int ghicp_ctx_loop_hazards(ghicp_ctx* ctx, int64_t* solves) {
+  GH_ENTER(ctx);
+  GH_ARG(solves != nullptr);
+  *solves = (int64_t)ctx->loop_hazards;
+  return GHICP_OK;
+}
+
 extern "C" int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8) {
   GH_ENTER(ctx);
   GH_ARG(out8 != nullptr);

@@ -969,6 +969,9 @@ __device__ inline void k4_solve_block(const Km2Problem& P, int flags, char* smem
   }
   if (tid == 0) {
     if (bad && P.status) *P.status = bad;
+    // diagnostics: solves that went through the literal fallback of rule R4, counted above the status bits (a persistent slot's pair keeps
+    // one status word for all its iterations; the host reads the count with the batch's results -- ghicp_ctx_loop_hazards)
+    if (hazard && P.status) atomicAdd(P.status, 0x10000);
     if (P.steps) {
       P.steps[0] = q_act;
       if (PROF) {

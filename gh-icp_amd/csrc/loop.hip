@@ -1066,7 +1066,10 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       GH_HIP(hipStreamSynchronize(s));
       int kmst = 0;
       for (int b = 0; b < nb; b++)
-        if (hp[b].km_status) kmst |= hkmst[(size_t)b];
+        if (hp[b].km_status) {
+          kmst |= hkmst[(size_t)b] & 0xFFFF;
+          ctx->loop_hazards += (long long)((unsigned)hkmst[(size_t)b] >> 16);  // solves through the literal fallback (diagnostics)
+        }
       if (any_dense && ctx->buf[B_KM_MISC].p) {  // the dense fallback reports through the context's own status word
         int v = 0;
         GH_HIP(hipMemcpy(&v, ctx->buf[B_KM_MISC].p, sizeof(int), hipMemcpyDeviceToHost));

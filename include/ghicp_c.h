@@ -102,6 +102,10 @@ int ghicp_ctx_km_launch_stats(ghicp_ctx* ctx, double* out8);
  * timing is on: out8 = { batches, workgroups that ran, solves, mean solve ms, longest solve ms, mean batch span ms, idle-slot fraction
  * (1 - slot lifetimes / (resident slots x span): the tail of a batch), share of the slot lifetimes spent inside Kuhn-Munkres solves }. */
 int ghicp_ctx_pair_loop_stats(ghicp_ctx* ctx, double* out8);
+/* Diagnostics: Kuhn-Munkres solves of this context's batched loops (ghicp_register_pairs / ghicp_register_clouds, Ct = KM) that went through the
+ * solver's literal single-lane fallback since the context was created (rule R4's hazard check, km4_dev.h: correct, slow by design;
+ * expected 0 on finite inputs -- a non-zero count explains multi-second solves). */
+int ghicp_ctx_loop_hazards(ghicp_ctx* ctx, int64_t* solves /*[host]*/);
 /* Scheduling hint for the NEXT batched Kuhn-Munkres registration on this context (ghicp_register_clouds / ghicp_register_pairs with
  * exactly n_pairs pairs; consumed by that call, ignored otherwise): cost[i] = expected relative TIME of pair i in a solve slot, e.g.
  * iterations x keypoints of the same pair last time, or any prior.  The solve slots of the persistent pair loop take the costliest pairs

@@ -76,3 +76,46 @@ def test_km4_model_kat_and_degenerate(oracle):
     assert oracle.km4_model(W)[0].tolist() == [0, 2, 1]
     for w in (np.full((7, 7), -3.0), np.zeros((1, 1)), -np.eye(6) * 2.0 - 1.0):
         np.testing.assert_array_equal(oracle.km4_model(w)[0], oracle.km(w)[0])
+
+
+@pytest.mark.parametrize("name,lazy_none", [("it0", 177), ("it10", 402), ("it30", 349), ("s22_it46", 206), ("s53_it0", 262)])
+def test_km4_model_lazy_s_real_matrices(oracle, name, lazy_none):
+    """Rule R5' (round 6, the kernel's configuration since): the search of an augmenting phase starts WITHOUT the set S and S is computed
+    when the search first steps back; the stack is then cut back to its deepest good frame.  Same matching as the reference on the five
+    real matrices; 21-48 % of their augmenting phases need no S at all, the pull rounds drop accordingly, and the search pays ~1 % more
+    activations for its excursions into rows that are not good."""
+    z = np.load(os.path.join(GOLD, "km_cfg2_%s.npz" % name))
+    n = int(z["n"])
+    w = np.full((n, n), float(z["bg"]))
+    w[z["rows"].astype(np.int64), z["cols"].astype(np.int64)] = z["vals"]
+    ref = oracle.km(w)[0]
+    m0, s0 = oracle.km4_model(w, cap=3, hint=6, exact_rest=True, seed=True)
+    m1, s1 = oracle.km4_model(w, cap=3, hint=6, exact_rest=True, seed=True, lazy=True)
+    assert m0 is not None and m1 is not None
+    np.testing.assert_array_equal(m0, ref)
+    np.testing.assert_array_equal(m1, ref)
+    assert s1["lazy_none"] == lazy_none and 0.2 * (s1["phases"] - s1["failed"]) < lazy_none < 0.5 * (s1["phases"] - s1["failed"])
+    assert s1["pull_rounds"] < s0["pull_rounds"] and s0["dfs_steps"] <= s1["dfs_steps"] < 1.1 * s0["dfs_steps"]
+    assert all(s1[k] == s0[k] for k in ("phases", "failed", "flood_rows", "push_rows", "rebuild_rows", "dfs_pops"))
+
+
+def test_km4_model_lazy_s_fuzz(oracle):
+    sys_path = os.path.join(ROOT, "scripts")
+    import sys
+
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import km4_model_fuzz as F
+
+    rng = np.random.default_rng(20260930)
+    none = 0
+    for t in range(300):
+        n = int(rng.choice([3, 5, 8, 17, 40, 65, 100, 130]))
+        w = F.gen(rng, n, t % 5)
+        ref, _ = oracle.km(w)
+        for kw in (dict(cap=3, hint=6, exact_rest=True, seed=True, lazy=True), dict(cap=1, lazy=True), dict(cap=3, hint=6, lazy=True)):
+            m, st = oracle.km4_model(w, **kw)
+            assert m is not None
+            np.testing.assert_array_equal(m, ref)
+            none += st["lazy_none"]
+    assert none > 0
