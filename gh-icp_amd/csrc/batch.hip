@@ -34,7 +34,7 @@ int gh_fpfh_batch_dev(ghicp_ctx* ctx, const float4* dsg, int M, const float4* pt
 namespace {
 
 constexpr int FB_MAX = 64;  // clouds per batch
-constexpr int FB_NMS_ROUNDS = 14;  // NMS rounds per launch sequence (the host looks at the last one's count and launches another sequence if need be)
+constexpr int FB_NMS_ROUNDS = 16;  // NMS rounds per launch sequence (the host looks at the last one's count and launches another sequence if need be)
 
 struct FbCloud {
   const float* xyz;  // raw cloud
