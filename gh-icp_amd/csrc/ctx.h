@@ -165,6 +165,7 @@ struct ghicp_ctx {
   // stays at three slots for the rest of the batch (round 5, call 5: 811 of 1024 slots busy from second 3.5 to the end of an 11 s batch).
   // GHICP_LOOP_CONFINE=0 switches it off (A/B measurements).
   bool loop_confine = true;
+  double loop_confine_margin = 1.15;  // on the confined class's share of the cost prior (GHICP_LOOP_CONFINE_MARGIN: experiments)
   hipStream_t confine_stream = nullptr, rest_stream = nullptr;  // masks: the confined class's CUs / all the others (the pair in use, owned by confine_cache)
   int confine_cus = 0;
   struct ConfinePair { int cus; hipStream_t confined, rest; };

@@ -42,6 +42,7 @@ extern "C" int ghicp_ctx_create(int device, ghicp_ctx** out) {
   if (const char* e = getenv("GHICP_LOOP_SLOTS")) c->loop_slots_cap = atoi(e) > 0 ? atoi(e) : 0;
   if (const char* e = getenv("GHICP_LOOP_CONFINE")) c->loop_confine = atoi(e) != 0;
   if (const char* e = getenv("GHICP_LOOP_MIN_LDS")) c->loop_min_lds = atoi(e) > 0 ? atoi(e) : 0;
+  if (const char* e = getenv("GHICP_LOOP_CONFINE_MARGIN")) { const double m = atof(e); if (m >= 0.25 && m <= 4.0) c->loop_confine_margin = m; }  // experiment hook: margin on the confined class's share
   if (hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) { delete c; return GHICP_ERR_HIP; }
   c->pinned_cap = 4096;
   *out = c;

@@ -736,7 +736,7 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
   int confine_b = 0;
   if (ctx->loop_confine && nc == 2 && plan.per_cu[0] == 3 && plan.per_cu[1] == 4 && plan.count[0] > 0 && plan.count[1] > 0 && ctx->cu_mask.empty() &&
       ctx->num_cu >= 8 && ctx->num_cu <= 2048 && plan.weight[0] > 0 && plan.weight[1] > 0) {
-    const double w = std::min(0.9, 1.15 * plan.weight[0] / (plan.weight[0] + plan.weight[1]));
+    const double w = std::min(0.9, ctx->loop_confine_margin * plan.weight[0] / (plan.weight[0] + plan.weight[1]));
     int B = (int)std::ceil(w * 4.0 * ctx->num_cu / (3.0 + w));
     B = std::max(B, (plan.count[0] >= 3 ? 1 : 0));
     B = std::min(B, std::min(ctx->num_cu / 2, cdiv(plan.count[0], 3)));
