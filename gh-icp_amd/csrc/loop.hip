@@ -604,7 +604,8 @@ __device__ __noinline__ void pl_solve(const LoopProb& P, double* red, int* ired,
 
 template <int FT, bool PROF>
 __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restrict__ probs, const int* __restrict__ order, const int npairs, int* qhead,
-                                                  const int km_flags, const int lds_bytes, unsigned long long* lstat, int* progress) {
+                                                  const int km_flags, const int lds_bytes, unsigned long long* lstat, int* progress,
+                                                  const int* __restrict__ order2, const int npairs2, int* qhead2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sB = reinterpret_cast<double*>(smem);
   double* red = sB + CHUNK_MAX * 3;
@@ -619,13 +620,22 @@ __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restric
   // alone by the model (scripts/km_hazard_survey.py; none of 2220 solves takes the hazard fallback), yet default runs show single solves
   // of 1-4 s (pair_loop_stats.longest_solve_ms).  Highest wave priority: the slot wins the arbitration whenever it can issue at all.
   __builtin_amdgcn_s_setprio(3);
+  // (round 6) a slot whose own queue is dry goes on with the queue of the class of SMALLER graphs (order2: they fit its LDS): the slots of the
+  // confined three-per-CU class used to leave one by one while the class's last pairs finished, and the launch that re-used their CUs for the
+  // other class waited behind the whole kernel in stream order -- 110-180 of 924 slots idle for ~2.2 s of a 9.5 s batch
+  // (profiles/r06_call10_log.txt: 924 -> 816 -> 744 before the 988 of the re-launch)
+  for (int qsel = 0; qsel < 2; qsel++) {
+  const int* const ord = qsel == 0 ? order : order2;
+  const int np = qsel == 0 ? npairs : npairs2;
+  int* const qh = qsel == 0 ? qhead : qhead2;
+  if (ord == nullptr) break;
   for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) *s_idx = atomicAdd(qhead, 1);
+    if (threadIdx.x == 0) *s_idx = atomicAdd(qh, 1);
     __syncthreads();
     const int q = *s_idx;
-    if (q >= npairs) break;
-    const LoopProb& P = probs[order[q]];
+    if (q >= np) break;
+    const LoopProb& P = probs[ord[q]];
     if (threadIdx.x == 0 && lstat) P.st->t_begin = __builtin_amdgcn_s_memrealtime();
     while (*(volatile int*)&P.st->done == 0) {
       pl_sweep<FT>(P, sB, red);   // calED + calCD_* + sums + penalty (ghicp_reg.cpp:114-139, 216-341)
@@ -640,6 +650,7 @@ __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restric
     }
     if (threadIdx.x == 0 && lstat) P.st->t_end = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && progress) __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   }
   if (threadIdx.x == 0 && lstat) {  // launch record: first slot start, last slot end, sum / max of the solve times, solves, sum of slot lifetimes
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -778,6 +789,7 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
   }
   hipEvent_t kt = ctx->kt_begin(KT_PAIR_LOOP);
   GH_HIP_JOIN(hipEventRecord(ctx->aux_events[0], s));
+  bool stole = false;
   for (int c = 0; c < nc; c++) {
     if (plan.count[c] <= 0) continue;
     // confined: the three-per-CU class on its CUs; the four-per-CU class on all the OTHER CUs (if it could use every CU, its slots would
@@ -801,27 +813,33 @@ int run_pair_loop(ghicp_ctx* ctx, const LoopProb* dprobs, int nb, const Km4Plan&
     batch_slots = std::max(batch_slots, per_cu * ctx->num_cu);
     batch_grid += grid;
     hipEvent_t kd = ctx->kt_begin_on(KT_PAIR_LOOP_DISPATCH, sc);  // this dispatch alone, on its own stream (behind the fork event)
+    // the confined class's slots go on with the other class's queue when their own is dry (smaller graphs: they fit)
+    const bool steal = confined && c == 0 && plan.lds[1] <= lds;
+    stole = stole || steal;
+    const int* o2 = steal ? (const int*)(plan.d_order + plan.begin[1]) : (const int*)nullptr;
+    const int n2 = steal ? plan.count[1] : 0;
+    int* q2 = steal ? dqheads + 1 : (int*)nullptr;
     if (prof)
       hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
-                         dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+                         dqheads + c, kflags, (int)lds, lstat, ctx->progress_host, o2, n2, q2);
     else
       hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid), dim3(K4_T), lds, sc, dprobs, (const int*)(plan.d_order + plan.begin[c]), plan.count[c],
-                         dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+                         dqheads + c, kflags, (int)lds, lstat, ctx->progress_host, o2, n2, q2);
     ctx->kt_end_on(KT_PAIR_LOOP_DISPATCH, kd, sc);
     GH_HIP_JOIN(hipGetLastError());
     if (c > 0 || confined) {
       GH_HIP_JOIN(hipEventRecord(ctx->aux_events[(size_t)c + 1], sc));
       GH_HIP_JOIN(hipStreamWaitEvent(s, ctx->aux_events[(size_t)c + 1], 0));
     }
-    if (confined && c == 1) {  // ... and the four-per-CU class once more, on the confined CUs, after the three-per-CU class
+    if (confined && c == 1 && !stole) {  // ... and the four-per-CU class once more, on the confined CUs, after the three-per-CU class (only when that class's slots could not take the queue over themselves)
       const int grid2 = std::min(plan.count[c], per_cu * confine_b);
       hipEvent_t kd2 = ctx->kt_begin_on(KT_PAIR_LOOP_DISPATCH, ctx->confine_stream);
       if (prof)
         hipLaunchKernelGGL((k_pair_loop<FT, true>), dim3(grid2), dim3(K4_T), lds, ctx->confine_stream, dprobs, (const int*)(plan.d_order + plan.begin[c]),
-                           plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+                           plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host, (const int*)nullptr, 0, (int*)nullptr);
       else
         hipLaunchKernelGGL((k_pair_loop<FT, false>), dim3(grid2), dim3(K4_T), lds, ctx->confine_stream, dprobs, (const int*)(plan.d_order + plan.begin[c]),
-                           plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host);
+                           plan.count[c], dqheads + c, kflags, (int)lds, lstat, ctx->progress_host, (const int*)nullptr, 0, (int*)nullptr);
       ctx->kt_end_on(KT_PAIR_LOOP_DISPATCH, kd2, ctx->confine_stream);
       GH_HIP_JOIN(hipGetLastError());
       batch_grid += grid2;
