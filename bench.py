@@ -692,9 +692,9 @@ def main():
     timelines = []
     for c in loop_ctxs:  # slot timeline of the last TIMED batch of every loop context (the comparison regions below would overwrite it)
         try:
-            timelines.append(c.loop_timeline())
+            timelines.append(c.loop_timeline(detail=True))
         except Exception:  # noqa: BLE001
-            timelines.append(np.zeros((0, 3), np.int64))
+            timelines.append(np.zeros((0, 7), np.int64))
     if args.no_hints_steps > 0 and hints_on[0] and CF["corr"] == "KM" and not dynamic and args.steps > 0:
         E = args.no_hints_steps
         rates = {}
@@ -989,7 +989,11 @@ def main():
         long_ = np.argsort(-(end - beg))[:10]
         timeline["last_batches"].append({"ctx": ci, "pairs": int(len(tl)), "span_s": round(span, 3), "active_pairs_every_250ms": active,
                                          "pair_seconds": round(float((end - beg).sum()), 1), "ms_per_iteration_in_slot": round(1e3 * float((end - beg).sum()) / max(1, int(tl[:, 2].sum())), 2),
-                                         "ten_longest": [{"begin_s": round(float(beg[i]), 2), "end_s": round(float(end[i]), 2), "iterations": int(tl[i, 2])} for i in long_],
+                                         # the stragglers of a batch, if any, lead this list: longest solve of the pair, the iteration it belongs to, where the slot ran
+                                         "ten_longest": [{"begin_s": round(float(beg[i]), 2), "end_s": round(float(end[i]), 2), "iterations": int(tl[i, 2]),
+                                                          "longest_solve_ms": round(float(tl[i, 3]) / 1e5, 1), "at_iteration": int(tl[i, 4]),
+                                                          "die_engine_array_cu": [int(tl[i, 5]) >> 8, (int(tl[i, 5]) >> 5) & 7, (int(tl[i, 5]) >> 4) & 1, int(tl[i, 5]) & 15]} for i in long_],
+                                         "pairs_whose_longest_solve_exceeds_1s": int((tl[:, 3] > 1e8).sum()),
                                          "last_begin_s": round(float(beg.max()), 2)})
     detail = {"timeline": timeline,
               # every pair of the LAST step's job, from the all-gather of the result records (all ranks): pair id -> [iterations, converged, 4x4]

@@ -221,13 +221,25 @@ class Context:
         c = np.ascontiguousarray(cost, dtype=np.float32)
         self._check(self.lib.ghicp_ctx_set_loop_cost_hints(self.h, C.c_int32(c.size), c.ctypes.data_as(C.POINTER(C.c_float))))
 
-    def loop_timeline(self):
-        """(n, 3) int64: per pair of the last persistent batch (kernel timing on) slot begin / end in 100 MHz ticks, iterations"""
+    def loop_timeline(self, detail=False):
+        """(n, 3) int64: per pair of the last persistent batch (kernel timing on) slot begin / end in 100 MHz ticks, iterations.
+        detail=True: (n, 7) -- + the pair's longest solve (ticks), its iteration, the compute unit (die * 64 + engine * 8 + array * ... packed as
+        die, engine, array, cu in one number: die << 8 | engine << 5 | array << 4 | cu) the slot ran on, 0 (ghicp_c.h: ghicp_ctx_loop_timeline)."""
         n = C.c_int64(0)
         self._check(self.lib.ghicp_ctx_loop_timeline(self.h, None, C.c_int64(0), C.byref(n)))
-        out = np.zeros((max(1, n.value), 3), np.int64)
-        self._check(self.lib.ghicp_ctx_loop_timeline(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(n.value), C.byref(n)))
-        return out[: n.value]
+        raw = np.zeros((max(1, n.value), 3), np.uint64)
+        self._check(self.lib.ghicp_ctx_loop_timeline(self.h, raw.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(n.value), C.byref(n)))
+        raw = raw[: n.value]
+        mask = np.uint64(0x000FFFFFFFFFFFFF)
+        out = np.zeros((raw.shape[0], 7 if detail else 3), np.int64)
+        out[:, 0] = (raw[:, 0] & mask).astype(np.int64)
+        out[:, 1] = (raw[:, 1] & mask).astype(np.int64)
+        out[:, 2] = (raw[:, 2] & np.uint64(0xFFFF)).astype(np.int64)
+        if detail:
+            out[:, 3] = ((raw[:, 2] >> np.uint64(32)) << np.uint64(4)).astype(np.int64)
+            out[:, 4] = ((raw[:, 2] >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64)
+            out[:, 5] = (raw[:, 0] >> np.uint64(52)).astype(np.int64)
+        return out
 
     def loop_hazards(self):
         """Kuhn-Munkres solves of this context's batched loops that took the solver's literal fallback (diagnostics; expected 0)."""

@@ -33,6 +33,11 @@ struct LoopState {
   double Rt_till[16];
   double rmse_after;
   unsigned long long t_begin, t_end;  // persistent pair loop: when a slot took the pair and when it let go (s_memrealtime, 100 MHz)
+  // diagnostics of the persistent loop (kernel timing on; round 6, the stragglers of DESIGN.md §6): the pair's longest Kuhn-Munkres solve, the
+  // iteration it belongs to, and where the slot ran (HW_ID: compute unit / shader array / engine, XCC_ID: the die)
+  unsigned long long t_solve_max;
+  int it_solve_max;
+  unsigned hw_id;
 };
 
 struct LoopConst {
@@ -637,6 +642,8 @@ __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restric
     if (q >= np) break;
     const LoopProb& P = probs[ord[q]];
     if (threadIdx.x == 0 && lstat) P.st->t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_pair_max = 0ull;
+    int it_pair_max = 0;
     while (*(volatile int*)&P.st->done == 0) {
       pl_sweep<FT>(P, sB, red);   // calED + calCD_* + sums + penalty (ghicp_reg.cpp:114-139, 216-341)
       pl_graph<FT>(P, ired);      // the sparse graph of findcorrespondenceKM (ghicp_reg.cpp:348-365): count, scan, fill
@@ -645,10 +652,17 @@ __global__ __launch_bounds__(K4_T, 4) void k_pair_loop(const LoopProb* __restric
       if (lstat) {
         const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
         t_solve += dt; t_solve_max = dt > t_solve_max ? dt : t_solve_max; n_solve++;
+        if (dt > t_pair_max) { t_pair_max = dt; it_pair_max = *(volatile int*)&P.st->it; }
       }
       pl_solve<FT>(P, red, ired, sh);  // Km::output, transformestimation, adjustweight (ghicp_reg.cpp:416-460, 605-927)
     }
-    if (threadIdx.x == 0 && lstat) P.st->t_end = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && lstat) {
+      P.st->t_end = __builtin_amdgcn_s_memrealtime();
+      P.st->t_solve_max = t_pair_max;
+      P.st->it_solve_max = it_pair_max;
+      // HW_ID (hwreg 4): CU_ID [11:8], SH_ID [12], SE_ID [15:13]; XCC_ID (hwreg 20): [3:0]
+      P.st->hw_id = ((unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) & 0xFFFFu) | (((unsigned)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xFu) << 16);
+    }
     if (threadIdx.x == 0 && progress) __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   }
@@ -1065,9 +1079,15 @@ int run_loops(ghicp_ctx* ctx, int nb, const gh_loop_job* jobs) {
       if (ctx->kt_on && persistent) {  // slot timeline of the batch (diagnostics, ghicp_ctx_loop_timeline): per pair begin / end / iterations
         ctx->loop_timeline.resize((size_t)nb * 3);
         for (int b = 0; b < nb; b++) {
-          ctx->loop_timeline[(size_t)b * 3] = (long long)hst[b].t_begin;
-          ctx->loop_timeline[(size_t)b * 3 + 1] = (long long)hst[b].t_end;
-          ctx->loop_timeline[(size_t)b * 3 + 2] = hst[b].it;
+          // iterations [15:0] | iteration of the pair's longest solve [31:16] | that solve in units of 16 ticks = 160 ns [63:32]; where the slot
+          // ran rides in the top bits of `begin` (ticks since boot need 48 bits): CU [55:52], shader array [56], engine [59:57], die [63:60]
+          const unsigned hw = hst[b].hw_id;
+          const unsigned long long where = (unsigned long long)((hw >> 8) & 0xFu) | ((unsigned long long)((hw >> 12) & 1u) << 4) | ((unsigned long long)((hw >> 13) & 7u) << 5) |
+                                           ((unsigned long long)((hw >> 16) & 0xFu) << 8);
+          ctx->loop_timeline[(size_t)b * 3] = (long long)((hst[b].t_begin & 0x000FFFFFFFFFFFFFull) | (where << 52));
+          ctx->loop_timeline[(size_t)b * 3 + 1] = (long long)(hst[b].t_end & 0x000FFFFFFFFFFFFFull);
+          ctx->loop_timeline[(size_t)b * 3 + 2] = (long long)(((unsigned long long)(hst[b].it & 0xFFFF)) | ((unsigned long long)(hst[b].it_solve_max & 0xFFFF) << 16) |
+                                                              (std::min<unsigned long long>(hst[b].t_solve_max >> 4, 0xFFFFFFFFull) << 32));
         }
       }
       for (int b = 0; b < nb; b++) {

@@ -115,8 +115,11 @@ int ghicp_ctx_loop_hazards(ghicp_ctx* ctx, int64_t* solves /*[host]*/);
  * sums.  Results do not depend on the hints (pairs share nothing); [host] array. */
 int ghicp_ctx_set_loop_cost_hints(ghicp_ctx* ctx, int32_t n_pairs, const float* cost);
 /* Diagnostics: the slot timeline of the LAST persistent batch that ran on this context while kernel timing was on -- per pair of the
- * batch (in the order of the call) three int64: when a solve slot took the pair, when it let go (device real-time clock, 100 MHz ticks),
- * and the pair's iterations.  out3 may be NULL (only *n_pairs is written); at most cap_pairs triples are copied. */
+ * batch (in the order of the call) three int64: when a solve slot took the pair, when it let go (device real-time clock, 100 MHz ticks,
+ * bits [51:0]), and the pair's iterations (bits [15:0]).  The spare bits carry what the stragglers of a batch are looked up by:
+ * out3[0] [55:52] compute unit, [56] shader array, [59:57] shader engine, [63:60] die (XCC) the slot ran on; out3[2] [31:16] the iteration of
+ * the pair's longest Kuhn-Munkres solve, [63:32] that solve's duration in units of 160 ns.
+ * out3 may be NULL (only *n_pairs is written); at most cap_pairs triples are copied. */
 int ghicp_ctx_loop_timeline(ghicp_ctx* ctx, int64_t* out3, int64_t cap_pairs, int64_t* n_pairs);
 /* Progress of the batched loop (ghicp_register_pairs / ghicp_register_clouds) currently running on this context: pairs that are still
  * iterating and pairs of the batch.  No device work; may be called from another thread while the loop runs (a scheduler can start the

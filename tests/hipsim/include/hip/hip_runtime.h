@@ -94,6 +94,7 @@ static inline void __builtin_amdgcn_wave_barrier(int line = __builtin_LINE()) { 
 static inline void __builtin_amdgcn_s_barrier() { hipsim::sync_threads(); }
 static inline void __builtin_amdgcn_s_sleep(int) { hipsim::yield(); }
 static inline void __builtin_amdgcn_s_setprio(int) {}  // issue arbitration between the waves of a SIMD: nothing to model
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }  // HW_ID / XCC_ID (where a wave runs: diagnostics of the pair loop): no hardware here
 static inline unsigned long long __ballot(int pred, int line = __builtin_LINE()) {
   return hipsim::wave_collective(hipsim::OP_BALLOT, line, pred ? 1 : 0, 0);
 }
