@@ -994,6 +994,10 @@ def main():
                                                           "longest_solve_ms": round(float(tl[i, 3]) / 1e5, 1), "at_iteration": int(tl[i, 4]),
                                                           "die_engine_array_cu": [int(tl[i, 5]) >> 8, (int(tl[i, 5]) >> 5) & 7, (int(tl[i, 5]) >> 4) & 1, int(tl[i, 5]) & 15]} for i in long_],
                                          "pairs_whose_longest_solve_exceeds_1s": int((tl[:, 3] > 1e8).sum()),
+                                         "five_longest_solves": [{"begin_s": round(float(beg[i]), 2), "end_s": round(float(end[i]), 2), "iterations": int(tl[i, 2]),
+                                                                  "longest_solve_ms": round(float(tl[i, 3]) / 1e5, 1), "at_iteration": int(tl[i, 4]),
+                                                                  "die_engine_array_cu": [int(tl[i, 5]) >> 8, (int(tl[i, 5]) >> 5) & 7, (int(tl[i, 5]) >> 4) & 1, int(tl[i, 5]) & 15]}
+                                                                 for i in np.argsort(-tl[:, 3])[:5]],
                                          "last_begin_s": round(float(beg.max()), 2)})
     detail = {"timeline": timeline,
               # every pair of the LAST step's job, from the all-gather of the result records (all ranks): pair id -> [iterations, converged, 4x4]
