@@ -48,7 +48,7 @@ class PairStats(C.Structure):
 EXPORTS = [
     "ghicp_ctx_create", "ghicp_ctx_destroy", "ghicp_ctx_set_stream", "ghicp_ctx_set_host_pointers", "ghicp_ctx_stage_stats", "ghicp_ctx_stage_clear", "ghicp_ctx_set_cu_mask",
     "ghicp_ctx_synchronize", "ghicp_ctx_kernel_timing", "ghicp_ctx_kernel_time", "ghicp_ctx_km_launch_stats", "ghicp_ctx_pair_loop_stats", "ghicp_ctx_loop_timeline", "ghicp_ctx_set_loop_cost_hints", "ghicp_ctx_loop_progress", "ghicp_ctx_loop_progress_reset", "ghicp_ctx_loop_hazards", "ghicp_last_error", "ghicp_version", "ghicp_params_default",
-    "ghicp_voxel_filter", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_cloud_bounds", "ghicp_pca_curvature", "ghicp_prune",
+    "ghicp_voxel_filter", "ghicp_sort_pairs", "ghicp_gather_points", "ghicp_bbx_magnitude", "ghicp_cloud_bounds", "ghicp_pca_curvature", "ghicp_prune",
     "ghicp_nms", "ghicp_keypoints", "ghicp_keypoints_adaptive", "ghicp_bsc_encode", "ghicp_fpfh", "ghicp_fpfh_keypoints", "ghicp_fd_bsc", "ghicp_fd_fpfh", "ghicp_km_solve",
     "ghicp_rigid_svd", "ghicp_rigid_svd_host", "ghicp_register", "ghicp_loop_create", "ghicp_iterate", "ghicp_loop_result", "ghicp_loop_destroy", "ghicp_transform_cloud", "ghicp_transform_clouds", "ghicp_register_pair",
     "ghicp_register_pairs",
@@ -362,6 +362,22 @@ class Context:
         m = C.c_int64(0)
         self._check(self.lib.ghicp_voxel_filter(self.h, _ptr(x), C.c_int64(n), x.shape[1], C.c_float(voxel), _ptr(keep), C.byref(m)))
         return keep[: m.value]
+
+    def sort_pairs(self, keys, vals=None, bit_begin=0, bit_end=None):
+        """stable ascending sort on the key bits [bit_begin, bit_end) (prims.hip); keys: int32 / int64 tensor or array holding u32 / u64 bit patterns"""
+        t = self.torch
+        k = self._dev(keys, None)
+        assert k.dtype in (t.int32, t.int64) and k.dim() == 1
+        kb = 4 if k.dtype == t.int32 else 8
+        n = k.shape[0]
+        ko = t.empty_like(k)
+        v = vo = None
+        if vals is not None:
+            v = self._dev(vals, t.int32)
+            vo = t.empty_like(v)
+        self._check(self.lib.ghicp_sort_pairs(self.h, kb, _ptr(k), _ptr(ko), _ptr(v) if v is not None else None, _ptr(vo) if vo is not None else None,
+                                              C.c_int64(n), int(bit_begin), int(8 * kb if bit_end is None else bit_end)))
+        return (ko, vo) if vals is not None else ko
 
     def bbx_magnitude(self, xyz):
         x = self._xyz(xyz)

@@ -20,12 +20,10 @@
 #include "bsc_dev.h"
 #include "prims.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <vector>
 
-typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096> GhSortConfig;  // see grid.hip
 
 float gh_fpfh_cell(const float* mm, long long m);  // fpfh.hip
 int gh_fpfh_batch_dev(ghicp_ctx* ctx, const float4* dsg, int M, const float4* pts, const unsigned* start, const GridDesc* gd_dev, const unsigned* cell_base_dev,
@@ -609,12 +607,7 @@ int build_grid(ghicp_ctx* ctx, const FbBlock* D, int which, const float4* dsg, i
   GH_TRY(ctx->reserve(sl.pts, (size_t)M + 1, &pts));
   hipEvent_t kg = ctx->kt_begin(KT_FB_GRID);
   hipLaunchKernelGGL(k_fb_cell_keys, dim3(cdiv(M, 256)), dim3(256), 0, s, D, which, dsg, M, keys, vals);
-  size_t tb = 0;
-  const int eb = bits_for(total_cells);
-  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, keys, keys2, vals, vals2, (size_t)M, 0u, (unsigned)eb, s)));
-  char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
-  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)M, 0u, (unsigned)eb, s)));
+  GH_TRY(gh_radix_sort_u32(ctx, keys, keys2, vals, vals2, M, 0, bits_for(total_cells)));  // stable: a cell keeps its points in down-sampled order (prims.hip)
   hipLaunchKernelGGL(k_fb_gather_sorted, dim3(cdiv(M, 256)), dim3(256), 0, s, dsg, vals2, M, pts);
   gh_cell_start_launch(s, keys2, (unsigned)M, total_cells, start);  // (round 5: the table is filled from the sorted keys, grid.hip)
   ctx->kt_end(KT_FB_GRID, kg);
@@ -732,16 +725,11 @@ extern "C" int ghicp_clouds_recompute(ghicp_ctx* ctx, int32_t n_clouds, ghicp_cl
   if (ebmax + cloud_bits + idx_bits > 64) idx_bits = 0;
   hipLaunchKernelGGL(k_fb_voxel_keys, dim3(cdiv(N, 256)), dim3(256), 0, s, (const FbBlock*)D, (int)N, ebmax, idx_bits, vkeys, vvals);
   ctx->kt_end(KT_FB_VOXEL, kv0);
-  size_t tb = 0;
-  const unsigned sort_bits = (unsigned)(ebmax + cloud_bits);
-  if (idx_bits > 0) GH_HIP((rocprim::radix_sort_keys<GhSortConfig>(nullptr, tb, vkeys, vkeys2, (size_t)N, (unsigned)idx_bits, (unsigned)idx_bits + sort_bits, s)));
-  else GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));
-  char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
+  const int sort_bits = ebmax + cloud_bits;
   hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
-  // stable: lowest index leads its voxel
-  if (idx_bits > 0) GH_HIP((rocprim::radix_sort_keys<GhSortConfig>(tmp, tb, vkeys, vkeys2, (size_t)N, (unsigned)idx_bits, (unsigned)idx_bits + sort_bits, s)));
-  else GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, vkeys, vkeys2, vvals, vvals2, (size_t)N, 0u, sort_bits, s)));
+  // stable: lowest index leads its voxel (prims.hip)
+  if (idx_bits > 0) GH_TRY(gh_radix_sort_u64(ctx, vkeys, vkeys2, nullptr, nullptr, N, idx_bits, idx_bits + sort_bits));
+  else GH_TRY(gh_radix_sort_u64(ctx, vkeys, vkeys2, vvals, vvals2, N, 0, sort_bits));
   ctx->kt_end(KT_VOXEL_SORT, kev);
   const unsigned long long vmask = ebmax >= 64 ? ~0ull : ((1ull << ebmax) - 1ull);
   hipEvent_t kv1 = ctx->kt_begin(KT_FB_VOXEL);

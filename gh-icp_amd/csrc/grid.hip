@@ -1,19 +1,11 @@
 // Uniform-grid build (cell keys -> stable radix sort -> cell table -> points in cell order) and the
-// voxel down-sampling filter.  rocPRIM/hipCUB is used for the radix sort / select primitives only.
+// voxel down-sampling filter.  The sort, scan and select primitives are this library's own (prims.hip); rounds 1-5 called rocPRIM's
+// Onesweep here (with its merge-sort limit lowered to 4096 items: the default dispatch cost ~17 launches per sort below 1 M items).
 #include "grid.h"
 #include "prims.h"
 
 #include <algorithm>
-
-#include <hipcub/hipcub.hpp>
-
 #include <cmath>
-
-// Radix sort of the voxel / cell keys (22-30 significant bits, 0.25-10 M pairs): rocPRIM's default dispatch picks its merge sort below
-// 1 M items -- ~17 launches of ~5 us each per sort, half of all the front end's launches (profiles/r01_kernel_stats_bench_default.txt),
-// and the front end is bound by the host's launch rate.  With the limit at 4096 items the Onesweep path runs instead: one histogram
-// + scan launch and one launch per 8-bit digit place.  Both are stable, so the order (lowest input index first) is unchanged.
-typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096> GhSortConfig;
 
 namespace {
 
@@ -114,12 +106,7 @@ int gh_grid_build(ghicp_ctx* ctx, const float* xyz, long long n, int stride, flo
   GH_TRY(ctx->reserve(sl.pts, (size_t)n + 1, &pts));
   if (n > 0) {
     hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, n, stride, g, keys, vals);
-    size_t tb = 0;
-    const int eb = bits_for(g.ncell);
-    GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));
-    char* tmp;
-    GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
-    GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));
+    GH_TRY(gh_radix_sort_u32(ctx, keys, keys2, vals, vals2, n, 0, bits_for(g.ncell)));  // stable: a cell keeps its points in input order (prims.hip)
     hipLaunchKernelGGL(k_gather_sorted, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, stride, vals2, n, pts);
   }
   gh_cell_start_launch(s, keys2, (unsigned)n, g.ncell, start);
@@ -194,12 +181,8 @@ int gh_voxel_filter_dev(ghicp_ctx* ctx, const float* xyz, long long n, int strid
   hipLaunchKernelGGL(k_voxel_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, xyz, n, stride, v, keys, vals);
   const unsigned long long maxkey = (maxv[0] - 1) * v.mul_x + (maxv[1] - 1) * v.mul_y + (maxv[2] - 1);
   const int eb = bits_for(maxkey);
-  size_t tb = 0;
-  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(nullptr, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));
-  char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
   hipEvent_t kev = ctx->kt_begin(KT_VOXEL_SORT);
-  GH_HIP((rocprim::radix_sort_pairs<GhSortConfig>(tmp, tb, keys, keys2, vals, vals2, (size_t)n, 0u, (unsigned)eb, s)));  // stable: lowest input index leads its voxel
+  GH_TRY(gh_radix_sort_u64(ctx, keys, keys2, vals, vals2, n, 0, eb));  // stable: lowest input index leads its voxel (prims.hip)
   ctx->kt_end(KT_VOXEL_SORT, kev);
   hipLaunchKernelGGL(k_voxel_flags, dim3(cdiv(n, 256)), dim3(256), 0, s, keys2, n, flags);
   hipLaunchKernelGGL(k_set_first, dim3(1), dim3(1), 0, s, keep);

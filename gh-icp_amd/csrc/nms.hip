@@ -12,7 +12,7 @@
 
 #include <algorithm>
 
-#include <hipcub/hipcub.hpp>
+#include "prims.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_nms_keys(const double* __restrict__ cur
                                                   unsigned long long* __restrict__ keys, int* __restrict__ vals) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= c) return;
-  keys[i] = f64_key(curvature[cand[i]]);
+  keys[i] = ~f64_key(curvature[cand[i]]);
   vals[i] = i;
 }
 
@@ -72,11 +72,8 @@ int gh_nms_dev(ghicp_ctx* ctx, const float* xyz, int stride, const double* curva
   GH_TRY(ctx->reserve(B_FE_CPTS, (size_t)c * 3 + 3, &cpts));
   GH_TRY(ctx->reserve(B_FE_SCAN, 16, &misc));
   hipLaunchKernelGGL(k_nms_keys, dim3(cdiv(c, 256)), dim3(256), 0, s, curvature, cand, (int)c, keys, vals);
-  size_t tb = 0;
-  GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, keys, keys2, vals, ord, (int)c, 0, 64, s));
-  char* tmp;
-  GH_TRY(ctx->reserve(B_GRID_TMP, tb + 16, &tmp));
-  GH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tb, keys, keys2, vals, ord, (int)c, 0, 64, s));  // stable
+  // descending curvature, ties in candidate order: a stable ascending sort of the complemented keys (prims.hip)
+  GH_TRY(gh_radix_sort_u64(ctx, keys, keys2, reinterpret_cast<const unsigned*>(vals), reinterpret_cast<unsigned*>(ord), c, 0, 64));
   hipLaunchKernelGGL(k_nms_points, dim3(cdiv(c, 256)), dim3(256), 0, s, xyz, stride, cand, ord, (int)c, cpts);
   const float r2 = (float)((double)radius * (double)radius);
   int* hflag = reinterpret_cast<int*>(ctx->pinned);

@@ -9,6 +9,8 @@
 // bound either way), and the result is position-exact: item i of the output is the i-th flagged / distinct input.
 #include "prims.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int PT = 256;           // threads per workgroup
@@ -158,6 +160,198 @@ __global__ __launch_bounds__(PT) void k_select_apply(const void* __restrict__ in
 
 int tiles_of(long long n) { return (int)((n + TILE - 1) / TILE); }
 
+// ================================================================================ stable LSD radix sort (round 6)
+// Replaces rocPRIM's Onesweep for the voxel keys, the two grids' cell keys and the single-cloud NMS order (filter.hpp:66,
+// keypoint_detect.hpp:119-130: the reference's std::sort calls; stability = "lowest input index leads its voxel / cell").
+// One pass per 8-bit digit place, four launches per pass over the same 4096-item tiles as the scan / select above:
+//   k_rs_hist     digit counts of every tile                      -> table[tile][digit]   (1 KB per tile, written coalesced)
+//   k_rs_chunks   per digit, exclusive scan over a chunk of tiles -> table (in place), chunk totals part[chunk][digit]
+//   k_rs_bases    one workgroup: chunk totals -> chunk bases per digit, digit totals -> digit bases
+//   k_rs_scatter  ranks inside the tile from wave ballots (items in input order: wave-contiguous chunks, a wave's rounds in turn), the
+//                 tile reordered by digit in LDS, then written out as runs -- consecutive threads store consecutive addresses of a run
+// No look-back, no spinning, no temporary-storage query; position-exact, so the result does not depend on the launch order of workgroups.
+constexpr int RD = 256;   // digits per place
+constexpr int RC = 64;    // tiles per chunk of k_rs_chunks
+
+template <typename K>
+__global__ __launch_bounds__(PT) void k_rs_hist(const K* __restrict__ keys, long long n, int shift, unsigned mask, unsigned* __restrict__ table) {
+  __shared__ unsigned cnt[4][RD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0u;
+  __syncthreads();
+  const long long t0 = (long long)blockIdx.x * TILE;
+  K key[PI];  // all loads of the tile in flight before the first LDS atomic
+#pragma unroll
+  for (int k = 0; k < PI; k++) {
+    const long long i = t0 + (long long)(wave * PI + k) * 64 + lane;
+    key[k] = i < n ? keys[i] : (K)0;
+  }
+#pragma unroll
+  for (int k = 0; k < PI; k++) {
+    const long long i = t0 + (long long)(wave * PI + k) * 64 + lane;
+    if (i < n) atomicAdd(&cnt[wave][(unsigned)(key[k] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  table[(size_t)blockIdx.x * RD + threadIdx.x] = cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
+}
+
+// thread = digit; a workgroup walks RC consecutive tiles (rows of 1 KB, coalesced)
+__global__ __launch_bounds__(RD) void k_rs_chunks(unsigned* __restrict__ table, int nt, unsigned* __restrict__ part) {
+  const int t0 = blockIdx.x * RC, t1 = t0 + RC < nt ? t0 + RC : nt;
+  unsigned run = 0;
+#pragma unroll 8
+  for (int t = t0; t < t1; t++) {
+    const unsigned v = table[(size_t)t * RD + threadIdx.x];
+    table[(size_t)t * RD + threadIdx.x] = run;
+    run += v;
+  }
+  part[(size_t)blockIdx.x * RD + threadIdx.x] = run;
+}
+
+__global__ __launch_bounds__(RD) void k_rs_bases(unsigned* __restrict__ part, int nchunk, unsigned* __restrict__ digit_base) {
+  __shared__ unsigned sh[4];
+  unsigned run = 0;
+#pragma unroll 8
+  for (int j = 0; j < nchunk; j++) {
+    const unsigned v = part[(size_t)j * RD + threadIdx.x];
+    part[(size_t)j * RD + threadIdx.x] = run;
+    run += v;
+  }
+  unsigned tot;
+  digit_base[threadIdx.x] = block_excl_scan(run, sh, &tot);
+}
+
+template <typename K, bool HASV>
+__global__ __launch_bounds__(PT) void k_rs_scatter(const K* __restrict__ kin, const unsigned* __restrict__ vin, K* __restrict__ kout, unsigned* __restrict__ vout,
+                                                   long long n, int shift, unsigned mask, const unsigned* __restrict__ table, const unsigned* __restrict__ part,
+                                                   const unsigned* __restrict__ digit_base) {
+  __shared__ unsigned cnt[4][RD];   // per wave: running count of a digit, then the wave's base inside the digit's run of this tile
+  __shared__ unsigned s_first[RD];  // first tile-local position of a digit
+  __shared__ unsigned s_delta[RD];  // global position of the digit's run of this tile - s_first
+  __shared__ unsigned sh[4];
+  __shared__ K lk[TILE];
+  __shared__ unsigned lv[HASV ? TILE : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long t0 = (long long)blockIdx.x * TILE;
+  const int here = n - t0 < (long long)TILE ? (int)(n - t0) : TILE;
+#pragma unroll
+  for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0u;
+  K key[PI];
+#pragma unroll
+  for (int k = 0; k < PI; k++) {
+    const long long i = t0 + (long long)(wave * PI + k) * 64 + lane;
+    key[k] = i < n ? kin[i] : (K)0;
+  }
+  __syncthreads();
+  // rank of every item among the earlier items of its digit in this wave's chunk
+  unsigned rk[PI];
+#pragma unroll
+  for (int k = 0; k < PI; k++) {
+    const bool valid = (wave * PI + k) * 64 + lane < here;
+    const unsigned d = (unsigned)(key[k] >> shift) & mask;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const int leader = valid ? (int)__ffsll(peers) - 1 : lane;
+    unsigned base = 0;
+    if (valid && lane == leader) {
+      base = cnt[wave][d];
+      cnt[wave][d] = base + (unsigned)__popcll(peers);
+    }
+    base = __shfl(base, leader, 64);
+    rk[k] = base + (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  {  // thread = digit: the waves' bases inside the digit's run, the run's place in the tile and in the output
+    const int d = threadIdx.x;
+    const unsigned c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+    cnt[0][d] = 0u; cnt[1][d] = c0; cnt[2][d] = c0 + c1; cnt[3][d] = c0 + c1 + c2;
+    unsigned tot;
+    const unsigned first = block_excl_scan(c0 + c1 + c2 + c3, sh, &tot);
+    s_first[d] = first;
+    s_delta[d] = digit_base[d] + part[(size_t)(blockIdx.x / RC) * RD + d] + table[(size_t)blockIdx.x * RD + d] - first;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PI; k++) {
+    const int q = (wave * PI + k) * 64 + lane;
+    if (q < here) {
+      const unsigned d = (unsigned)(key[k] >> shift) & mask;
+      const unsigned p = s_first[d] + cnt[wave][d] + rk[k];
+      lk[p] = key[k];
+      if (HASV) lv[p] = vin[t0 + q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PI; j++) {
+    const int p = j * PT + threadIdx.x;
+    if (p < here) {
+      const K kk = lk[p];
+      const unsigned pos = s_delta[(unsigned)(kk >> shift) & mask] + (unsigned)p;
+      kout[pos] = kk;
+      if (HASV) vout[pos] = lv[p];
+    }
+  }
+}
+
+template <typename K>
+int radix_sort_impl(ghicp_ctx* ctx, const K* kin, K* kout, const unsigned* vin, unsigned* vout, long long n, int bit_begin, int bit_end) {
+  if (n <= 0) return GHICP_OK;
+  hipStream_t s = ctx->stream;
+  const bool hasv = vin != nullptr;
+  const int passes = bit_end > bit_begin ? (bit_end - bit_begin + 7) / 8 : 0;
+  if (passes == 0) {
+    GH_HIP(hipMemcpyAsync(kout, kin, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, s));
+    if (hasv) GH_HIP(hipMemcpyAsync(vout, vin, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+    return GHICP_OK;
+  }
+  const int nt = tiles_of(n), nchunk = (nt + RC - 1) / RC;
+  unsigned* table;
+  GH_TRY(ctx->reserve(B_PRIM_TMP, (size_t)nt * RD + (size_t)nchunk * RD + RD + 4, &table));
+  unsigned* part = table + (size_t)nt * RD;
+  unsigned* digit_base = part + (size_t)nchunk * RD;
+  // the input is left alone: passes alternate between a spare buffer and the output so that the last one lands in the output
+  K* spare_k = nullptr;
+  unsigned* spare_v = nullptr;
+  if (passes > 1) {
+    char* sp;
+    const size_t kb = (((size_t)n * sizeof(K) + 255) / 256) * 256;
+    GH_TRY(ctx->reserve(B_GRID_TMP, kb + (hasv ? (size_t)n * sizeof(unsigned) : 0) + 16, &sp));
+    spare_k = reinterpret_cast<K*>(sp);
+    spare_v = reinterpret_cast<unsigned*>(sp + kb);
+  }
+  const K* src_k = kin;
+  const unsigned* src_v = vin;
+  for (int p = 0; p < passes; p++) {
+    const bool to_out = ((passes - 1 - p) & 1) == 0;
+    K* dst_k = to_out ? kout : spare_k;
+    unsigned* dst_v = to_out ? vout : spare_v;
+    const int shift = bit_begin + 8 * p;
+    const unsigned mask = (1u << std::min(8, bit_end - shift)) - 1u;
+    hipLaunchKernelGGL((k_rs_hist<K>), dim3(nt), dim3(PT), 0, s, src_k, n, shift, mask, table);
+    hipLaunchKernelGGL(k_rs_chunks, dim3(nchunk), dim3(RD), 0, s, table, nt, part);
+    hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(RD), 0, s, part, nchunk, digit_base);
+    if (hasv)
+      hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(nt), dim3(PT), 0, s, src_k, src_v, dst_k, dst_v, n, shift, mask, (const unsigned*)table, (const unsigned*)part,
+                         (const unsigned*)digit_base);
+    else
+      hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(nt), dim3(PT), 0, s, src_k, (const unsigned*)nullptr, dst_k, (unsigned*)nullptr, n, shift, mask,
+                         (const unsigned*)table, (const unsigned*)part, (const unsigned*)digit_base);
+    src_k = dst_k;
+    src_v = dst_v;
+  }
+  GH_HIP(hipGetLastError());
+  return GHICP_OK;
+}
+
+
+
 template <int MODE>
 int select_impl(ghicp_ctx* ctx, const void* in, long long n, unsigned* out, int* d_count, const unsigned* vals = nullptr) {
   hipStream_t s = ctx->stream;
@@ -200,4 +394,43 @@ int gh_select_flagged_u32(ghicp_ctx* ctx, const unsigned* vals, const unsigned c
 
 int gh_unique_sorted_u32(ghicp_ctx* ctx, const unsigned* keys, long long n, unsigned* out, int* d_count) {
   return select_impl<2>(ctx, keys, n, out, d_count);
+}
+
+int gh_radix_sort_u32(ghicp_ctx* ctx, const unsigned* keys_in, unsigned* keys_out, const unsigned* vals_in, unsigned* vals_out, long long n, int bit_begin,
+                      int bit_end) {
+  return radix_sort_impl<unsigned>(ctx, keys_in, keys_out, vals_in, vals_out, n, bit_begin, bit_end);
+}
+
+int gh_radix_sort_u64(ghicp_ctx* ctx, const unsigned long long* keys_in, unsigned long long* keys_out, const unsigned* vals_in, unsigned* vals_out, long long n,
+                      int bit_begin, int bit_end) {
+  return radix_sort_impl<unsigned long long>(ctx, keys_in, keys_out, vals_in, vals_out, n, bit_begin, bit_end);
+}
+
+extern "C" int ghicp_sort_pairs(ghicp_ctx* ctx, int key_bytes, const void* keys_in, void* keys_out, const uint32_t* vals_in, uint32_t* vals_out, int64_t n,
+                                int bit_begin, int bit_end) {
+  GH_ENTER(ctx);
+  GH_ARG((key_bytes == 4 || key_bytes == 8) && n >= 0 && n < (1ll << 31) - 2 && bit_begin >= 0 && bit_begin <= bit_end && bit_end <= 8 * key_bytes);
+  GH_ARG((vals_in == nullptr) == (vals_out == nullptr) && (n == 0 || (keys_in != nullptr && keys_out != nullptr && keys_in != keys_out)));
+  if (n == 0) return GHICP_OK;
+  Stager sg(ctx);
+  const unsigned* vi = nullptr;
+  unsigned* vo = nullptr;
+  if (vals_in) {
+    GH_TRY(sg.in(vals_in, (size_t)n, &vi));
+    GH_TRY(sg.out(vals_out, (size_t)n, &vo));
+  }
+  if (key_bytes == 4) {
+    const unsigned* ki;
+    unsigned* ko;
+    GH_TRY(sg.in(static_cast<const unsigned*>(keys_in), (size_t)n, &ki));
+    GH_TRY(sg.out(static_cast<unsigned*>(keys_out), (size_t)n, &ko));
+    GH_TRY(gh_radix_sort_u32(ctx, ki, ko, vi, vo, n, bit_begin, bit_end));
+  } else {
+    const unsigned long long* ki;
+    unsigned long long* ko;
+    GH_TRY(sg.in(static_cast<const unsigned long long*>(keys_in), (size_t)n, &ki));
+    GH_TRY(sg.out(static_cast<unsigned long long*>(keys_out), (size_t)n, &ko));
+    GH_TRY(gh_radix_sort_u64(ctx, ki, ko, vi, vo, n, bit_begin, bit_end));
+  }
+  return sg.finish();
 }

@@ -135,6 +135,12 @@ void ghicp_params_default(ghicp_params* p);
 /* CFilter::voxelfilter (include/filter.hpp:28-88, incl. its phantom-entry quirk: output row 0 is
  * a copy of input point 0).  keep_idx: capacity n+1 int32; *m [host]. */
 int ghicp_voxel_filter(ghicp_ctx* ctx, const float* xyz, int64_t n, int stride, float voxel, int32_t* keep_idx, int64_t* m);
+/* The stable sort behind the voxel filter, the grids and the NMS order (the reference's std::sort calls, include/filter.hpp:66 and
+ * include/keypoint_detect.hpp:119-130, made deterministic: equal keys keep their input order).  Ascending on the key bits
+ * [bit_begin, bit_end) of n keys of key_bytes (4 or 8) bytes each; vals_in / vals_out (u32) may both be NULL (keys only).  The inputs are
+ * left untouched; out-of-place (keys_out != keys_in). */
+int ghicp_sort_pairs(ghicp_ctx* ctx, int key_bytes, const void* keys_in, void* keys_out, const uint32_t* vals_in, uint32_t* vals_out, int64_t n,
+                     int bit_begin, int bit_end);
 /* gather rows: out[i] = xyz[idx[i]] as packed float4 (x,y,z,0). */
 int ghicp_gather_points(ghicp_ctx* ctx, const float* xyz, int stride, const int32_t* idx, int64_t m, float* out_xyz4);
 /* bbx_magnitude of test/ghicp_main.cpp:91-93 (CloudUtility::getCloudBound, utility.h:153-183). [host] out */

@@ -32,6 +32,37 @@ def test_voxel_filter(ctx, oracle, tls, synth):
     np.testing.assert_array_equal(ctx.voxel_filter(same, 0.1).cpu().numpy(), oracle.voxel_filter(same, 0.1))
 
 
+def test_sort_pairs_is_a_stable_sort_on_the_bit_range(ctx, api):
+    """The library's own radix sort (prims.hip; the reference's std::sort of filter.hpp:66 / keypoint_detect.hpp:119-130 made deterministic)
+    against numpy's stable sort of the masked keys: keys AND values bit for bit -- i.e. equal keys keep their input order --, for 4- and
+    8-byte keys, keys only, bit ranges that end inside a digit, inputs of one item, one tile, a ragged last tile and several chunks of tiles,
+    few distinct keys (long runs), and inputs left untouched."""
+    rng = np.random.default_rng(5)
+    cases = [(1, 4, 0, 32), (63, 4, 0, 7), (4096, 4, 0, 26), (4097, 8, 0, 39), (70_001, 4, 3, 21), (70_001, 8, 25, 64), (300_000, 8, 0, 64), (300_000, 4, 0, 32),
+             (5000, 8, 0, 0), (5000, 4, 9, 9)]
+    for n, kb, b, e in cases:
+        for distinct in (0, 5):
+            if kb == 4:
+                k = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+            else:
+                k = rng.integers(0, 1 << 63, n, dtype=np.uint64) * 2 + rng.integers(0, 2, n, dtype=np.uint64)
+            if distinct:
+                k = k[rng.integers(0, distinct, n)]
+            v = rng.permutation(n).astype(np.int32)
+            sub = (k >> np.uint64(b)) & np.uint64((1 << (e - b)) - 1) if kb == 8 else (k.astype(np.uint64) >> np.uint64(b)) & np.uint64((1 << (e - b)) - 1)
+            order = np.argsort(sub, kind="stable")
+            ks = k.view(np.int32 if kb == 4 else np.int64)
+            k0 = ks.copy()
+            ko, vo = ctx.sort_pairs(ks, v, b, e)
+            np.testing.assert_array_equal(ko.cpu().numpy(), ks[order])
+            np.testing.assert_array_equal(vo.cpu().numpy(), v[order])
+            np.testing.assert_array_equal(ctx.sort_pairs(ks, None, b, e).cpu().numpy(), ks[order])  # keys only
+            np.testing.assert_array_equal(ks, k0)
+    assert ctx.sort_pairs(np.zeros(0, np.int64)).shape[0] == 0
+    with pytest.raises(api.GhicpError):
+        ctx.sort_pairs(np.zeros(4, np.int32), None, 5, 33)
+
+
 def test_bbx_magnitude(ctx, oracle, tls):
     assert ctx.bbx_magnitude(tls.source) == oracle.bbx_magnitude(tls.source)
 
