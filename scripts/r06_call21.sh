@@ -8,6 +8,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_frontend.py tests/test_gpu_batch.py tests/test_golden.py tests/test_gpu_cloud_cache.py tests/test_gpu_zz_batch_fullsize.py tests/test_gpu_icp.py -m gpu -q -x > $O/r06_gputests_call21.txt 2>&1
 echo "pytest rc=$?" | tee -a $O/r06_gputests_call21.txt; tail -3 $O/r06_gputests_call21.txt
+timeout 200 python scripts/sort_bench.py 2>&1 | tail -6 | tee $O/r06_sort_bench_call21.txt
 cd /tmp
 B1="python $R/bench.py --steps 1 --warmup 1 --distinct 8 --pairs-per-step 256 --cpu-baseline 0 --no-hints-steps 0 --fe-batch 32 --fe-batch-streams 1 --fe-streams 1 --pipeline 0 --scene-cache /tmp/scenes64"
 for v in base new; do
