@@ -169,6 +169,7 @@ int tiles_of(long long n) { return (int)((n + TILE - 1) / TILE); }
 //   k_rs_bases    one workgroup: chunk totals -> chunk bases per digit, digit totals -> digit bases
 //   k_rs_scatter  ranks inside the tile from wave ballots (items in input order: wave-contiguous chunks, a wave's rounds in turn), the
 //                 tile reordered by digit in LDS, then written out as runs -- consecutive threads store consecutive addresses of a run
+// (three launches up to 64 tiles: k_rs_chunk_bases; ONE launch for all places up to one tile: k_rs_small)
 // No look-back, no spinning, no temporary-storage query; position-exact, so the result does not depend on the launch order of workgroups.
 constexpr int RD = 256;   // digits per place
 constexpr int RC = 64;    // tiles per chunk of k_rs_chunks
@@ -222,29 +223,24 @@ __global__ __launch_bounds__(RD) void k_rs_bases(unsigned* __restrict__ part, in
   digit_base[threadIdx.x] = block_excl_scan(run, sh, &tot);
 }
 
+// One digit place of one tile, by the whole workgroup: the items (key[k], val[k] of item (wave * PI + k) * 64 + lane, `here` of them) end up in
+// T.lk / T.lv in stable order of the digit, T.first[d] = first position of digit d.  Ranks from wave ballots: a wave owns PI * 64 consecutive
+// items and takes them 64 at a time; the lanes of a round that share a digit find each other with eight ballots, the lowest of them bumps the
+// wave's counter of that digit (LDS, that one lane only) and hands the old value round.  Ends with a barrier.
 template <typename K, bool HASV>
-__global__ __launch_bounds__(PT) void k_rs_scatter(const K* __restrict__ kin, const unsigned* __restrict__ vin, K* __restrict__ kout, unsigned* __restrict__ vout,
-                                                   long long n, int shift, unsigned mask, const unsigned* __restrict__ table, const unsigned* __restrict__ part,
-                                                   const unsigned* __restrict__ digit_base) {
-  __shared__ unsigned cnt[4][RD];   // per wave: running count of a digit, then the wave's base inside the digit's run of this tile
-  __shared__ unsigned s_first[RD];  // first tile-local position of a digit
-  __shared__ unsigned s_delta[RD];  // global position of the digit's run of this tile - s_first
-  __shared__ unsigned sh[4];
-  __shared__ K lk[TILE];
-  __shared__ unsigned lv[HASV ? TILE : 1];
+struct RsTile {
+  unsigned cnt[4][RD];  // per wave: running count of a digit, then the wave's base inside the digit's run of this tile
+  unsigned first[RD];
+  unsigned sh[4];
+  K lk[TILE];
+  unsigned lv[HASV ? TILE : 1];
+};
+template <typename K, bool HASV>
+__device__ inline void rs_tile_sort(RsTile<K, HASV>& T, const K (&key)[PI], const unsigned (&val)[PI], int here, int shift, unsigned mask) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long t0 = (long long)blockIdx.x * TILE;
-  const int here = n - t0 < (long long)TILE ? (int)(n - t0) : TILE;
 #pragma unroll
-  for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0u;
-  K key[PI];
-#pragma unroll
-  for (int k = 0; k < PI; k++) {
-    const long long i = t0 + (long long)(wave * PI + k) * 64 + lane;
-    key[k] = i < n ? kin[i] : (K)0;
-  }
+  for (int w = 0; w < 4; w++) T.cnt[w][threadIdx.x] = 0u;
   __syncthreads();
-  // rank of every item among the earlier items of its digit in this wave's chunk
   unsigned rk[PI];
 #pragma unroll
   for (int k = 0; k < PI; k++) {
@@ -260,44 +256,118 @@ __global__ __launch_bounds__(PT) void k_rs_scatter(const K* __restrict__ kin, co
     const int leader = valid ? (int)__ffsll(peers) - 1 : lane;
     unsigned base = 0;
     if (valid && lane == leader) {
-      base = cnt[wave][d];
-      cnt[wave][d] = base + (unsigned)__popcll(peers);
+      base = T.cnt[wave][d];
+      T.cnt[wave][d] = base + (unsigned)__popcll(peers);
     }
     base = __shfl(base, leader, 64);
     rk[k] = base + (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  {  // thread = digit: the waves' bases inside the digit's run, the run's place in the tile and in the output
+  {  // thread = digit: the waves' bases inside the digit's run, the run's place in the tile
     const int d = threadIdx.x;
-    const unsigned c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
-    cnt[0][d] = 0u; cnt[1][d] = c0; cnt[2][d] = c0 + c1; cnt[3][d] = c0 + c1 + c2;
+    const unsigned c0 = T.cnt[0][d], c1 = T.cnt[1][d], c2 = T.cnt[2][d], c3 = T.cnt[3][d];
+    T.cnt[0][d] = 0u; T.cnt[1][d] = c0; T.cnt[2][d] = c0 + c1; T.cnt[3][d] = c0 + c1 + c2;
     unsigned tot;
-    const unsigned first = block_excl_scan(c0 + c1 + c2 + c3, sh, &tot);
-    s_first[d] = first;
-    s_delta[d] = digit_base[d] + part[(size_t)(blockIdx.x / RC) * RD + d] + table[(size_t)blockIdx.x * RD + d] - first;
+    T.first[d] = block_excl_scan(c0 + c1 + c2 + c3, T.sh, &tot);
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PI; k++) {
-    const int q = (wave * PI + k) * 64 + lane;
-    if (q < here) {
+    if ((wave * PI + k) * 64 + lane < here) {
       const unsigned d = (unsigned)(key[k] >> shift) & mask;
-      const unsigned p = s_first[d] + cnt[wave][d] + rk[k];
-      lk[p] = key[k];
-      if (HASV) lv[p] = vin[t0 + q];
+      const unsigned p = T.first[d] + T.cnt[wave][d] + rk[k];
+      T.lk[p] = key[k];
+      if (HASV) T.lv[p] = val[k];
     }
   }
+  __syncthreads();
+}
+
+template <typename K, bool HASV>
+__global__ __launch_bounds__(PT) void k_rs_scatter(const K* __restrict__ kin, const unsigned* __restrict__ vin, K* __restrict__ kout, unsigned* __restrict__ vout,
+                                                   long long n, int shift, unsigned mask, const unsigned* __restrict__ table, const unsigned* __restrict__ part,
+                                                   const unsigned* __restrict__ digit_base) {
+  __shared__ RsTile<K, HASV> T;
+  __shared__ unsigned s_delta[RD];  // global position of the digit's run of this tile - its first position in the tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long t0 = (long long)blockIdx.x * TILE;
+  const int here = n - t0 < (long long)TILE ? (int)(n - t0) : TILE;
+  K key[PI];
+  unsigned val[PI];
+#pragma unroll
+  for (int k = 0; k < PI; k++) {
+    const long long i = t0 + (long long)(wave * PI + k) * 64 + lane;
+    key[k] = i < n ? kin[i] : (K)0;
+    val[k] = (HASV && i < n) ? vin[i] : 0u;
+  }
+  const unsigned run_at = digit_base[threadIdx.x] + part[(size_t)(blockIdx.x / RC) * RD + threadIdx.x] + table[(size_t)blockIdx.x * RD + threadIdx.x];  // thread = digit
+  rs_tile_sort<K, HASV>(T, key, val, here, shift, mask);
+  s_delta[threadIdx.x] = run_at - T.first[threadIdx.x];
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < PI; j++) {
     const int p = j * PT + threadIdx.x;
     if (p < here) {
-      const K kk = lk[p];
+      const K kk = T.lk[p];
       const unsigned pos = s_delta[(unsigned)(kk >> shift) & mask] + (unsigned)p;
       kout[pos] = kk;
-      if (HASV) vout[pos] = lv[p];
+      if (HASV) vout[pos] = T.lv[p];
     }
   }
+}
+
+// n <= TILE: every digit place in ONE launch of one workgroup (the single-cloud front end's NMS order, small grids): the items stay in
+// registers between the places and go through the tile once per place.
+template <typename K, bool HASV>
+__global__ __launch_bounds__(PT) void k_rs_small(const K* __restrict__ kin, const unsigned* __restrict__ vin, K* __restrict__ kout, unsigned* __restrict__ vout, int n,
+                                                 int bit_begin, int bit_end) {
+  __shared__ RsTile<K, HASV> T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  K key[PI];
+  unsigned val[PI];
+#pragma unroll
+  for (int k = 0; k < PI; k++) {
+    const int i = (wave * PI + k) * 64 + lane;
+    key[k] = i < n ? kin[i] : (K)0;
+    val[k] = (HASV && i < n) ? vin[i] : 0u;
+  }
+  for (int shift = bit_begin; shift < bit_end; shift += 8) {
+    const unsigned mask = (1u << (bit_end - shift < 8 ? bit_end - shift : 8)) - 1u;
+    rs_tile_sort<K, HASV>(T, key, val, n, shift, mask);
+    if (shift + 8 < bit_end) {
+#pragma unroll
+      for (int k = 0; k < PI; k++) {
+        const int i = (wave * PI + k) * 64 + lane;
+        if (i < n) {
+          key[k] = T.lk[i];
+          if (HASV) val[k] = T.lv[i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PI; j++) {
+    const int p = j * PT + threadIdx.x;
+    if (p < n) {
+      kout[p] = T.lk[p];
+      if (HASV) vout[p] = T.lv[p];
+    }
+  }
+}
+
+// nt <= RC: k_rs_chunks and k_rs_bases in one launch (one chunk: its base is 0)
+__global__ __launch_bounds__(RD) void k_rs_chunk_bases(unsigned* __restrict__ table, int nt, unsigned* __restrict__ part, unsigned* __restrict__ digit_base) {
+  __shared__ unsigned sh[4];
+  unsigned run = 0;
+#pragma unroll 8
+  for (int t = 0; t < nt; t++) {
+    const unsigned v = table[(size_t)t * RD + threadIdx.x];
+    table[(size_t)t * RD + threadIdx.x] = run;
+    run += v;
+  }
+  part[threadIdx.x] = 0u;
+  unsigned tot;
+  digit_base[threadIdx.x] = block_excl_scan(run, sh, &tot);
 }
 
 template <typename K>
@@ -309,6 +379,12 @@ int radix_sort_impl(ghicp_ctx* ctx, const K* kin, K* kout, const unsigned* vin, 
   if (passes == 0) {
     GH_HIP(hipMemcpyAsync(kout, kin, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, s));
     if (hasv) GH_HIP(hipMemcpyAsync(vout, vin, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+    return GHICP_OK;
+  }
+  if (n <= TILE) {
+    if (hasv) hipLaunchKernelGGL((k_rs_small<K, true>), dim3(1), dim3(PT), 0, s, kin, vin, kout, vout, (int)n, bit_begin, bit_end);
+    else hipLaunchKernelGGL((k_rs_small<K, false>), dim3(1), dim3(PT), 0, s, kin, (const unsigned*)nullptr, kout, (unsigned*)nullptr, (int)n, bit_begin, bit_end);
+    GH_HIP(hipGetLastError());
     return GHICP_OK;
   }
   const int nt = tiles_of(n), nchunk = (nt + RC - 1) / RC;
@@ -335,8 +411,11 @@ int radix_sort_impl(ghicp_ctx* ctx, const K* kin, K* kout, const unsigned* vin, 
     const int shift = bit_begin + 8 * p;
     const unsigned mask = (1u << std::min(8, bit_end - shift)) - 1u;
     hipLaunchKernelGGL((k_rs_hist<K>), dim3(nt), dim3(PT), 0, s, src_k, n, shift, mask, table);
-    hipLaunchKernelGGL(k_rs_chunks, dim3(nchunk), dim3(RD), 0, s, table, nt, part);
-    hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(RD), 0, s, part, nchunk, digit_base);
+    if (nchunk == 1) hipLaunchKernelGGL(k_rs_chunk_bases, dim3(1), dim3(RD), 0, s, table, nt, part, digit_base);
+    else {
+      hipLaunchKernelGGL(k_rs_chunks, dim3(nchunk), dim3(RD), 0, s, table, nt, part);
+      hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(RD), 0, s, part, nchunk, digit_base);
+    }
     if (hasv)
       hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(nt), dim3(PT), 0, s, src_k, src_v, dst_k, dst_v, n, shift, mask, (const unsigned*)table, (const unsigned*)part,
                          (const unsigned*)digit_base);
