@@ -1,4 +1,4 @@
-"""profiles/pmc_traffic.json from the two counter passes of the default command (scripts/r06_final.sh): HBM-side bytes per unit of work of the
+"""profiles/pmc_traffic.json from the two counter passes of the default command (scripts/r06_final2.sh): HBM-side bytes per unit of work of the
 dominant kernels, FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE (KB) as reported.
 usage: r06_pmc_traffic.py <FETCH summary> <WRITE summary> <pairs per step> <mean iterations> <out.json>"""
 import json
@@ -25,14 +25,14 @@ def main():
                 return v
         return (0, 0.0)
 
-    res = {"source": "profiles/r06_pmc_FETCH_SIZE.txt and profiles/r06_pmc_WRITE_SIZE.txt: two separate rocprofv3 --kernel-trace --pmc passes (scripts/r06_final.sh) of the DEFAULT "
+    res = {"source": "profiles/r06_pmc_FETCH_SIZE.txt and profiles/r06_pmc_WRITE_SIZE.txt: two separate rocprofv3 --kernel-trace --pmc passes (scripts/r06_final2.sh) of the DEFAULT "
                      "workload on the round-6 final tree (python bench.py --steps 1 --warmup 1 --cpu-baseline 0 --no-hints-steps 0); FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md "
                      "prescribes for gfx950 (calibrated for wide coalesced reads; an upper bound for the 16-byte gathers and scalar CSR reads here), WRITE_SIZE (KB) as reported "
                      "(uncalibrated).  Round 5, same method: pair_loop 24.7 MB per pair-iteration, pca_cells 26.7 MB and bsc 79.2 MB per cloud",
            "unit": "bytes per unit of work"}
     nd, fk = find(fetch, "k_pair_loop")
     _, wk = find(write, "k_pair_loop")
-    batches = max(1, (nd - 3) // 3)  # three class launches per batch + three single-pair runs (latency measurement)
+    batches = max(1, (nd - 3) // 2)  # two class launches per batch (round 6: the confined class and the other; the re-launch is gone) + three single-pair runs (latency measurement)
     pair_it = batches * pairs * it_mean
     res["pair_loop"] = {"per": "pair_iteration", "bytes": int((2 * fk + wk) * 1024 / pair_it), "dispatches": nd, "batches": batches}
     clouds = batches * pairs * 2 + 768  # + the front-end calibration (64 pairs x 2 passes x 3 shapes)
