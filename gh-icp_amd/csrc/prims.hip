@@ -169,7 +169,8 @@ int tiles_of(long long n) { return (int)((n + TILE - 1) / TILE); }
 //   k_rs_bases    one workgroup: chunk totals -> chunk bases per digit, digit totals -> digit bases
 //   k_rs_scatter  ranks inside the tile from wave ballots (items in input order: wave-contiguous chunks, a wave's rounds in turn), the
 //                 tile reordered by digit in LDS, then written out as runs -- consecutive threads store consecutive addresses of a run
-// (three launches up to 64 tiles: k_rs_chunk_bases; ONE launch for all places up to one tile: k_rs_small)
+// (three launches per place up to 64 tiles: k_rs_chunk_bases, and up to 32 chunks = 8 M items: the scatter sums the chunk rows itself; ONE launch for all
+// places up to one tile: k_rs_small)
 // No look-back, no spinning, no temporary-storage query; position-exact, so the result does not depend on the launch order of workgroups.
 constexpr int RD = 256;   // digits per place
 constexpr int RC = 64;    // tiles per chunk of k_rs_chunks
@@ -283,10 +284,13 @@ __device__ inline void rs_tile_sort(RsTile<K, HASV>& T, const K (&key)[PI], cons
   __syncthreads();
 }
 
-template <typename K, bool HASV>
+// BASES: the launch has no k_rs_bases before it (up to RS_INLINE_CHUNKS chunks): `part` holds the chunks' raw totals and every workgroup sums the
+// few rows it needs itself (thread = digit; the rows come out of L2) -- a launch less per digit place where launches are what a place costs.
+constexpr int RS_INLINE_CHUNKS = 32;
+template <typename K, bool HASV, bool BASES>
 __global__ __launch_bounds__(PT) void k_rs_scatter(const K* __restrict__ kin, const unsigned* __restrict__ vin, K* __restrict__ kout, unsigned* __restrict__ vout,
                                                    long long n, int shift, unsigned mask, const unsigned* __restrict__ table, const unsigned* __restrict__ part,
-                                                   const unsigned* __restrict__ digit_base) {
+                                                   const unsigned* __restrict__ digit_base, int nchunk) {
   __shared__ RsTile<K, HASV> T;
   __shared__ unsigned s_delta[RD];  // global position of the digit's run of this tile - its first position in the tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -300,7 +304,20 @@ __global__ __launch_bounds__(PT) void k_rs_scatter(const K* __restrict__ kin, co
     key[k] = i < n ? kin[i] : (K)0;
     val[k] = (HASV && i < n) ? vin[i] : 0u;
   }
-  const unsigned run_at = digit_base[threadIdx.x] + part[(size_t)(blockIdx.x / RC) * RD + threadIdx.x] + table[(size_t)blockIdx.x * RD + threadIdx.x];  // thread = digit
+  unsigned run_at = table[(size_t)blockIdx.x * RD + threadIdx.x];  // thread = digit
+  if (BASES) {
+    const int mine = (int)blockIdx.x / RC;
+    unsigned below = 0, total = 0;
+    for (int j = 0; j < nchunk; j++) {
+      const unsigned v = part[(size_t)j * RD + threadIdx.x];
+      total += v;
+      below += j < mine ? v : 0u;
+    }
+    unsigned tot;
+    run_at += below + block_excl_scan(total, T.sh, &tot);
+  } else {
+    run_at += digit_base[threadIdx.x] + part[(size_t)(blockIdx.x / RC) * RD + threadIdx.x];
+  }
   rs_tile_sort<K, HASV>(T, key, val, here, shift, mask);
   s_delta[threadIdx.x] = run_at - T.first[threadIdx.x];
   __syncthreads();
@@ -411,17 +428,21 @@ int radix_sort_impl(ghicp_ctx* ctx, const K* kin, K* kout, const unsigned* vin, 
     const int shift = bit_begin + 8 * p;
     const unsigned mask = (1u << std::min(8, bit_end - shift)) - 1u;
     hipLaunchKernelGGL((k_rs_hist<K>), dim3(nt), dim3(PT), 0, s, src_k, n, shift, mask, table);
+    const bool inline_bases = nchunk > 1 && nchunk <= RS_INLINE_CHUNKS;
     if (nchunk == 1) hipLaunchKernelGGL(k_rs_chunk_bases, dim3(1), dim3(RD), 0, s, table, nt, part, digit_base);
     else {
       hipLaunchKernelGGL(k_rs_chunks, dim3(nchunk), dim3(RD), 0, s, table, nt, part);
-      hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(RD), 0, s, part, nchunk, digit_base);
+      if (!inline_bases) hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(RD), 0, s, part, nchunk, digit_base);
     }
-    if (hasv)
-      hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(nt), dim3(PT), 0, s, src_k, src_v, dst_k, dst_v, n, shift, mask, (const unsigned*)table, (const unsigned*)part,
-                         (const unsigned*)digit_base);
-    else
-      hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(nt), dim3(PT), 0, s, src_k, (const unsigned*)nullptr, dst_k, (unsigned*)nullptr, n, shift, mask,
-                         (const unsigned*)table, (const unsigned*)part, (const unsigned*)digit_base);
+    const unsigned* tb = table;
+    const unsigned* pt = part;
+    const unsigned* db = digit_base;
+    const unsigned* nov = nullptr;
+    unsigned* novo = nullptr;
+    if (hasv && inline_bases) hipLaunchKernelGGL((k_rs_scatter<K, true, true>), dim3(nt), dim3(PT), 0, s, src_k, src_v, dst_k, dst_v, n, shift, mask, tb, pt, db, nchunk);
+    else if (hasv) hipLaunchKernelGGL((k_rs_scatter<K, true, false>), dim3(nt), dim3(PT), 0, s, src_k, src_v, dst_k, dst_v, n, shift, mask, tb, pt, db, nchunk);
+    else if (inline_bases) hipLaunchKernelGGL((k_rs_scatter<K, false, true>), dim3(nt), dim3(PT), 0, s, src_k, nov, dst_k, novo, n, shift, mask, tb, pt, db, nchunk);
+    else hipLaunchKernelGGL((k_rs_scatter<K, false, false>), dim3(nt), dim3(PT), 0, s, src_k, nov, dst_k, novo, n, shift, mask, tb, pt, db, nchunk);
     src_k = dst_k;
     src_v = dst_v;
   }
