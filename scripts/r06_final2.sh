@@ -39,6 +39,8 @@ timeout 400 python bench.py --config 14 --steps 4 --warmup 1 > $O/r06_bench_cfg1
 echo "bench cfg14 (cfg4 as surveyed) rc=$?"; tail -c 1200 $O/r06_bench_cfg14.json
 timeout 700 python bench.py --config 13 --steps 2 --warmup 1 --cpu-procs 16 > $O/r06_bench_cfg13.json 2> $O/r06_bench_cfg13.err
 echo "bench cfg13 (cfg3 as surveyed) rc=$?"; tail -c 1500 $O/r06_bench_cfg13.json
+timeout 900 python bench.py --config 3 --steps 2 --warmup 1 --cpu-procs 16 > $O/r06_bench_cfg3.json 2> $O/r06_bench_cfg3.err
+echo "bench cfg3 rc=$?"; tail -c 1500 $O/r06_bench_cfg3.json
 timeout 1500 python bench.py --config 5 --steps 1 --warmup 1 --pipeline 0 --cpu-procs 8 --scene-cache /tmp/scenes5 > $O/r06_bench_cfg5.json 2> $O/r06_bench_cfg5.err
 echo "bench cfg5 rc=$?"; tail -c 1500 $O/r06_bench_cfg5.json
 timeout 300 python scripts/dropin_time.py > $O/r06_dropin_time.out 2> $O/r06_dropin_time.err; echo "dropin rc=$?"; tail -c 600 $O/r06_dropin_time.out
