@@ -75,6 +75,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise GhicpError("libghicp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(or make -C gh-icp_amd/csrc). There is no CPU fallback.")
+        # torch BEFORE the library: libtorch_hip links the unversioned name "libamdhip64.so", which does not match the soname (libamdhip64.so.7) of a
+        # runtime that is already loaded, so with the library first the process ends up with TWO HIP runtimes and ghicp_ctx_create reports no GPU
+        # (build() followed by smoke() in one process did, round 6 call 25); with torch first the library's libamdhip64.so.7 resolves to torch's copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.ghicp_last_error.restype = C.c_char_p
         _lib.ghicp_version.restype = C.c_char_p
