@@ -282,6 +282,27 @@ def test_product_never_touches_the_oracle():
                     assert "ghicp_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
 
 
+def test_device_wide_primitives_are_the_librarys_own():
+    """Sort, scan, select and unique are hand-written (csrc/prims.hip): no kernel source includes rocPRIM / hipCUB / Thrust, and the built
+    library carries none of their kernels and depends on the HIP runtime only."""
+    import re
+    import subprocess
+
+    for dp, _, files in os.walk(os.path.join(ROOT, "gh-icp_amd", "csrc")):
+        for f in files:
+            if f.endswith((".hip", ".h")):
+                for line in open(os.path.join(dp, f), errors="ignore"):
+                    if line.lstrip().startswith("#include"):
+                        assert not re.search(r"hipcub|rocprim|thrust|cub/", line), (f, line)
+    lib = os.path.join(ROOT, "gh-icp_amd", "libghicp_hip.so")
+    if os.path.exists(lib):
+        blob = open(lib, "rb").read()
+        assert b"rocprim" not in blob and b"hipcub" not in blob
+        needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+        libs = re.findall(r"NEEDED.*\[(.*?)\]", needed)
+        assert libs and all(not re.search(r"rocprim|hipcub|rocblas|hipblas|rccl", n) for n in libs), libs
+
+
 def test_every_abi_struct_has_the_layout_the_bindings_assume(api, tmp_path):
     """sizeof / offsetof of every struct of include/ghicp_c.h as gcc lays it out, against the ctypes mirrors in api.py and
     the oracle's own structs (the parity tests pass the same parameter blocks to both sides)."""
